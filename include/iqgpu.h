@@ -1,0 +1,191 @@
+/*
+ * iqgpu.h -- C ABI of libiqgpu: the MI355X (gfx950) replacement for iq_tool's
+ * pre_processor -> resampler -> post_processor sample path.
+ *
+ * One `iqgpu_chain` handle stands in for the three DSP stage threads of the reference
+ * (/root/reference/src/pipeline.c:436-595) for ONE stream.  It is what a single "GPU stage"
+ * thread sitting between reader_output_queue and the writer would call; see INTEGRATION.md for
+ * the binding a maintainer adds on the reference side.
+ *
+ * Conventions (they mirror the reference's, src/pipeline.c / include/resampler.h):
+ *   - the caller owns every host buffer; handles are opaque; one thread per handle; handles are
+ *     independent (one per GPU shard);
+ *   - the stream is continuous across calls: any split of the input into calls produces the
+ *     same output bytes (all in-scope operators are chunk-size invariant);
+ *   - nothing is flushed at end of stream (resampler / FIR tails and the FFT-filter remainder
+ *     are dropped exactly as the reference drops them, src/filter.c:521-525);
+ *   - frames_out may be 0 (resampler group buffering, FFT block quantisation);
+ *   - every entry point returns 0 on success or a negative IQGPU_E* code, with a message
+ *     available from iqgpu_last_error().  There is no CPU fallback: without a usable HIP
+ *     device every compute entry point fails with IQGPU_ENODEV.
+ */
+#ifndef IQGPU_H_
+#define IQGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IQGPU_ABI_VERSION 1
+
+/* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
+enum {
+    IQGPU_FMT_CU8 = 8, IQGPU_FMT_CS8 = 9, IQGPU_FMT_CU16 = 10, IQGPU_FMT_CS16 = 11,
+    IQGPU_FMT_CS24 = 12, IQGPU_FMT_CU32 = 13, IQGPU_FMT_CS32 = 14, IQGPU_FMT_CF32 = 15,
+    IQGPU_FMT_SC16Q11 = 16
+};
+/* == FilterType (include/common_types.h:45-51) */
+enum { IQGPU_FILTER_NONE = 0, IQGPU_FILTER_LOWPASS = 1, IQGPU_FILTER_HIGHPASS = 2,
+       IQGPU_FILTER_PASSBAND = 3, IQGPU_FILTER_STOPBAND = 4 };
+/* == FilterTypeRequest (include/common_types.h:61-65) */
+enum { IQGPU_FILTER_IMPL_AUTO = 0, IQGPU_FILTER_IMPL_FIR = 1, IQGPU_FILTER_IMPL_FFT = 2 };
+/* == FilterImplementationType (include/common_types.h:53-59) */
+enum { IQGPU_FI_NONE = 0, IQGPU_FI_FIR_SYMMETRIC = 1, IQGPU_FI_FIR_ASYMMETRIC = 2,
+       IQGPU_FI_FFT_SYMMETRIC = 3, IQGPU_FI_FFT_ASYMMETRIC = 4 };
+
+enum {
+    IQGPU_OK = 0,
+    IQGPU_EINVAL = -1,      /* bad argument / NULL handle */
+    IQGPU_ENODEV = -2,      /* no HIP device, or device_ordinal out of range */
+    IQGPU_ENOMEM = -3,      /* device or host allocation failed */
+    IQGPU_ERATIO = -4,      /* ratio not finite or outside [1e-3, 1e3]   (src/setup.c:109-112) */
+    IQGPU_EFORMAT = -5,     /* unhandled sample format                    (src/sample_convert.c:203-206) */
+    IQGPU_ESHIFT = -6,      /* shift beyond 5x rate, or shift_after_resample without a shift (src/frequency_shift.c:36-49) */
+    IQGPU_EFILTER = -7,     /* filter band beyond output Nyquist, fft size too small, too many stages (src/filter.c:80-84, 321-325) */
+    IQGPU_ECAPACITY = -8,   /* out_capacity_bytes too small for this call */
+    IQGPU_EHIP = -9,        /* a HIP runtime call failed */
+    IQGPU_EUNSUPPORTED = -10/* configuration valid for the reference but not built yet */
+};
+
+typedef struct iqgpu_chain iqgpu_chain; /* opaque, like resampler_t (include/resampler.h:25-26) */
+
+typedef struct { int type; float f1_hz, f2_hz; } iqgpu_filter_req; /* == FilterRequest: f1 = cutoff or centre, f2 = bandwidth */
+
+/* Mirrors the AppConfig / AppResources fields the path reads (include/app_context.h:66-138). */
+typedef struct {
+    int    in_format, out_format;       /* IQGPU_FMT_*                                                      */
+    double input_rate_hz;               /* source_info.samplerate                                           */
+    double target_rate_hz;              /* config->target_rate; r = (float)(target/input)  src/setup.c:107  */
+    float  resample_ratio;              /* if > 0: use this float ratio as-is (create_resampler's argument,  */
+                                        /*   src/resampler.c:20) instead of deriving it from the rates      */
+    float  gain;                        /* config->gain, applied at unpack (src/pre_processor.c:21-22)      */
+    double shift_hz;                    /* resources->nco_shift_hz (sign selects mix up / down)             */
+    int    shift_after_resample;        /* config->shift_after_resample                                     */
+    int    dc_block_enable;             /* config->dc_block.enable                                          */
+    int    iq_correct_enable;           /* config->iq_correction.enable                                     */
+    float  iq_mag, iq_phase;            /* initial correction factors (reference starts at 0,0)             */
+    int    no_resample;                 /* config->no_resample                                              */
+    int    n_filters;                   /* config->num_filter_requests (<= 5)                               */
+    iqgpu_filter_req filters[5];        /* config->filter_requests                                          */
+    float  transition_width_hz;         /* config->transition_width_hz_arg (0 = auto)                       */
+    float  attenuation_db;              /* config->attenuation_db_arg (0 = 60 dB)                           */
+    int    filter_taps;                 /* config->filter_taps_arg AFTER the odd bump of src/config.c:233-236 (0 = auto) */
+    int    filter_impl;                 /* IQGPU_FILTER_IMPL_*  (config->filter_type_request)               */
+    int    fft_size;                    /* config->filter_fft_size_arg (0 = auto)                           */
+    /* GPU-only knobs */
+    int    device_ordinal;              /* HIP device index                                                 */
+    size_t block_samples;               /* input samples per workgroup block, multiple of 2048 (0 = 262144) */
+} iqgpu_chain_desc;
+
+/* What create() derived; for diagnostics and for parity tests of the design path. */
+typedef struct {
+    float    ratio;                     /* float32 resampling ratio                                         */
+    int      interp;                    /* 1 if ratio > 1                                                   */
+    int      num_halfband_stages;       /* S                                                                */
+    int      stage_m[16];               /* half-band semi-lengths in run order (highest rate first)         */
+    float    rate_arb;                  /* arbitrary-resampler rate                                         */
+    uint32_t arb_step;                  /* 24-bit fixed-point phase step                                    */
+    uint32_t nco_dtheta;                /* uint32 NCO phase increment                                       */
+    float    dc_alpha;                  /* float32 alpha of the DC blocker                                  */
+    int      filter_post_resample;      /* apply_user_filter_post_resample                                  */
+    int      filter_impl;               /* IQGPU_FI_*                                                       */
+    uint32_t filter_ntaps;
+    uint32_t filter_block;              /* fftfilt block size (0 for FIR)                                   */
+    uint32_t history_samples;           /* processed input samples kept between calls                       */
+} iqgpu_chain_info;
+
+/* Per-kernel device time accumulated by HIP events on the chain's stream (profiling mode only). */
+enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_COUNT = 8 };
+typedef struct {
+    uint64_t launches[IQGPU_K_COUNT];
+    double   ms[IQGPU_K_COUNT];
+} iqgpu_profile;
+
+/* ---- library ---- */
+int         iqgpu_abi_version(void);
+const char *iqgpu_last_error(void);              /* thread-local message of the last failure        */
+int         iqgpu_device_count(void);            /* number of HIP devices, 0 if none / no runtime   */
+
+/* ---- chain lifecycle: replaces _create_dsp_components/_destroy_dsp_components (src/pipeline.c:138-157) ---- */
+void   iqgpu_chain_desc_init(iqgpu_chain_desc *d);                 /* reference defaults: gain 1, cs16->cs16, no ops */
+int    iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out);
+void   iqgpu_chain_destroy(iqgpu_chain *c);
+int    iqgpu_chain_get_info(const iqgpu_chain *c, iqgpu_chain_info *info);
+/* copies min(cap, ntaps) complex taps (re,im interleaved) of the combined user filter; returns ntaps */
+int    iqgpu_chain_get_filter_taps(const iqgpu_chain *c, float *re_im, size_t cap_taps);
+/* The create-time design path alone (ratio, half-band plan, NCO increment, filter placement and
+ * taps) without touching a device: same validation and error codes as iqgpu_chain_create.
+ * filter_taps_re_im / hb_taps / arb_proto may be NULL.  hb_taps receives the 4m+1 prototype of
+ * every half-band stage back to back in run order; arb_proto the 3584 scaled polyphase taps. */
+int    iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *info,
+                          float *filter_taps_re_im, size_t cap_taps,
+                          float *hb_taps, size_t cap_hb, float *arb_proto, size_t cap_arb);
+
+/* ---- per-chunk: replaces pre_processor_apply_chain (src/pre_processor.c:10), resampler_execute
+ *      (include/resampler.h:48) and post_processor_apply_chain (src/post_processor.c:9) in one call ---- */
+int    iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t frames_in,
+                           void *out, size_t out_capacity_bytes, size_t *frames_out);
+/* Same, with both buffers already in device memory (HBM) of the chain's device.  Asynchronous on the
+ * chain's stream; *frames_out is exact on return (it is a closed form of the stream position). */
+int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                                  void *d_out, size_t out_capacity_bytes, size_t *frames_out);
+/* == pre_processor_reset + resampler_reset + post_processor_reset (stream discontinuity) */
+int    iqgpu_chain_reset(iqgpu_chain *c);
+/* what the I/Q optimiser thread publishes (src/iq_correct.c:141-152 reads them once per chunk) */
+int    iqgpu_chain_set_iq_factors(iqgpu_chain *c, float mag, float phase);
+/* upper bound on frames_out for a call with frames_in frames (>= ceil(n*max(1,r))+128 (+ FFT block),
+ * the reference's buffer rule src/pipeline.c:246-258) */
+size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames_in);
+/* exact number of frames the NEXT call with frames_in frames will produce */
+size_t iqgpu_chain_next_out_frames(const iqgpu_chain *c, size_t frames_in);
+
+/* ---- stream / profiling plumbing ---- */
+int    iqgpu_chain_set_stream(iqgpu_chain *c, void *hip_stream);   /* hipStream_t; NULL = chain's own stream */
+void  *iqgpu_chain_get_stream(const iqgpu_chain *c);
+int    iqgpu_chain_synchronize(iqgpu_chain *c);
+int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets every launch with HIP events  */
+int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
+
+/* ---- operator-level entry points (same kernels, one operator enabled) ----
+ * Names follow the reference functions they replace. Host buffers. */
+size_t iqgpu_get_bytes_per_sample(int format);                                  /* get_bytes_per_sample, src/sample_convert.c:102 */
+int    iqgpu_convert_block_to_cf32(const void *in, float *out_re_im, size_t frames,
+                                   int in_format, float gain, int device);       /* convert_block_to_cf32, src/sample_convert.c:127 */
+int    iqgpu_convert_cf32_to_block(const float *in_re_im, void *out, size_t frames,
+                                   int out_format, int device);                  /* convert_cf32_to_block, src/sample_convert.c:213 */
+
+/* ---- device memory helpers for hosts that have no HIP binding of their own (harness, ctypes) ---- */
+int    iqgpu_device_malloc(int device, size_t bytes, void **d_ptr);
+int    iqgpu_device_free(int device, void *d_ptr);
+int    iqgpu_host_malloc_pinned(size_t bytes, void **h_ptr);
+int    iqgpu_host_free_pinned(void *h_ptr);
+int    iqgpu_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+int    iqgpu_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+int    iqgpu_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *hip_stream);
+int    iqgpu_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *hip_stream);
+int    iqgpu_stream_create(int device, void **hip_stream);
+int    iqgpu_stream_destroy(void *hip_stream);
+int    iqgpu_stream_synchronize(void *hip_stream);
+int    iqgpu_event_create(void **hip_event);
+int    iqgpu_event_destroy(void *hip_event);
+int    iqgpu_event_record(void *hip_event, void *hip_stream);
+int    iqgpu_stream_wait_event(void *hip_stream, void *hip_event);
+int    iqgpu_event_elapsed_ms(void *start_event, void *stop_event, float *ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQGPU_H_ */

@@ -1,0 +1,123 @@
+"""ctypes loader for libiqgpu.so.  Fails loudly when the HIP library is missing: there is no
+CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libiqgpu.so")
+
+FMT = dict(cu8=8, cs8=9, cu16=10, cs16=11, cs24=12, cu32=13, cs32=14, cf32=15, sc16q11=16)
+FMT_NAME = {v: k for k, v in FMT.items()}
+BYTES_PER_FRAME = {8: 2, 9: 2, 10: 4, 11: 4, 16: 4, 12: 6, 13: 8, 14: 8, 15: 8}
+FILTER = dict(none=0, lowpass=1, highpass=2, passband=3, stopband=4)
+FILTER_IMPL = dict(auto=0, fir=1, fft=2)
+K_NAMES = ("dc_prefix", "dc_scan", "front", "filter", "move")
+
+ERRORS = {0: "OK", -1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ERATIO", -5: "EFORMAT", -6: "ESHIFT",
+          -7: "EFILTER", -8: "ECAPACITY", -9: "EHIP", -10: "EUNSUPPORTED"}
+
+
+class FilterReq(C.Structure):
+    _fields_ = [("type", C.c_int), ("f1_hz", C.c_float), ("f2_hz", C.c_float)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("in_format", C.c_int), ("out_format", C.c_int),
+                ("input_rate_hz", C.c_double), ("target_rate_hz", C.c_double),
+                ("resample_ratio", C.c_float), ("gain", C.c_float),
+                ("shift_hz", C.c_double), ("shift_after_resample", C.c_int),
+                ("dc_block_enable", C.c_int),
+                ("iq_correct_enable", C.c_int), ("iq_mag", C.c_float), ("iq_phase", C.c_float),
+                ("no_resample", C.c_int),
+                ("n_filters", C.c_int), ("filters", FilterReq * 5),
+                ("transition_width_hz", C.c_float), ("attenuation_db", C.c_float),
+                ("filter_taps", C.c_int), ("filter_impl", C.c_int), ("fft_size", C.c_int),
+                ("device_ordinal", C.c_int), ("block_samples", C.c_size_t)]
+
+
+class ChainInfo(C.Structure):
+    _fields_ = [("ratio", C.c_float), ("interp", C.c_int), ("num_halfband_stages", C.c_int),
+                ("stage_m", C.c_int * 16), ("rate_arb", C.c_float), ("arb_step", C.c_uint32),
+                ("nco_dtheta", C.c_uint32), ("dc_alpha", C.c_float),
+                ("filter_post_resample", C.c_int), ("filter_impl", C.c_int),
+                ("filter_ntaps", C.c_uint32), ("filter_block", C.c_uint32),
+                ("history_samples", C.c_uint32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * 8), ("ms", C.c_double * 8)]
+
+
+class IqgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libiqgpu %s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+
+
+# every symbol include/iqgpu.h declares: (name, restype, argtypes)
+_vp, _sz = C.c_void_p, C.c_size_t
+SYMBOLS = [
+    ("iqgpu_abi_version", C.c_int, []),
+    ("iqgpu_last_error", C.c_char_p, []),
+    ("iqgpu_device_count", C.c_int, []),
+    ("iqgpu_chain_desc_init", None, [C.POINTER(ChainDesc)]),
+    ("iqgpu_chain_create", C.c_int, [C.POINTER(ChainDesc), C.POINTER(_vp)]),
+    ("iqgpu_chain_destroy", None, [_vp]),
+    ("iqgpu_chain_get_info", C.c_int, [_vp, C.POINTER(ChainInfo)]),
+    ("iqgpu_chain_get_filter_taps", C.c_int, [_vp, _vp, _sz]),
+    ("iqgpu_design_probe", C.c_int, [C.POINTER(ChainDesc), C.POINTER(ChainInfo), _vp, _sz, _vp, _sz, _vp, _sz]),
+    ("iqgpu_chain_process", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("iqgpu_chain_process_device", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("iqgpu_chain_reset", C.c_int, [_vp]),
+    ("iqgpu_chain_set_iq_factors", C.c_int, [_vp, C.c_float, C.c_float]),
+    ("iqgpu_chain_max_out_frames", _sz, [_vp, _sz]),
+    ("iqgpu_chain_next_out_frames", _sz, [_vp, _sz]),
+    ("iqgpu_chain_set_stream", C.c_int, [_vp, _vp]),
+    ("iqgpu_chain_get_stream", _vp, [_vp]),
+    ("iqgpu_chain_synchronize", C.c_int, [_vp]),
+    ("iqgpu_chain_set_profiling", C.c_int, [_vp, C.c_int]),
+    ("iqgpu_chain_get_profile", C.c_int, [_vp, C.POINTER(Profile)]),
+    ("iqgpu_get_bytes_per_sample", _sz, [C.c_int]),
+    ("iqgpu_convert_block_to_cf32", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_float, C.c_int]),
+    ("iqgpu_convert_cf32_to_block", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int]),
+    ("iqgpu_device_malloc", C.c_int, [C.c_int, _sz, C.POINTER(_vp)]),
+    ("iqgpu_device_free", C.c_int, [C.c_int, _vp]),
+    ("iqgpu_host_malloc_pinned", C.c_int, [_sz, C.POINTER(_vp)]),
+    ("iqgpu_host_free_pinned", C.c_int, [_vp]),
+    ("iqgpu_memcpy_h2d", C.c_int, [C.c_int, _vp, _vp, _sz]),
+    ("iqgpu_memcpy_d2h", C.c_int, [C.c_int, _vp, _vp, _sz]),
+    ("iqgpu_memcpy_h2d_async", C.c_int, [_vp, _vp, _sz, _vp]),
+    ("iqgpu_memcpy_d2h_async", C.c_int, [_vp, _vp, _sz, _vp]),
+    ("iqgpu_stream_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("iqgpu_stream_destroy", C.c_int, [_vp]),
+    ("iqgpu_stream_synchronize", C.c_int, [_vp]),
+    ("iqgpu_event_create", C.c_int, [C.POINTER(_vp)]),
+    ("iqgpu_event_destroy", C.c_int, [_vp]),
+    ("iqgpu_event_record", C.c_int, [_vp, _vp]),
+    ("iqgpu_stream_wait_event", C.c_int, [_vp, _vp]),
+    ("iqgpu_event_elapsed_ms", C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+]
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if libiqgpu.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libiqgpu.so is missing at %s -- run `python -m iq_tool_amd.build` (needs hipcc). "
+                "iq_tool_amd has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IqgpuError(rc, load().iqgpu_last_error().decode("utf-8", "replace"))

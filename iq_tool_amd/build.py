@@ -1,0 +1,56 @@
+"""Builds libiqgpu.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m iq_tool_amd.build
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libiqgpu.so")
+SOURCES = ["design.cpp", "iqgpu_api.cpp", "kernels.hip"]
+HEADERS = ["design.hpp", "kernels.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
+HARNESS_SRC = os.path.join(CSRC, "harness", "iqgpu_run.c")
+HARNESS_BIN = os.path.join(LIBDIR, "iqgpu_run")
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libiqgpu cannot be built (no CPU fallback exists)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB, deps):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               *srcs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    if os.path.exists(HARNESS_SRC) and (force or _stale(HARNESS_BIN, [HARNESS_SRC, LIB])):
+        cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(HERE, "..", "include"),
+               HARNESS_SRC, "-o", HARNESS_BIN, "-L", LIBDIR, "-liqgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

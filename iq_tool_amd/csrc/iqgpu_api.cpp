@@ -1,0 +1,779 @@
+// iqgpu_api.cpp -- the C ABI of libiqgpu (include/iqgpu.h): chain lifecycle, stream-position
+// bookkeeping and kernel launches.  No CPU compute path exists here: every entry point that moves
+// samples launches the gfx950 kernels of kernels.hip or fails.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/iqgpu.h"
+#include "design.hpp"
+#include "kernels.hpp"
+
+using namespace iqgpu;
+
+// ------------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(IQGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+static size_t bytes_per_frame(int fmt)
+{
+    switch (fmt) { // get_bytes_per_sample, src/sample_convert.c:102-122 (complex formats)
+    case IQGPU_FMT_CS8: case IQGPU_FMT_CU8: return 2;
+    case IQGPU_FMT_CS16: case IQGPU_FMT_CU16: case IQGPU_FMT_SC16Q11: return 4;
+    case IQGPU_FMT_CS24: return 6;
+    case IQGPU_FMT_CS32: case IQGPU_FMT_CU32: case IQGPU_FMT_CF32: return 8;
+    default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the chain object
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return IQGPU_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return fail(IQGPU_ENOMEM, "hipMalloc(%zu) failed", want); }
+        cap = want;
+        return IQGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct iqgpu_chain {
+    iqgpu_chain_desc desc;
+    int device = 0;
+    float ratio = 1.0f;
+    double target_rate = 0.0;
+    bool resample = false;
+    ResamplePlan rp;
+    FilterPlan fp;
+    // operator constants
+    bool dc = false; float dc_alpha = 0.0f, dc_c = 1.0f; double dc_logc = 0.0;
+    float iq_mag = 0.0f, iq_phase = 0.0f;
+    int nco_mode = 0, pnco_mode = 0; uint32_t nco_dtheta = 0;
+    // geometry
+    int S = 0, D = 1, TG = kTile;
+    int warm_tiles = 0, hist_cap = 0, tiles_per_block = 128;
+    uint32_t n_est = 0;
+    int lvl_off[kMaxS + 2] = {0};
+    int tap_off[kMaxS] = {0};
+    int n_hb_taps = 0;
+    // stream position (since the last reset)
+    int rem = 0;                 // samples of the open group
+    uint64_t phi = 0;            // phase of the next output relative to the next group
+    uint32_t nco_theta = 0;      // pre-NCO phase of the next input sample
+    uint32_t pnco_theta = 0;     // post-NCO phase of the next output sample
+    uint64_t fpending = 0;       // FFT-mode filter input samples not yet emitted
+    // device state
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    cf2 *d_nco_tab = nullptr; float *d_arb = nullptr; float *d_hb = nullptr; cf2 *d_ftaps = nullptr;
+    cf2 *d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
+    cd2 *d_dc_state = nullptr;
+    DevBuf dc_agg, dc_carry;
+    DevBuf fbuf[2]; int fcur = 0;
+    DevBuf stage_in, stage_out;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+    std::vector<hipEvent_t> event_pool;
+    iqgpu_profile prof{};
+};
+
+// ------------------------------------------------------------------------------------------------
+// library-level
+// ------------------------------------------------------------------------------------------------
+extern "C" int iqgpu_abi_version(void) { return IQGPU_ABI_VERSION; }
+extern "C" const char *iqgpu_last_error(void) { return g_err; }
+
+extern "C" int iqgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" size_t iqgpu_get_bytes_per_sample(int format) { return bytes_per_frame(format); }
+
+extern "C" void iqgpu_chain_desc_init(iqgpu_chain_desc *d)
+{
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    d->in_format = IQGPU_FMT_CS16;
+    d->out_format = IQGPU_FMT_CS16;
+    d->gain = 1.0f;              // src/main.c:145
+    d->no_resample = 0;
+    d->block_samples = 262144;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+static void free_device_state(iqgpu_chain *c)
+{
+    (void)hipSetDevice(c->device);
+    if (c->d_nco_tab) (void)hipFree(c->d_nco_tab);
+    if (c->d_arb) (void)hipFree(c->d_arb);
+    if (c->d_hb) (void)hipFree(c->d_hb);
+    if (c->d_ftaps) (void)hipFree(c->d_ftaps);
+    for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
+    if (c->d_dc_state) (void)hipFree(c->d_dc_state);
+    c->dc_agg.release(); c->dc_carry.release();
+    c->fbuf[0].release(); c->fbuf[1].release();
+    c->stage_in.release(); c->stage_out.release();
+    for (auto &pe : c->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+template <typename T>
+static int upload(T **dst, const T *src, size_t n)
+{
+    if (n == 0) { *dst = nullptr; return IQGPU_OK; }
+    if (hipMalloc((void **)dst, n * sizeof(T)) != hipSuccess) return fail(IQGPU_ENOMEM, "hipMalloc(%zu) failed", n * sizeof(T));
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return IQGPU_OK;
+}
+
+// Everything create() derives on the host: validation (the reference's fatal paths), ratio,
+// operator constants, resampler / filter plans and launch geometry.  Touches no device.
+static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
+{
+    if (!bytes_per_frame(d->in_format)) return fail(IQGPU_EFORMAT, "Unhandled input format: %d", d->in_format);
+    if (!bytes_per_frame(d->out_format)) return fail(IQGPU_EFORMAT, "Unhandled output format: %d", d->out_format);
+    if (!(d->input_rate_hz > 0.0) && !(d->resample_ratio > 0.0f) && !d->no_resample)
+        return fail(IQGPU_EINVAL, "input_rate_hz must be positive");
+    c->desc = *d;
+    c->device = d->device_ordinal;
+
+    // ---- ratio (src/setup.c:91-122) ----
+    const double in_rate = d->input_rate_hz > 0.0 ? d->input_rate_hz : 1.0;
+    c->target_rate = d->no_resample ? in_rate : d->target_rate_hz;
+    if (d->resample_ratio > 0.0f && !d->no_resample) {
+        c->ratio = d->resample_ratio;
+        if (!(d->target_rate_hz > 0.0)) c->target_rate = in_rate * (double)c->ratio;
+    } else {
+        c->ratio = (float)(c->target_rate / in_rate);
+    }
+    if (!std::isfinite(c->ratio) || c->ratio < 0.001f || c->ratio > 1000.0f) return fail(IQGPU_ERATIO, "Calculated resampling ratio (%.6f) is invalid or outside acceptable range.", (double)c->ratio);
+    c->resample = !d->no_resample;
+
+    // ---- dc blocker (src/dc_block.c:32) ----
+    if (d->dc_block_enable) {
+        c->dc = true;
+        c->dc_alpha = (float)(2.0 * 3.14159265358979323846 * 10.0f / in_rate);
+        if (!(c->dc_alpha > 0.0f)) return fail(IQGPU_EINVAL, "DC Block: Calculated normalized alpha is invalid.");
+        const float a1 = -1.0f + c->dc_alpha;       // liquid: a = {1, -1 + alpha}
+        c->dc_c = -a1;
+        c->dc_logc = std::log((double)c->dc_c);
+    }
+    c->iq_mag = d->iq_mag; c->iq_phase = d->iq_phase;
+
+    // ---- frequency shift (src/frequency_shift.c:24-81) ----
+    if (d->shift_after_resample && std::fabs(d->shift_hz) < 1e-9) return fail(IQGPU_ESHIFT, "Option --shift-after-resample was used, but no effective frequency shift was requested or calculated.");
+    if (std::fabs(d->shift_hz) >= 1e-9) {
+        const double rate = d->shift_after_resample ? c->target_rate : in_rate;
+        if (std::fabs(d->shift_hz) > 5.0 * rate) return fail(IQGPU_ESHIFT, "Requested frequency shift %.2f Hz exceeds sanity limit for the rate of %.1f Hz.", d->shift_hz, rate);
+        const float w = (float)(2.0 * 3.14159265358979323846 * std::fabs(d->shift_hz) / rate);
+        c->nco_dtheta = nco_constrain(w);
+        const int mode = d->shift_hz >= 0 ? +1 : -1;
+        if (d->shift_after_resample) c->pnco_mode = mode; else c->nco_mode = mode;
+    }
+
+    // ---- resampler (src/resampler.c:20-34, 60 dB include/constants.h:137) ----
+    std::string err;
+    if (c->resample) {
+        if (!make_resample_plan(c->ratio, 60.0f, c->rp, err)) return fail(IQGPU_ERATIO, "%s", err.c_str());
+        if (c->rp.interp) return fail(IQGPU_EUNSUPPORTED, "interpolating ratios (r > 1) are not built yet (ratio %.6f)", (double)c->ratio);
+        if (c->rp.S >= kMaxS) return fail(IQGPU_ERATIO, "too many half-band stages");
+        c->S = c->rp.S;
+    }
+    c->D = 1 << c->S;
+    c->TG = kTile >> c->S;
+
+    // ---- user filter (src/filter.c:138-393) ----
+    {
+        int rc = make_filter_plan(*d, in_rate, c->target_rate, c->fp, err);
+        if (rc != IQGPU_OK) return fail(rc, "%s", err.c_str());
+        if (c->fp.enabled && c->resample && !c->fp.post_resample)
+            return fail(IQGPU_EUNSUPPORTED, "pre-resample user filter together with a resampler is not built yet");
+    }
+
+    // ---- geometry ----
+    size_t block = d->block_samples ? d->block_samples : 262144;
+    if (block % kTile != 0 || block == 0) return fail(IQGPU_EINVAL, "block_samples must be a multiple of %d", kTile);
+    c->tiles_per_block = (int)(block / kTile);
+    if (c->resample) {
+        c->warm_tiles = (int)((c->rp.history_in + kTile - 1) / kTile);
+        if (c->warm_tiles < 1) c->warm_tiles = 1;
+        c->hist_cap = c->warm_tiles * kTile + c->D;
+        int off = 0;
+        for (int i = 0; i <= c->S; ++i) {
+            const int H = (i < c->S) ? 4 * c->rp.stages[(size_t)i].m : kArbHist;
+            c->lvl_off[i] = off;
+            off += H + (kTile >> i);
+            off = (off + 1) & ~1;
+        }
+        c->lvl_off[c->S + 1] = off;
+        c->n_est = (uint32_t)((((uint64_t)c->TG) << 24) / c->rp.step);
+    } else {
+        c->warm_tiles = 0; c->hist_cap = 0;
+        c->lvl_off[0] = 0; c->lvl_off[1] = 0;
+    }
+
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
+{
+    if (!d || !out) return fail(IQGPU_EINVAL, "iqgpu_chain_create: NULL argument");
+    *out = nullptr;
+    iqgpu_chain *c = new (std::nothrow) iqgpu_chain();
+    if (!c) return fail(IQGPU_ENOMEM, "out of host memory");
+    { const int drc = design_chain(c, d); if (drc != IQGPU_OK) { delete c; return drc; } }
+
+    // ---- device ----
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { int rc = fail(IQGPU_ENODEV, "no HIP device available"); delete c; return rc; }
+    if (c->device < 0 || c->device >= ndev) { int rc = fail(IQGPU_ENODEV, "device_ordinal %d out of range (%d devices)", c->device, ndev); delete c; return rc; }
+    int rc = IQGPU_OK;
+#define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(IQGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto bad; } } while (0)
+#define CREATE_RC(expr) do { rc = (expr); if (rc != IQGPU_OK) goto bad; } while (0)
+    {
+        CREATE_TRY(hipSetDevice(c->device));
+        CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        std::vector<cfloat> tab(1024);
+        nco_fill_sincos(tab.data());
+        CREATE_RC(upload(&c->d_nco_tab, (const cf2 *)tab.data(), 1024));
+        if (c->resample) {
+            CREATE_RC(upload(&c->d_arb, c->rp.arb_table.data(), c->rp.arb_table.size()));
+            std::vector<float> hb;
+            for (int i = 0; i < c->S; ++i) {
+                c->tap_off[i] = (int)hb.size();
+                for (float v : c->rp.stages[(size_t)i].branch) hb.push_back(0.5f * v);   // per-stage gain 1/2 (exact)
+            }
+            c->n_hb_taps = (int)hb.size();
+            if (hb.empty()) hb.push_back(0.0f);
+            CREATE_RC(upload(&c->d_hb, hb.data(), hb.size()));
+            for (int i = 0; i < 2; ++i) {
+                CREATE_TRY(hipMalloc((void **)&c->d_hist[i], (size_t)c->hist_cap * sizeof(cf2)));
+                CREATE_TRY(hipMemset(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2)));
+            }
+        }
+        if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
+        CREATE_TRY(hipMalloc((void **)&c->d_dc_state, sizeof(cd2)));
+        CREATE_TRY(hipMemset(c->d_dc_state, 0, sizeof(cd2)));
+        if (c->fp.enabled) {
+            // the filter-input buffer starts as ntaps-1 zeros of history
+            const size_t h = c->fp.taps.size() - 1;
+            for (int i = 0; i < 2; ++i) {
+                CREATE_RC(c->fbuf[i].ensure((h + 1) * sizeof(cf2)));
+                CREATE_TRY(hipMemset(c->fbuf[i].p, 0, c->fbuf[i].cap));
+            }
+        }
+        CREATE_TRY(hipDeviceSynchronize());
+    }
+    *out = c;
+    return IQGPU_OK;
+bad:
+    free_device_state(c);
+    delete c;
+    return rc;
+#undef CREATE_TRY
+#undef CREATE_RC
+}
+
+extern "C" void iqgpu_chain_destroy(iqgpu_chain *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_device_state(c);
+    delete c;
+}
+
+static void fill_info(const iqgpu_chain *c, iqgpu_chain_info *info);
+
+extern "C" int iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *info,
+                                  float *filter_taps_re_im, size_t cap_taps,
+                                  float *hb_taps, size_t cap_hb, float *arb_proto, size_t cap_arb)
+{
+    if (!d || !info) return fail(IQGPU_EINVAL, "iqgpu_design_probe: NULL argument");
+    iqgpu_chain *c = new (std::nothrow) iqgpu_chain();
+    if (!c) return fail(IQGPU_ENOMEM, "out of host memory");
+    const int rc = design_chain(c, d);
+    if (rc == IQGPU_OK) {
+        fill_info(c, info);
+        if (filter_taps_re_im) {
+            const size_t n = c->fp.taps.size() < cap_taps ? c->fp.taps.size() : cap_taps;
+            memcpy(filter_taps_re_im, c->fp.taps.data(), n * sizeof(cfloat));
+        }
+        if (hb_taps) {
+            size_t o = 0;
+            for (int i = 0; i < c->S; ++i)
+                for (float v : c->rp.stages[(size_t)i].proto) { if (o < cap_hb) hb_taps[o] = v; ++o; }
+        }
+        if (arb_proto && c->resample) {
+            const size_t n = c->rp.arb_proto.size() < cap_arb ? c->rp.arb_proto.size() : cap_arb;
+            memcpy(arb_proto, c->rp.arb_proto.data(), n * sizeof(float));
+        }
+    }
+    delete c;
+    return rc;
+}
+
+extern "C" int iqgpu_chain_get_info(const iqgpu_chain *c, iqgpu_chain_info *info)
+{
+    if (!c || !info) return fail(IQGPU_EINVAL, "iqgpu_chain_get_info: NULL argument");
+    fill_info(c, info);
+    return IQGPU_OK;
+}
+
+static void fill_info(const iqgpu_chain *c, iqgpu_chain_info *info)
+{
+    memset(info, 0, sizeof(*info));
+    info->ratio = c->ratio;
+    info->interp = c->rp.interp ? 1 : 0;
+    info->num_halfband_stages = c->S;
+    for (int i = 0; i < c->S && i < 16; ++i) info->stage_m[i] = c->rp.stages[(size_t)i].m;
+    info->rate_arb = c->rp.rate_arb;
+    info->arb_step = c->rp.step;
+    info->nco_dtheta = c->nco_dtheta;
+    info->dc_alpha = c->dc_alpha;
+    info->filter_post_resample = c->fp.post_resample ? 1 : 0;
+    info->filter_impl = c->fp.impl;
+    info->filter_ntaps = (uint32_t)c->fp.taps.size();
+    info->filter_block = c->fp.block;
+    info->history_samples = (uint32_t)c->hist_cap;
+}
+
+extern "C" int iqgpu_chain_get_filter_taps(const iqgpu_chain *c, float *re_im, size_t cap_taps)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    const size_t n = c->fp.taps.size();
+    if (re_im) memcpy(re_im, c->fp.taps.data(), (n < cap_taps ? n : cap_taps) * sizeof(cfloat));
+    return (int)n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream-position arithmetic (closed forms; SPEC B.6)
+// ------------------------------------------------------------------------------------------------
+struct CallPlan {
+    int64_t n_groups = 0;      // complete 2^S groups this call
+    int64_t n_res = 0;         // resampler (or pass-through) outputs this call
+    int64_t n_emit = 0;        // frames written to the caller
+    uint64_t phi_next = 0;
+    int rem_next = 0;
+    uint64_t fpending_next = 0;
+};
+
+static CallPlan plan_call(const iqgpu_chain *c, size_t frames_in)
+{
+    CallPlan p;
+    if (c->resample) {
+        const uint64_t avail = (uint64_t)c->rem + frames_in;
+        p.n_groups = (int64_t)(avail >> c->S);
+        p.rem_next = (int)(avail & (uint64_t)(c->D - 1));
+        const uint64_t span = (uint64_t)p.n_groups << 24;
+        const uint64_t step = c->rp.step;
+        if (span > c->phi) { p.n_res = (int64_t)((span - c->phi + step - 1) / step); p.phi_next = c->phi + (uint64_t)p.n_res * step - span; }
+        else { p.n_res = 0; p.phi_next = c->phi - span; }
+    } else {
+        p.n_res = (int64_t)frames_in;
+    }
+    if (c->fp.enabled && c->fp.block) { // src/filter.c:503-525
+        const uint64_t total = c->fpending + (uint64_t)p.n_res;
+        p.n_emit = (int64_t)((total / c->fp.block) * c->fp.block);
+        p.fpending_next = total - (uint64_t)p.n_emit;
+    } else {
+        p.n_emit = p.n_res;
+    }
+    return p;
+}
+
+extern "C" size_t iqgpu_chain_next_out_frames(const iqgpu_chain *c, size_t frames_in)
+{
+    if (!c) return 0;
+    return (size_t)plan_call(c, frames_in).n_emit;
+}
+
+extern "C" size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames_in)
+{
+    if (!c) return 0;
+    // src/pipeline.c:246-258, generalised from PIPELINE_CHUNK_BASE_SAMPLES to frames_in
+    double r = c->resample ? (double)c->ratio : 1.0;
+    if (r < 1.0) r = 1.0;
+    size_t cap = (size_t)std::ceil((double)frames_in * r) + 128;
+    if (cap < frames_in) cap = frames_in;
+    if (c->fp.enabled && c->fp.block) cap += c->fp.block;
+    return cap;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling helpers
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t get_event(iqgpu_chain *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct KernelTimer {
+    iqgpu_chain *c; int kind; hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(iqgpu_chain *c_, int kind_) : c(c_), kind(kind_)
+    {
+        if (c->profiling) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~KernelTimer()
+    {
+        if (c->profiling) { (void)hipEventRecord(b, c->stream); c->pending_events.push_back({kind, {a, b}}); }
+    }
+};
+
+static void drain_events(iqgpu_chain *c)
+{
+    for (auto &pe : c->pending_events) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(pe.second.second);
+        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+            c->prof.ms[pe.first] += (double)ms;
+            c->prof.launches[pe.first] += 1;
+        }
+        c->event_pool.push_back(pe.second.first);
+        c->event_pool.push_back(pe.second.second);
+    }
+    c->pending_events.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// process
+// ------------------------------------------------------------------------------------------------
+extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                                          void *d_out, size_t out_capacity_bytes, size_t *frames_out)
+{
+    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
+    *frames_out = 0;
+    if (frames_in == 0) return IQGPU_OK;
+    if (!d_raw_in || !d_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL buffer");
+    if (frames_in > ((size_t)1 << 40)) return fail(IQGPU_EINVAL, "frames_in too large");
+    HIP_TRY(hipSetDevice(c->device));
+
+    const CallPlan p = plan_call(c, frames_in);
+    const size_t obps = bytes_per_frame(c->desc.out_format);
+    if ((size_t)p.n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", (size_t)p.n_emit * obps, out_capacity_bytes);
+
+    const bool filt = c->fp.enabled;
+    const size_t L1 = filt ? c->fp.taps.size() - 1 : 0;
+
+    // ---- geometry of this call ----
+    const int64_t span_samples = (int64_t)c->rem + (int64_t)frames_in;
+    const int64_t total_tiles = (span_samples + kTile - 1) / kTile;
+    int n_blocks = (int)((total_tiles + c->tiles_per_block - 1) / c->tiles_per_block);
+    if (n_blocks < 1) n_blocks = 1;
+
+    // ---- dc-blocker carries ----
+    if (c->dc) {
+        int rc = c->dc_agg.ensure((size_t)n_blocks * sizeof(cf2)); if (rc) return rc;
+        rc = c->dc_carry.ensure((size_t)n_blocks * sizeof(cd2)); if (rc) return rc;
+        DcPrefixArgs pa{};
+        pa.raw = d_raw_in; pa.frames_in = (int64_t)frames_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
+        pa.c = c->dc_c; pa.logc = c->dc_logc;
+        pa.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
+        pa.seg_len = (int64_t)c->tiles_per_block * kTile;
+        pa.n_seg = n_blocks; pa.agg = (cf2 *)c->dc_agg.p;
+        { KernelTimer kt(c, IQGPU_K_DC_PREFIX); HIP_TRY(launch_dc_prefix(pa, c->stream)); }
+        DcScanArgs sa{};
+        sa.agg = (const cf2 *)c->dc_agg.p; sa.carry = (cd2 *)c->dc_carry.p; sa.state = c->d_dc_state;
+        sa.frames_in = (int64_t)frames_in; sa.seg_first = pa.seg_first; sa.seg_len = pa.seg_len; sa.n_seg = n_blocks; sa.logc = c->dc_logc;
+        { KernelTimer kt(c, IQGPU_K_DC_SCAN); HIP_TRY(launch_dc_scan(sa, c->stream)); }
+    }
+
+    // ---- filter-input buffer ----
+    cf2 *fcur = nullptr;
+    if (filt) {
+        const size_t need = (L1 + (size_t)c->fpending + (size_t)p.n_res + 1) * sizeof(cf2);
+        if (need > c->fbuf[c->fcur].cap) {
+            // grow, keeping history + pending samples
+            DevBuf nb;
+            int rc = nb.ensure(need); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(nb.p, c->fbuf[c->fcur].p, (L1 + (size_t)c->fpending) * sizeof(cf2), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->fbuf[c->fcur].release();
+            c->fbuf[c->fcur] = nb;
+        }
+        fcur = (cf2 *)c->fbuf[c->fcur].p;
+    }
+
+    // ---- front kernel ----
+    {
+        FrontArgs a{};
+        a.raw = d_raw_in;
+        a.hist_in = c->d_hist[c->hist_cur]; a.hist_out = c->d_hist[c->hist_cur ^ 1];
+        a.frames_in = (int64_t)frames_in; a.hist_cap = c->hist_cap; a.rem0 = c->rem;
+        a.in_fmt = c->desc.in_format; a.gain = c->desc.gain;
+        a.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        a.dc_enable = c->dc ? 1 : 0;
+        if (c->dc) {
+            a.dc_c = c->dc_c; a.dc_a = 1.0f - c->dc_c; a.dc_logc = c->dc_logc;
+            for (int k = 0; k < 6; ++k) a.dc_cpow[k] = (float)std::exp((double)(4 << k) * c->dc_logc);
+            a.dc_cpow[6] = (float)std::exp(256.0 * c->dc_logc);
+            a.dc_cpow[7] = (float)std::exp(1024.0 * c->dc_logc);
+            a.dc_carry = (const cd2 *)c->dc_carry.p;
+        }
+        a.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
+        a.iq_magp1 = 1.0f + c->iq_mag; a.iq_phase = c->iq_phase;
+        a.nco_mode = c->nco_mode;
+        a.nco_dtheta = c->nco_dtheta;
+        // phase of i_rel = 0, i.e. rem samples before the first new sample
+        a.nco_theta0 = c->nco_theta - (uint32_t)c->rem * c->nco_dtheta;
+        a.nco_tab = c->d_nco_tab;
+        a.mode = c->resample ? 1 : 0;
+        a.S = c->S;
+        for (int i = 0; i < c->S; ++i) { a.m[i] = c->rp.stages[(size_t)i].m; a.tap_off[i] = c->tap_off[i]; }
+        for (int i = 0; i <= c->S + 1; ++i) a.lvl_off[i] = c->lvl_off[i];
+        a.n_hb_taps = c->n_hb_taps; a.hb_taps = c->d_hb; a.arb_table = c->d_arb;
+        a.step = c->rp.step; a.n_est = c->n_est; a.phi0 = c->phi;
+        a.n_groups = p.n_groups; a.n_out = p.n_res;
+        a.total_tiles = total_tiles; a.tiles_per_block = c->tiles_per_block; a.warm_tiles = c->warm_tiles;
+        const bool nco_in_front = !filt;                 // with a filter stage the post NCO runs after it
+        a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
+        a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
+        if (filt) { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
+        else      { a.out_fmt = c->desc.out_format; a.out = d_out; }
+        KernelTimer kt(c, IQGPU_K_FRONT);
+        HIP_TRY(launch_front(a, n_blocks, c->stream));
+    }
+    if (c->resample) c->hist_cur ^= 1;
+
+    // ---- filter stage ----
+    if (filt) {
+        FirArgs fa{};
+        fa.fbuf = fcur; fa.taps = c->d_ftaps; fa.ntaps = (int)c->fp.taps.size(); fa.is_complex = c->fp.is_complex ? 1 : 0;
+        fa.n_emit = p.n_emit;
+        fa.pnco_mode = c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
+        fa.out_fmt = c->desc.out_format; fa.out = d_out;
+        { KernelTimer kt(c, IQGPU_K_FILTER); HIP_TRY(launch_fir(fa, c->stream)); }
+        // next call's buffer front: history (L-1) + still-pending samples
+        const size_t keep = L1 + (size_t)p.fpending_next;
+        int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;
+        { KernelTimer kt(c, IQGPU_K_MOVE);
+          HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + p.n_emit, (int64_t)keep, c->stream)); }
+        c->fcur ^= 1;
+        c->fpending = p.fpending_next;
+    }
+
+    // ---- advance the stream position ----
+    c->nco_theta += (uint32_t)frames_in * c->nco_dtheta;
+    c->pnco_theta += (uint32_t)(uint64_t)p.n_emit * c->nco_dtheta;
+    c->rem = p.rem_next;
+    c->phi = p.phi_next;
+    *frames_out = (size_t)p.n_emit;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t frames_in,
+                                   void *out, size_t out_capacity_bytes, size_t *frames_out)
+{
+    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process: NULL argument");
+    *frames_out = 0;
+    if (frames_in == 0) return IQGPU_OK;
+    if (!raw_in || !out) return fail(IQGPU_EINVAL, "iqgpu_chain_process: NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
+    const size_t n_emit = (size_t)plan_call(c, frames_in).n_emit;
+    if (n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
+    int rc = c->stage_in.ensure(frames_in * ibps); if (rc) return rc;
+    rc = c->stage_out.ensure(n_emit * obps + 16); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->stage_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, c->stream));
+    size_t produced = 0;
+    rc = iqgpu_chain_process_device(c, c->stage_in.p, frames_in, c->stage_out.p, c->stage_out.cap, &produced);
+    if (rc) return rc;
+    if (produced) HIP_TRY(hipMemcpyAsync(out, c->stage_out.p, produced * obps, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *frames_out = produced;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    HIP_TRY(hipSetDevice(c->device));
+    // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
+    c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
+    HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
+    if (c->resample)
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2), c->stream));
+    if (c->fp.enabled) {
+        // the filter object's history is cleared; the FFT remainder is NOT (src/filter.c:417-436):
+        // pending samples stay queued in front of the new stream
+        const size_t L1 = c->fp.taps.size() - 1;
+        HIP_TRY(hipMemsetAsync(c->fbuf[c->fcur].p, 0, L1 * sizeof(cf2), c->stream));
+    }
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_set_iq_factors(iqgpu_chain *c, float mag, float phase)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    c->iq_mag = mag; c->iq_phase = phase;
+    return IQGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream / profiling plumbing
+// ------------------------------------------------------------------------------------------------
+extern "C" int iqgpu_chain_set_stream(iqgpu_chain *c, void *hip_stream)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return IQGPU_OK;
+}
+extern "C" void *iqgpu_chain_get_stream(const iqgpu_chain *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int iqgpu_chain_synchronize(iqgpu_chain *c)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_chain_set_profiling(iqgpu_chain *c, int enable)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    c->profiling = enable != 0;
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p)
+{
+    if (!c || !p) return fail(IQGPU_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    drain_events(c);
+    *p = c->prof;
+    memset(&c->prof, 0, sizeof(c->prof));
+    return IQGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level entry points
+// ------------------------------------------------------------------------------------------------
+static int convert_via_chain(const void *in, void *out, size_t frames, int in_fmt, int out_fmt, float gain, int device)
+{
+    iqgpu_chain_desc d;
+    iqgpu_chain_desc_init(&d);
+    d.in_format = in_fmt; d.out_format = out_fmt; d.gain = gain; d.no_resample = 1;
+    d.input_rate_hz = 1.0; d.target_rate_hz = 1.0; d.device_ordinal = device;
+    iqgpu_chain *c = nullptr;
+    int rc = iqgpu_chain_create(&d, &c);
+    if (rc) return rc;
+    size_t n = 0;
+    rc = iqgpu_chain_process(c, in, frames, out, frames * bytes_per_frame(out_fmt), &n);
+    iqgpu_chain_destroy(c);
+    if (rc == IQGPU_OK && n != frames) return fail(IQGPU_EHIP, "convert produced %zu of %zu frames", n, frames);
+    return rc;
+}
+
+extern "C" int iqgpu_convert_block_to_cf32(const void *in, float *out_re_im, size_t frames, int in_format, float gain, int device)
+{
+    if (!bytes_per_frame(in_format)) return fail(IQGPU_EFORMAT, "Unhandled input format: %d", in_format);
+    return convert_via_chain(in, out_re_im, frames, in_format, IQGPU_FMT_CF32, gain, device);
+}
+
+extern "C" int iqgpu_convert_cf32_to_block(const float *in_re_im, void *out, size_t frames, int out_format, int device)
+{
+    if (!bytes_per_frame(out_format)) return fail(IQGPU_EFORMAT, "Unhandled output format: %d", out_format);
+    return convert_via_chain(in_re_im, out, frames, IQGPU_FMT_CF32, out_format, 1.0f, device);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int iqgpu_device_malloc(int device, size_t bytes, void **d_ptr)
+{
+    if (!d_ptr) return fail(IQGPU_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return fail(IQGPU_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_device_free(int device, void *d_ptr) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipFree(d_ptr)); return IQGPU_OK; }
+extern "C" int iqgpu_host_malloc_pinned(size_t bytes, void **h_ptr)
+{
+    if (!h_ptr) return fail(IQGPU_EINVAL, "NULL argument");
+    if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(IQGPU_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_host_free_pinned(void *h_ptr) { HIP_TRY(hipHostFree(h_ptr)); return IQGPU_OK; }
+extern "C" int iqgpu_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return IQGPU_OK;
+}
+extern "C" int iqgpu_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return IQGPU_OK;
+}
+extern "C" int iqgpu_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *s)
+{
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); return IQGPU_OK;
+}
+extern "C" int iqgpu_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *s)
+{
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); return IQGPU_OK;
+}
+extern "C" int iqgpu_stream_create(int device, void **s)
+{
+    if (!s) return fail(IQGPU_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *s = (void *)st;
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_stream_destroy(void *s) { HIP_TRY(hipStreamDestroy((hipStream_t)s)); return IQGPU_OK; }
+extern "C" int iqgpu_stream_synchronize(void *s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return IQGPU_OK; }
+extern "C" int iqgpu_event_create(void **e)
+{
+    if (!e) return fail(IQGPU_EINVAL, "NULL argument");
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreate(&ev));
+    *e = (void *)ev;
+    return IQGPU_OK;
+}
+extern "C" int iqgpu_event_destroy(void *e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return IQGPU_OK; }
+extern "C" int iqgpu_event_record(void *e, void *s) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return IQGPU_OK; }
+extern "C" int iqgpu_stream_wait_event(void *s, void *e) { HIP_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); return IQGPU_OK; }
+extern "C" int iqgpu_event_elapsed_ms(void *a, void *b, float *ms)
+{
+    if (!ms) return fail(IQGPU_EINVAL, "NULL argument");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)b));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return IQGPU_OK;
+}

@@ -1,0 +1,685 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the I/Q chain.
+//
+//   k_front      raw -> unpack/gain -> dc block -> iq correct -> NCO -> half-band cascade ->
+//                256-arm polyphase -> post NCO -> pack           (one launch per process() call)
+//   k_dc_prefix  per-segment aggregate of the DC blocker's first-order recurrence
+//   k_dc_scan    carries of the (few) segments
+//   k_fir        time-domain FIR with LDS tap tiling over the cf32 filter-input buffer
+//
+// Reference semantics and file:line citations are in DESIGN.md; the per-operator arithmetic
+// follows sample_convert.c (bit-exact: explicit round-to-nearest intrinsics, no contraction),
+// frequency_shift.c / dc_block.c / iq_correct.c / resampler.c / filter.c call sites.
+#include <hip/hip_runtime.h>
+
+#include "../../include/iqgpu.h"
+#include "kernels.hpp"
+
+namespace iqgpu {
+
+// ============================================================================================
+// sample_convert (src/sample_convert.c:75-96, 127-208): normaliser first, then gain, each a
+// separately rounded float multiply.
+// ============================================================================================
+__device__ __forceinline__ float up_s(float v, float norm, float gain)
+{
+    return __fmul_rn(__fmul_rn(v, norm), gain);
+}
+__device__ __forceinline__ float up_u(float v, float off, float norm, float gain)
+{
+    return __fmul_rn(__fmul_rn(__fsub_rn(v, off), norm), gain);
+}
+
+// one frame, any format (slow path: tile edges, unaligned calls, rare formats)
+__device__ __forceinline__ cf2 unpack_one(const void *raw, int64_t j, int fmt, float gain)
+{
+    cf2 r;
+    switch (fmt) {
+    case IQGPU_FMT_CS8: {
+        const signed char *p = (const signed char *)raw + 2 * j;
+        r.x = up_s((float)p[0], 1.0f / 128.0f, gain); r.y = up_s((float)p[1], 1.0f / 128.0f, gain);
+        break; }
+    case IQGPU_FMT_CU8: {
+        const unsigned char *p = (const unsigned char *)raw + 2 * j;
+        r.x = up_u((float)p[0], 127.5f, 1.0f / 128.0f, gain); r.y = up_u((float)p[1], 127.5f, 1.0f / 128.0f, gain);
+        break; }
+    case IQGPU_FMT_CS16: {
+        const short *p = (const short *)raw + 2 * j;
+        r.x = up_s((float)p[0], 1.0f / 32768.0f, gain); r.y = up_s((float)p[1], 1.0f / 32768.0f, gain);
+        break; }
+    case IQGPU_FMT_SC16Q11: {
+        const short *p = (const short *)raw + 2 * j;
+        r.x = up_s((float)p[0], 1.0f / 2048.0f, gain); r.y = up_s((float)p[1], 1.0f / 2048.0f, gain);
+        break; }
+    case IQGPU_FMT_CU16: {
+        const unsigned short *p = (const unsigned short *)raw + 2 * j;
+        r.x = up_u((float)p[0], 32767.5f, 1.0f / 32768.0f, gain); r.y = up_u((float)p[1], 32767.5f, 1.0f / 32768.0f, gain);
+        break; }
+    case IQGPU_FMT_CS24: {
+        const unsigned char *p = (const unsigned char *)raw + 6 * j;
+        int a = (int)(((unsigned)p[0] << 8) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 24)) >> 8;
+        int b = (int)(((unsigned)p[3] << 8) | ((unsigned)p[4] << 16) | ((unsigned)p[5] << 24)) >> 8;
+        r.x = up_s((float)a, 1.0f / 8388608.0f, gain); r.y = up_s((float)b, 1.0f / 8388608.0f, gain);
+        break; }
+    case IQGPU_FMT_CS32: {
+        const int *p = (const int *)raw + 2 * j;
+        r.x = (float)__dmul_rn(__dmul_rn((double)p[0], 1.0 / 2147483648.0), (double)gain);
+        r.y = (float)__dmul_rn(__dmul_rn((double)p[1], 1.0 / 2147483648.0), (double)gain);
+        break; }
+    case IQGPU_FMT_CU32: {
+        const unsigned *p = (const unsigned *)raw + 2 * j;
+        r.x = (float)__dmul_rn(__dmul_rn(__dsub_rn((double)p[0], 2147483647.5), 1.0 / 2147483648.0), (double)gain);
+        r.y = (float)__dmul_rn(__dmul_rn(__dsub_rn((double)p[1], 2147483647.5), 1.0 / 2147483648.0), (double)gain);
+        break; }
+    default: { // IQGPU_FMT_CF32
+        const cf2 *p = (const cf2 *)raw + j;
+        r.x = __fmul_rn(p->x, gain); r.y = __fmul_rn(p->y, gain);
+        break; }
+    }
+    return r;
+}
+
+// four consecutive frames starting at j with one coalesced vector load (aligned fast path)
+__device__ __forceinline__ bool unpack_four_fast(const void *raw, int64_t j, int fmt, float gain, cf2 x[4])
+{
+    switch (fmt) {
+    case IQGPU_FMT_CS16: case IQGPU_FMT_SC16Q11: {
+        const float norm = (fmt == IQGPU_FMT_CS16) ? 1.0f / 32768.0f : 1.0f / 2048.0f;
+        const uint4 v = *(const uint4 *)((const char *)raw + 4 * j);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            x[s].x = up_s((float)(short)(w[s] & 0xffffu), norm, gain);
+            x[s].y = up_s((float)(short)(w[s] >> 16), norm, gain);
+        }
+        return true; }
+    case IQGPU_FMT_CU16: {
+        const uint4 v = *(const uint4 *)((const char *)raw + 4 * j);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            x[s].x = up_u((float)(w[s] & 0xffffu), 32767.5f, 1.0f / 32768.0f, gain);
+            x[s].y = up_u((float)(w[s] >> 16), 32767.5f, 1.0f / 32768.0f, gain);
+        }
+        return true; }
+    case IQGPU_FMT_CU8: {
+        const uint2 v = *(const uint2 *)((const char *)raw + 2 * j);
+        const unsigned w[2] = {v.x, v.y};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned h = w[s >> 1] >> ((s & 1) * 16);
+            x[s].x = up_u((float)(h & 0xffu), 127.5f, 1.0f / 128.0f, gain);
+            x[s].y = up_u((float)((h >> 8) & 0xffu), 127.5f, 1.0f / 128.0f, gain);
+        }
+        return true; }
+    case IQGPU_FMT_CS8: {
+        const uint2 v = *(const uint2 *)((const char *)raw + 2 * j);
+        const unsigned w[2] = {v.x, v.y};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned h = w[s >> 1] >> ((s & 1) * 16);
+            x[s].x = up_s((float)(signed char)(h & 0xffu), 1.0f / 128.0f, gain);
+            x[s].y = up_s((float)(signed char)((h >> 8) & 0xffu), 1.0f / 128.0f, gain);
+        }
+        return true; }
+    case IQGPU_FMT_CF32: {
+        const float4 v0 = *(const float4 *)((const char *)raw + 8 * j);
+        const float4 v1 = *(const float4 *)((const char *)raw + 8 * j + 16);
+        x[0].x = __fmul_rn(v0.x, gain); x[0].y = __fmul_rn(v0.y, gain);
+        x[1].x = __fmul_rn(v0.z, gain); x[1].y = __fmul_rn(v0.w, gain);
+        x[2].x = __fmul_rn(v1.x, gain); x[2].y = __fmul_rn(v1.y, gain);
+        x[3].x = __fmul_rn(v1.z, gain); x[3].y = __fmul_rn(v1.w, gain);
+        return true; }
+    default:
+        return false;
+    }
+}
+
+// src/sample_convert.c:40-57: scale, +-0.5 by sign, clamp, truncate
+__device__ __forceinline__ int pk_signed(float x, float scale, float lo, float hi)
+{
+    float v = __fmul_rn(x, scale);
+    v = (v > 0.0f) ? __fadd_rn(v, 0.5f) : __fsub_rn(v, 0.5f);
+    if (v > hi) v = hi;
+    if (v < lo) v = lo;
+    return (int)v;
+}
+// src/sample_convert.c:59-73: scale, offset, clamp, +0.5, truncate
+__device__ __forceinline__ unsigned pk_unsigned(float x, float scale, float off, float hi)
+{
+    float v = __fadd_rn(__fmul_rn(x, scale), off);
+    if (v > hi) v = hi;
+    if (v < 0.0f) v = 0.0f;
+    return (unsigned)__fadd_rn(v, 0.5f);
+}
+
+// one frame -> out[idx] in any format (src/sample_convert.c:213-309)
+__device__ __forceinline__ void pack_store(void *out, int64_t idx, int fmt, cf2 v)
+{
+    switch (fmt) {
+    case IQGPU_FMT_CS16: case IQGPU_FMT_SC16Q11: {
+        const float s = (fmt == IQGPU_FMT_CS16) ? 32767.0f : 2048.0f;
+        const unsigned a = (unsigned)pk_signed(v.x, s, -32768.0f, 32767.0f) & 0xffffu;
+        const unsigned b = (unsigned)pk_signed(v.y, s, -32768.0f, 32767.0f) & 0xffffu;
+        ((unsigned *)out)[idx] = a | (b << 16);
+        break; }
+    case IQGPU_FMT_CU16: {
+        const unsigned a = pk_unsigned(v.x, 32767.0f, 32767.5f, 65535.0f);
+        const unsigned b = pk_unsigned(v.y, 32767.0f, 32767.5f, 65535.0f);
+        ((unsigned *)out)[idx] = a | (b << 16);
+        break; }
+    case IQGPU_FMT_CS8: {
+        const unsigned a = (unsigned)pk_signed(v.x, 127.0f, -128.0f, 127.0f) & 0xffu;
+        const unsigned b = (unsigned)pk_signed(v.y, 127.0f, -128.0f, 127.0f) & 0xffu;
+        ((unsigned short *)out)[idx] = (unsigned short)(a | (b << 8));
+        break; }
+    case IQGPU_FMT_CU8: {
+        const unsigned a = pk_unsigned(v.x, 127.0f, 127.5f, 255.0f);
+        const unsigned b = pk_unsigned(v.y, 127.0f, 127.5f, 255.0f);
+        ((unsigned short *)out)[idx] = (unsigned short)(a | (b << 8));
+        break; }
+    case IQGPU_FMT_CS24: {
+        const float fa = __fmul_rn(v.x, 8388607.0f), fb = __fmul_rn(v.y, 8388607.0f);
+        int a = (int)((fa > 0.0f) ? __fadd_rn(fa, 0.5f) : __fsub_rn(fa, 0.5f));
+        int b = (int)((fb > 0.0f) ? __fadd_rn(fb, 0.5f) : __fsub_rn(fb, 0.5f));
+        a = a > 8388607 ? 8388607 : (a < -8388608 ? -8388608 : a);
+        b = b > 8388607 ? 8388607 : (b < -8388608 ? -8388608 : b);
+        unsigned char *o = (unsigned char *)out + 6 * idx;
+        o[0] = (unsigned char)(a & 0xff); o[1] = (unsigned char)((a >> 8) & 0xff); o[2] = (unsigned char)((a >> 16) & 0xff);
+        o[3] = (unsigned char)(b & 0xff); o[4] = (unsigned char)((b >> 8) & 0xff); o[5] = (unsigned char)((b >> 16) & 0xff);
+        break; }
+    case IQGPU_FMT_CS32: {
+        const double hi = 2147483647.0, lo = -2147483648.0;
+        double a = __dmul_rn((double)v.x, hi), b = __dmul_rn((double)v.y, hi);
+        a = (a > 0.0) ? __dadd_rn(a, 0.5) : __dsub_rn(a, 0.5);
+        b = (b > 0.0) ? __dadd_rn(b, 0.5) : __dsub_rn(b, 0.5);
+        a = a > hi ? hi : (a < lo ? lo : a);
+        b = b > hi ? hi : (b < lo ? lo : b);
+        ((int2 *)out)[idx] = make_int2((int)a, (int)b);
+        break; }
+    case IQGPU_FMT_CU32: {
+        const double hi = 4294967295.0;
+        double a = __dadd_rn(__dmul_rn((double)v.x, 2147483647.0), 2147483647.5);
+        double b = __dadd_rn(__dmul_rn((double)v.y, 2147483647.0), 2147483647.5);
+        a = a > hi ? hi : (a < 0.0 ? 0.0 : a);
+        b = b > hi ? hi : (b < 0.0 ? 0.0 : b);
+        ((uint2 *)out)[idx] = make_uint2((unsigned)__dadd_rn(a, 0.5), (unsigned)__dadd_rn(b, 0.5));
+        break; }
+    default: // IQGPU_FMT_CF32: memcpy (src/sample_convert.c:301-303)
+        ((cf2 *)out)[idx] = v;
+        break;
+    }
+}
+
+// LIQUID_NCO phasor of phase theta: table index = rounded top 10 bits (SPEC B.4)
+__device__ __forceinline__ cf2 nco_phasor(const cf2 *tab, uint32_t theta)
+{
+    return tab[(theta + (1u << 21)) >> 22];
+}
+// y = x * (c + j s) for mode +1, x * (c - j s) for mode -1 (src/frequency_shift.c:91-95)
+__device__ __forceinline__ cf2 nco_mix(cf2 x, cf2 cs, int mode)
+{
+    const float s = (mode > 0) ? cs.y : -cs.y, c = cs.x;
+    cf2 y;
+    y.x = x.x * c - x.y * s;
+    y.y = x.x * s + x.y * c;
+    return y;
+}
+
+__device__ __forceinline__ uint64_t first_k_at(uint64_t target, uint64_t phi0, uint32_t step)
+{
+    return target > phi0 ? (target - phi0 + (uint64_t)step - 1) / (uint64_t)step : 0;
+}
+
+__device__ __forceinline__ int lvl_hist(const FrontArgs &a, int i) { return (i < a.S) ? 4 * a.m[i] : kArbHist; }
+
+// ============================================================================================
+// k_front
+//   Block b owns tiles [b*tpb, (b+1)*tpb) of kTile input samples (tile boundaries are aligned to
+//   the stream's 2^S groups) and first re-runs warm_tiles tiles to rebuild every stage window, so
+//   blocks are independent; inside a block the tiles run in order and all state (dc blocker
+//   value, stage histories, next output index) is carried in registers / LDS.
+// ============================================================================================
+__global__ __launch_bounds__(kThreads) void k_front(const FrontArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S;
+
+    cf2   *s_nco = (cf2 *)smem;                              // 1024 {cos, sin}
+    float *s_arb = (float *)(s_nco + 1024);                  // [256][16]
+    float *s_hb  = s_arb + 256 * 16;                         // branch taps
+    cf2   *s_wtot = (cf2 *)(s_hb + ((a.n_hb_taps + 3) & ~3)); // [2][4] dc wave totals
+    cf2   *s_lvl = s_wtot + 8;                               // level buffers
+
+    // ---- tables and zeroed histories ----
+    if (a.nco_mode != 0 || a.pnco_mode != 0)
+        for (int i = tid; i < 1024; i += kThreads) s_nco[i] = a.nco_tab[i];
+    if (a.mode == 1) {
+        for (int i = tid; i < 256 * 16; i += kThreads) s_arb[i] = a.arb_table[i];
+        for (int i = tid; i < a.n_hb_taps; i += kThreads) s_hb[i] = a.hb_taps[i];
+        const int total = a.lvl_off[S + 1];
+        for (int i = tid; i < total; i += kThreads) s_lvl[i] = cf2{0.0f, 0.0f};
+    }
+
+    const int b = blockIdx.x;
+    const int64_t t_emit0 = (int64_t)b * a.tiles_per_block;
+    int64_t t_emit1 = t_emit0 + a.tiles_per_block;
+    if (t_emit1 > a.total_tiles || b == (int)gridDim.x - 1) t_emit1 = a.total_tiles;
+    const int64_t t_begin = t_emit0 - a.warm_tiles;
+    const int TG = kTile >> S;
+    const int bps = (a.in_fmt == IQGPU_FMT_CS8 || a.in_fmt == IQGPU_FMT_CU8) ? 2
+                  : (a.in_fmt == IQGPU_FMT_CS24) ? 6
+                  : (a.in_fmt == IQGPU_FMT_CS32 || a.in_fmt == IQGPU_FMT_CU32 || a.in_fmt == IQGPU_FMT_CF32) ? 8 : 4;
+
+    // ---- block 0 keeps the part of the old history that this (short) call does not replace ----
+    if (b == 0 && a.frames_in < (int64_t)a.hist_cap) {
+        const int keep = a.hist_cap - (int)a.frames_in;
+        for (int i = tid; i < keep; i += kThreads) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
+    }
+
+    // ---- dc blocker state ----
+    float vr = 0.0f, vi = 0.0f;       // v[n-1] at the start of the next chunk (uniform)
+    bool dc_started = false;
+    float lane_pow = 1.0f;            // c^(4*lane)
+    if (a.dc_enable) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
+    }
+
+    uint64_t k_next = 0;
+    if (a.mode == 1) k_next = first_k_at((uint64_t)(t_emit0 * TG) << 24, a.phi0, a.step);
+
+    __syncthreads();
+
+    for (int64_t t = t_begin; t < t_emit1; ++t) {
+        const int64_t i0 = t * kTile;             // group-aligned index of the tile's first sample
+        const int64_t j0 = i0 - a.rem0;           // index into this call's new samples
+        const bool emit = t >= t_emit0;
+        const bool interior = (j0 >= 0) && (j0 + kTile <= a.frames_in) && a.raw_aligned &&
+                              (((j0 * bps) & 15) == 0);
+        cf2 *lv0 = s_lvl + a.lvl_off[0] + lvl_hist(a, 0);
+
+        if (a.dc_enable && !dc_started && j0 + kTile > 0) {
+            // state before the block's first new sample, moved back over the n_h history
+            // positions of this tile that precede it (they feed zeros into the recurrence)
+            const cd2 cv = a.dc_carry[b];
+            const int64_t n_h = (j0 < 0) ? -j0 : 0;
+            const double back = exp(-(double)n_h * a.dc_logc);
+            vr = (float)(cv.x * back); vi = (float)(cv.y * back);
+            dc_started = true;
+        }
+
+        // ------------------------------------------------------------ phase 1: pointwise
+        for (int c = 0; c < kTile / 1024; ++c) {
+            const int l = c * 1024 + 4 * tid;
+            const int64_t j = j0 + l;
+            cf2 x[4];
+            bool is_hist[4] = {false, false, false, false};
+            bool is_new[4] = {true, true, true, true};
+            bool fast = false;
+            if (interior) fast = unpack_four_fast(a.raw, j, a.in_fmt, a.gain, x);
+            if (!fast) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t js = j + s;
+                    if (js < 0) {
+                        const int64_t h = (int64_t)a.hist_cap + js;
+                        x[s] = (h >= 0) ? a.hist_in[h] : cf2{0.0f, 0.0f};
+                        is_hist[s] = true; is_new[s] = false;
+                    } else if (js >= a.frames_in) {
+                        x[s] = cf2{0.0f, 0.0f};
+                        is_new[s] = false;
+                    } else {
+                        x[s] = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                    }
+                }
+            }
+
+            if (a.dc_enable) {
+                // v[n] = x[n] + c v[n-1];  y[n] = v[n] - v[n-1] = x[n] - (1-c) v[n-1]   (SPEC B.5)
+                const float cc = a.dc_c;
+                cf2 xd[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xd[s] = is_hist[s] ? cf2{0.0f, 0.0f} : x[s];
+                float br = xd[0].x, bi = xd[0].y;
+#pragma unroll
+                for (int s = 1; s < 4; ++s) { br = fmaf(br, cc, xd[s].x); bi = fmaf(bi, cc, xd[s].y); }
+                // inclusive scan over the 64 lanes: B_l += c^(4*2^k) B_(l-2^k)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const float ur = __shfl_up(br, 1 << k), ui = __shfl_up(bi, 1 << k);
+                    if (lane >= (1 << k)) { br = fmaf(a.dc_cpow[k], ur, br); bi = fmaf(a.dc_cpow[k], ui, bi); }
+                }
+                cf2 *wt = s_wtot + 4 * (c & 1);
+                if (lane == 63) wt[wave] = cf2{br, bi};
+                float er = __shfl_up(br, 1), ei = __shfl_up(bi, 1);   // exclusive within the wave
+                if (lane == 0) { er = 0.0f; ei = 0.0f; }
+                __syncthreads();
+                // state at this wave's first sample, and at the end of the chunk
+                const float c256 = a.dc_cpow[6];
+                float pr = vr, pi = vi;           // running state across the 4 waves
+                float wr = 0.0f, wi = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w == wave) { wr = pr; wi = pi; }
+                    const cf2 tot = wt[w];
+                    pr = fmaf(c256, pr, tot.x); pi = fmaf(c256, pi, tot.y);
+                }
+                vr = pr; vi = pi;
+                float sr = fmaf(lane_pow, wr, er), si = fmaf(lane_pow, wi, ei);  // v[n-1] of x[0]
+                const float aa = a.dc_a;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float yr = fmaf(-aa, sr, xd[s].x), yi = fmaf(-aa, si, xd[s].y);
+                    sr = fmaf(cc, sr, xd[s].x); si = fmaf(cc, si, xd[s].y);
+                    if (!is_hist[s]) { x[s].x = yr; x[s].y = yi; }
+                }
+            }
+
+            if (a.iq_enable) { // src/iq_correct.c:307-313
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (!is_hist[s]) {
+                    const float re = x[s].x;
+                    x[s].x = re * a.iq_magp1;
+                    x[s].y = x[s].y + a.iq_phase * re;
+                }
+            }
+
+            if (a.nco_mode != 0) {
+                uint32_t th = a.nco_theta0 + (uint32_t)(i0 + l) * a.nco_dtheta;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (!is_hist[s]) x[s] = nco_mix(x[s], nco_phasor(s_nco, th), a.nco_mode);
+                    th += a.nco_dtheta;
+                }
+            }
+
+            if (emit && a.hist_cap > 0 && j + 4 > a.frames_in - (int64_t)a.hist_cap) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t back = a.frames_in - (j + s);      // 1 .. hist_cap for kept samples
+                    if (is_new[s] && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = x[s];
+                }
+            }
+
+            if (a.mode == 1) {
+                float4 *dst = (float4 *)(lv0 + l);
+                dst[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+                dst[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+            } else if (emit) {
+                // no resampler: frames map one to one (src/pipeline.c:516-519)
+                uint32_t th = a.pnco_theta0 + (uint32_t)j * a.pnco_dtheta;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (is_new[s]) {
+                        cf2 y = x[s];
+                        if (a.pnco_mode != 0) y = nco_mix(y, nco_phasor(s_nco, th), a.pnco_mode);
+                        pack_store(a.out, j + s, a.out_fmt, y);
+                    }
+                    th += a.pnco_dtheta;
+                }
+            }
+        }
+        if (a.mode != 1) continue;
+        __syncthreads();
+
+        // ------------------------------------------------------------ phase 2: half-band cascade
+        for (int i = 0; i < S; ++i) {
+            const int m = a.m[i], n_out = kTile >> (i + 1);
+            const cf2 *src = s_lvl + a.lvl_off[i] + 4 * m;
+            cf2 *dst = s_lvl + a.lvl_off[i + 1] + lvl_hist(a, i + 1);
+            const float *taps = s_hb + a.tap_off[i];
+            for (int jl = tid; jl < n_out; jl += kThreads) {
+                const cf2 d = src[2 * jl + 1 - 2 * m];       // centre tap (delay branch), gain 0.5
+                float ar = 0.5f * d.x, ai = 0.5f * d.y;
+                const cf2 *p = src + 2 * jl;
+                for (int q = 0; q < 2 * m; ++q) {            // odd taps h[2q+1] on x[2jl - 2q]
+                    const cf2 sv = p[-2 * q];
+                    const float h = taps[q];
+                    ar = fmaf(h, sv.x, ar); ai = fmaf(h, sv.y, ai);
+                }
+                dst[jl] = cf2{ar, ai};
+            }
+            __syncthreads();
+        }
+
+        // ------------------------------------------------------------ phase 3: polyphase + pack
+        if (emit) {
+            const int64_t qa = t * TG;
+            int64_t qb = qa + TG; if (qb > a.n_groups) qb = a.n_groups;
+            if (qb > qa) {
+                const uint64_t k_lo = k_next;
+                uint64_t k_hi;
+                if (qb - qa == TG) {
+                    k_hi = k_lo + a.n_est;
+                    while (a.phi0 + k_hi * (uint64_t)a.step < ((uint64_t)qb << 24)) ++k_hi;
+                } else {
+                    k_hi = first_k_at((uint64_t)qb << 24, a.phi0, a.step);
+                }
+                const cf2 *hb = s_lvl + a.lvl_off[S] + kArbHist;
+                for (uint64_t k = k_lo + tid; k < k_hi; k += kThreads) {
+                    const uint64_t P = a.phi0 + k * (uint64_t)a.step;
+                    const int ql = (int)((int64_t)(P >> 24) - qa);
+                    const int arm = (int)((P >> 16) & 255u);
+                    const cf2 *w = hb + ql;
+                    const float *tp = s_arb + arm * 16;
+                    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+                    for (int n = 0; n < 14; ++n) {
+                        const cf2 sv = w[-n];
+                        ar = fmaf(tp[n], sv.x, ar); ai = fmaf(tp[n], sv.y, ai);
+                    }
+                    cf2 y{ar, ai};
+                    if (a.pnco_mode != 0)
+                        y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
+                    pack_store(a.out, (int64_t)k, a.out_fmt, y);
+                }
+                k_next = k_hi;
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ phase 4: slide histories
+        for (int i = wave; i <= S; i += 4) {
+            const int H = lvl_hist(a, i), n_i = kTile >> i;
+            cf2 *buf = s_lvl + a.lvl_off[i];
+            if (lane < H) { const cf2 v = buf[n_i + lane]; buf[lane] = v; }
+        }
+        __syncthreads();
+    }
+}
+
+size_t front_lds_bytes(const FrontArgs &a)
+{
+    size_t bytes = 1024 * sizeof(cf2) + 256 * 16 * sizeof(float) + (size_t)((a.n_hb_taps + 3) & ~3) * sizeof(float) + 8 * sizeof(cf2);
+    if (a.mode == 1) bytes += (size_t)a.lvl_off[a.S + 1] * sizeof(cf2);
+    return bytes;
+}
+
+hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s)
+{
+    const size_t lds = front_lds_bytes(a);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_front, dim3((unsigned)n_blocks), dim3(kThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+// ============================================================================================
+// DC-blocker carries
+// ============================================================================================
+// Segment s covers the new samples [start(s), start(s+1)); start(0) = 0 and start(s) for s >= 1 is
+// the first new sample that block s of k_front processes (its warm-up start), clamped to the call.
+__host__ __device__ __forceinline__ int64_t dc_seg_start(int s, int64_t seg_first, int64_t seg_len, int64_t frames_in)
+{
+    if (s == 0) return 0;
+    int64_t v = seg_first + (int64_t)(s - 1) * seg_len;
+    if (v < 0) v = 0;
+    if (v > frames_in) v = frames_in;
+    return v;
+}
+
+// One workgroup per segment: A = sum_k c^(end-1-k) x[k] over the segment's new samples.
+__global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
+{
+    __shared__ float red[2 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sgm = blockIdx.x;
+    const int64_t beg = dc_seg_start(sgm, a.seg_first, a.seg_len, a.frames_in);
+    const int64_t end = (sgm == a.n_seg - 1) ? a.frames_in : dc_seg_start(sgm + 1, a.seg_first, a.seg_len, a.frames_in);
+    const int64_t len = end - beg;
+    float accr = 0.0f, acci = 0.0f;
+    if (len > 0) {
+        // left-pad the segment to whole chunks of 1024 so that the last chunk ends at `end`
+        const int64_t n_chunks = (len + 1023) >> 10;
+        const int64_t pad = (n_chunks << 10) - len;
+        const float c = a.c;
+        const float c1024 = (float)exp(1024.0 * a.logc);
+        for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            const int64_t u = (ch << 10) + 4 * tid;       // padded position of this thread's 4 samples
+            float lr = 0.0f, li = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int64_t k = beg + u + s - pad;
+                cf2 x{0.0f, 0.0f};
+                if (u + s >= pad) x = unpack_one(a.raw, k, a.in_fmt, a.gain);
+                lr = fmaf(lr, c, x.x); li = fmaf(li, c, x.y);
+            }
+            accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
+        }
+        const float wt = (float)exp((double)(1020 - 4 * tid) * a.logc);  // to the end of the chunk
+        accr *= wt; acci *= wt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { accr += __shfl_down(accr, o); acci += __shfl_down(acci, o); }
+    if (lane == 0) { red[2 * wave] = accr; red[2 * wave + 1] = acci; }
+    __syncthreads();
+    if (tid == 0) {
+        float r = 0.0f, i = 0.0f;
+        for (int w = 0; w < 4; ++w) { r += red[2 * w]; i += red[2 * w + 1]; }
+        a.agg[sgm] = cf2{r, i};
+    }
+}
+
+hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dc_prefix, dim3((unsigned)a.n_seg), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+// carry[b] = state before segment b; state <- state after the last sample.  Sequential over the
+// (few thousand at most) segments, in double.
+__global__ void k_dc_scan(const DcScanArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double vr = a.state->x, vi = a.state->y;
+    int64_t prev_len = -1; double f = 1.0;
+    for (int sgm = 0; sgm < a.n_seg; ++sgm) {
+        const int64_t beg = dc_seg_start(sgm, a.seg_first, a.seg_len, a.frames_in);
+        const int64_t end = (sgm == a.n_seg - 1) ? a.frames_in : dc_seg_start(sgm + 1, a.seg_first, a.seg_len, a.frames_in);
+        const int64_t len = end > beg ? end - beg : 0;
+        a.carry[sgm] = cd2{vr, vi};
+        if (len != prev_len) { f = exp((double)len * a.logc); prev_len = len; }
+        const cf2 g = a.agg[sgm];
+        vr = vr * f + (double)g.x; vi = vi * f + (double)g.y;
+    }
+    a.state->x = vr; a.state->y = vi;
+}
+
+hipError_t launch_dc_scan(const DcScanArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// ============================================================================================
+// k_fir: y[i] = sum_k h[k] f[(L-1) + i - k]   (firfilt / fftfilt are the same linear convolution,
+// SPEC B.2/B.3); taps and the matching data window are staged through LDS in chunks of
+// kFirTapChunk taps; each thread owns four outputs 256 apart so LDS reads are conflict free.
+// ============================================================================================
+__global__ __launch_bounds__(kThreads) void k_fir(const FirArgs a)
+{
+    __shared__ __align__(16) cf2 s_w[kFirOutTile + kFirTapChunk];
+    __shared__ __align__(16) cf2 s_h[kFirTapChunk];
+    __shared__ __align__(16) cf2 s_nco[1024];
+    const int tid = threadIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.x * kFirOutTile;
+    const int L = a.ntaps;
+    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += kThreads) s_nco[i] = a.nco_tab[i];
+
+    float ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < L; k0 += kFirTapChunk) {
+        __syncthreads();
+        // window element e <-> f index base + e, base = (L-1) + o0 - k0 - (C-1)
+        const int64_t base = (int64_t)(L - 1) + o0 - k0 - (kFirTapChunk - 1);
+        const int64_t fmax = (int64_t)(L - 1) + a.n_emit;   // valid f indices are [0, fmax)
+        for (int e = tid; e < kFirOutTile + kFirTapChunk - 1; e += kThreads) {
+            const int64_t fi = base + e;
+            s_w[e] = (fi >= 0 && fi < fmax) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+        }
+        for (int e = tid; e < kFirTapChunk; e += kThreads)
+            s_h[e] = (k0 + e < L) ? a.taps[k0 + e] : cf2{0.0f, 0.0f};
+        __syncthreads();
+        const int kn = (L - k0 < kFirTapChunk) ? L - k0 : kFirTapChunk;
+        if (a.is_complex) {
+            for (int kk = 0; kk < kn; ++kk) {
+                const cf2 h = s_h[kk];
+                const cf2 *p = s_w + tid + (kFirTapChunk - 1) - kk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cf2 x = p[256 * r];
+                    ar[r] = fmaf(h.x, x.x, ar[r]); ar[r] = fmaf(-h.y, x.y, ar[r]);
+                    ai[r] = fmaf(h.x, x.y, ai[r]); ai[r] = fmaf(h.y, x.x, ai[r]);
+                }
+            }
+        } else {
+            for (int kk = 0; kk < kn; ++kk) {
+                const float h = s_h[kk].x;
+                const cf2 *p = s_w + tid + (kFirTapChunk - 1) - kk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cf2 x = p[256 * r];
+                    ar[r] = fmaf(h, x.x, ar[r]); ai[r] = fmaf(h, x.y, ai[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = o0 + tid + 256 * r;
+        if (i < a.n_emit) {
+            cf2 y{ar[r], ai[r]};
+            if (a.pnco_mode != 0)
+                y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)i * a.pnco_dtheta), a.pnco_mode);
+            pack_store(a.out, i, a.out_fmt, y);
+        }
+    }
+}
+
+hipError_t launch_fir(const FirArgs &a, hipStream_t s)
+{
+    if (a.n_emit <= 0) return hipSuccess;
+    const unsigned nb = (unsigned)((a.n_emit + kFirOutTile - 1) / kFirOutTile);
+    hipLaunchKernelGGL(k_fir, dim3(nb), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void k_copy_cf(cf2 *dst, const cf2 *src, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    unsigned nb = (unsigned)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_copy_cf, dim3(nb), dim3(256), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

@@ -1,0 +1,125 @@
+// kernels.hpp -- argument blocks and launchers of the gfx950 kernels (defined in kernels.hip).
+#pragma once
+
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+
+namespace iqgpu {
+
+constexpr int kTile = 2048;        // input samples per workgroup tile
+constexpr int kThreads = 256;      // 4 wavefronts of 64
+constexpr int kMaxS = 12;
+constexpr int kArbHist = 16;       // 13 needed, padded
+constexpr int kFirOutTile = 1024;  // outputs per workgroup tile in the FIR kernel
+constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
+
+struct cf2 { float x, y; };
+struct cd2 { double x, y; };
+
+// ---------------------------------------------------------------------------------------------
+// k_front: raw -> [unpack, gain] -> [dc block] -> [iq correct] -> [pre NCO] -> [half-band cascade ->
+//          arbitrary polyphase] -> [post NCO] -> [pack] -> out
+// ---------------------------------------------------------------------------------------------
+struct FrontArgs {
+    // input
+    const void *raw;          // frames_in new samples, in_fmt
+    const cf2  *hist_in;      // hist_cap processed samples that precede this call
+    cf2        *hist_out;     // the same for the next call
+    int64_t     frames_in;
+    int32_t     hist_cap;
+    int32_t     rem0;         // samples of the open 2^S group carried in from the previous call
+    int32_t     in_fmt;
+    float       gain;
+    int32_t     raw_aligned;  // raw pointer is 16-byte aligned
+    // dc blocker
+    int32_t     dc_enable;
+    float       dc_c;         // 1 - alpha
+    float       dc_a;         // alpha' = 1 - c (exact)
+    float       dc_cpow[8];   // c^(4*2^k), k=0..5; [6] = c^256; [7] = c^1024
+    double      dc_logc;      // log(c), for c^(-n) at block start
+    const cd2  *dc_carry;     // per block: state before the block's first new sample
+    // iq correction
+    int32_t     iq_enable;
+    float       iq_magp1, iq_phase;
+    // pre-resample NCO
+    int32_t     nco_mode;     // 0 off, +1 mix up, -1 mix down
+    uint32_t    nco_theta0;   // phase of input sample i_rel = 0
+    uint32_t    nco_dtheta;
+    const cf2  *nco_tab;      // 1024 x {cos, sin}
+    // resampler
+    int32_t     mode;         // 0 = no resampler (pointwise only), 1 = decimating msresamp
+    int32_t     S;
+    int32_t     m[kMaxS];
+    int32_t     tap_off[kMaxS];
+    int32_t     lvl_off[kMaxS + 2]; // LDS offset (in cf32) of each level buffer; [S+1] = total
+    int32_t     n_hb_taps;
+    const float *hb_taps;     // branch taps of every stage, pre-scaled by 0.5
+    const float *arb_table;   // [256][16]
+    uint32_t    step;
+    uint32_t    n_est;        // floor((kTile >> S) * 2^24 / step): outputs of a full tile, or one more
+    uint64_t    phi0;         // phase of output k_rel = 0 relative to group q_rel = 0
+    int64_t     n_groups;     // complete groups available in this call
+    int64_t     n_out;        // outputs of this call
+    int64_t     total_tiles;
+    int32_t     tiles_per_block;
+    int32_t     warm_tiles;
+    // post-resample NCO
+    int32_t     pnco_mode;
+    uint32_t    pnco_theta0, pnco_dtheta;
+    // output
+    int32_t     out_fmt;
+    void       *out;
+};
+
+size_t front_lds_bytes(const FrontArgs &a);
+hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
+// ---------------------------------------------------------------------------------------------
+struct DcPrefixArgs {
+    const void *raw;
+    int64_t     frames_in;
+    int32_t     in_fmt;
+    float       gain;
+    float       c;            // 1 - alpha
+    double      logc;
+    int64_t     seg_first;    // start (new-sample index, may be <= 0) of segment 1; segment 0 starts at 0
+    int64_t     seg_len;      // spacing of the starts of segments 1..n-1; starts clamp to [0, frames_in]
+    int32_t     n_seg;
+    cf2        *agg;          // [n_seg]
+};
+hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s);
+
+struct DcScanArgs {
+    const cf2 *agg;
+    cd2       *carry;         // [n_seg]
+    cd2       *state;         // in: state before sample 0; out: state after the last sample
+    int64_t    frames_in;
+    int64_t    seg_first, seg_len;
+    int32_t    n_seg;
+    double     logc;
+};
+hipError_t launch_dc_scan(const DcScanArgs &a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// k_fir: time-domain FIR over the cf32 filter-input buffer, [post NCO], pack
+// ---------------------------------------------------------------------------------------------
+struct FirArgs {
+    const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]
+    const cf2 *taps;          // ntaps complex taps h[k]
+    int32_t    ntaps;
+    int32_t    is_complex;
+    int64_t    n_emit;        // outputs to produce
+    int32_t    pnco_mode;
+    uint32_t   pnco_theta0, pnco_dtheta;
+    const cf2 *nco_tab;
+    int32_t    out_fmt;
+    void      *out;
+};
+hipError_t launch_fir(const FirArgs &a, hipStream_t s);
+
+// dst[i] = src[i], i < n (cf32)
+hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);
+
+} // namespace iqgpu

@@ -1,0 +1,54 @@
+"""Synthetic I/Q test streams: three complex tones at -150 kHz, +30 kHz and
++200 kHz scaled (0.20, 0.25, 0.15), complex Gaussian noise sigma 0.05, DC offset (0.01, -0.02),
+clipped to +-0.999 and quantised to the raw-file sample format with the reference's packing rule
+(src/sample_convert.c:40-73).  numpy only; used by bench.py, the harness and the tests."""
+import numpy as np
+
+TONES_HZ = (-150e3, 30e3, 200e3)
+TONE_AMP = (0.20, 0.25, 0.15)
+
+
+def complex_signal(n, rate_hz, seed, start=0):
+    """cf32 samples [start, start+n) of the stream with this seed (noise is re-seeded per call
+    with (seed, start) so arbitrary windows are reproducible)."""
+    t = (np.arange(start, start + n, dtype=np.float64)) / float(rate_hz)
+    x = np.zeros(n, np.complex128)
+    for f, a in zip(TONES_HZ, TONE_AMP):
+        x += a * np.exp(2j * np.pi * f * t)
+    rng = np.random.default_rng([int(seed), int(start)])
+    x += 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x += 0.01 - 0.02j
+    x = np.clip(x.real, -0.999, 0.999) + 1j * np.clip(x.imag, -0.999, 0.999)
+    return x.astype(np.complex64)
+
+
+def quantise(x, fmt):
+    """cf32 -> interleaved integer frames, float32 arithmetic as convert_cf32_to_block does it."""
+    v = np.ascontiguousarray(x, np.complex64).view(np.float32)
+    half = np.float32(0.5)
+    if fmt in ("cs16", "sc16q11", "cs8"):
+        scale, lo, hi, dt = {"cs16": (32767.0, -32768.0, 32767.0, np.int16),
+                             "sc16q11": (2048.0, -32768.0, 32767.0, np.int16),
+                             "cs8": (127.0, -128.0, 127.0, np.int8)}[fmt]
+        w = v * np.float32(scale)
+        w = np.where(w > 0, w + half, w - half).astype(np.float32)
+        w = np.clip(w, np.float32(lo), np.float32(hi))
+        return np.trunc(w).astype(dt)
+    if fmt in ("cu8", "cu16"):
+        scale, off, hi, dt = {"cu8": (127.0, 127.5, 255.0, np.uint8),
+                              "cu16": (32767.0, 32767.5, 65535.0, np.uint16)}[fmt]
+        w = (v * np.float32(scale)).astype(np.float32) + np.float32(off)
+        w = np.clip(w, np.float32(0.0), np.float32(hi))
+        return np.trunc(w + half).astype(dt)
+    if fmt == "cf32":
+        return v.copy()
+    raise ValueError("synth.quantise: format %r not supported" % fmt)
+
+
+def raw_stream(n, rate_hz, seed, fmt, chunk=1 << 22):
+    """n frames of the synthetic stream in the given raw format (generated in chunks)."""
+    parts = []
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        parts.append(quantise(complex_signal(m, rate_hz, seed, s), fmt))
+    return np.concatenate(parts) if parts else np.zeros(0, np.int16)

@@ -1,0 +1,330 @@
+"""Parity of the HIP path (through the C ABI of include/iqgpu.h) against the CPU oracle.
+
+Bars (DESIGN.md "Parity contract"):
+  * sample_convert paths (a3, a15): bit-exact;
+  * cf32 results of every liquid-derived operator: max |delta| <= 1e-5 on unit-scale signals;
+  * integer outputs of full chains: never more than +-1 LSB apart, >= 97 % identical codes.
+"""
+import numpy as np
+import pytest
+
+from iq_tool_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def cf(a):
+    return np.ascontiguousarray(a).view(np.float32).view(np.complex64) if a.dtype != np.complex64 else a
+
+
+def run_gpu(gpu, raw, splits=None, **kw):
+    ch = gpu.Chain(**kw)
+    if splits is None:
+        return ch.process(raw)
+    bpf = ch.in_bytes
+    rb = np.ascontiguousarray(raw).view(np.uint8)
+    outs, pos = [], 0
+    for n in splits:
+        outs.append(ch.process(rb[pos * bpf:(pos + n) * bpf]))
+        pos += n
+    assert pos * bpf == rb.size
+    return np.concatenate(outs)
+
+
+def run_oracle(oracle, raw, **kw):
+    kw = dict(kw)
+    kw.pop("block_samples", None)
+    kw.pop("device", None)
+    ft = kw.get("filter_taps", 0)
+    if ft and ft % 2 == 0:
+        kw["filter_taps"] = ft + 1          # src/config.c:233-236
+    return oracle.Chain(**kw).process(raw)
+
+
+def int_close(a, b, min_same=0.97):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+    assert d.max() <= 1, "max code difference %d" % d.max()
+    same = float((d == 0).mean())
+    assert same >= min_same, "only %.4f of codes identical" % same
+    return same
+
+
+# --------------------------------------------------------------------------------------------
+# a3 / a15 / a16: sample_convert, bit-exact
+# --------------------------------------------------------------------------------------------
+FORMATS = ["cs8", "cu8", "cs16", "cu16", "sc16q11", "cs24", "cs32", "cu32", "cf32"]
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("gain", [1.0, 0.37, -2.5])
+def test_convert_block_to_cf32_bit_exact(gpu, oracle, fmt, gain):
+    from iq_tool_amd import ops
+    rng = np.random.default_rng(7)
+    for n in (1, 3, 2047, 2049, 70001):
+        nbytes = n * oracle.BYTES[oracle.FMT[fmt]]
+        raw = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        if fmt == "cf32":
+            raw = rng.standard_normal(2 * n).astype(np.float32).view(np.uint8)
+        want = oracle.to_cf32(raw, fmt, gain)
+        got = ops.convert_block_to_cf32(raw, fmt, gain)
+        assert np.array_equal(got.view(np.float32), want.view(np.float32)), (fmt, gain, n)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_convert_cf32_to_block_bit_exact(gpu, oracle, fmt):
+    from iq_tool_amd import ops
+    rng = np.random.default_rng(11)
+    n = 100003
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.6)
+    # rounding boundaries and the clamps
+    edge = np.array([0, 1, -1, 0.5, -0.5, 1.5, -1.5, 2.0, -2.0, 1e-8, -1e-8, 0.999999, -0.999999, 1e9, -1e9], np.float32)
+    scale = {"cs8": 127, "cu8": 127, "cs16": 32767, "cu16": 32767, "sc16q11": 2048, "cs24": 8388607,
+             "cs32": 2147483647, "cu32": 2147483647, "cf32": 1}[fmt]
+    halves = (np.arange(-40, 40, dtype=np.float32) + np.float32(0.5)) / np.float32(scale)
+    if fmt in ("cs32", "cu32"):
+        edge = edge[np.abs(edge) < 1e8]      # (int32_t) of an out-of-range double is UB in the reference
+    ext = np.concatenate([edge, halves, np.nextafter(halves, np.float32(1)), np.nextafter(halves, np.float32(-1))])
+    x[:ext.size] = ext + 1j * ext[::-1]
+    want = oracle.from_cf32(x, fmt)
+    got = ops.convert_cf32_to_block(x, fmt)
+    assert np.array_equal(got, want)
+
+
+def test_get_bytes_per_sample(gpu, oracle):
+    from iq_tool_amd import ops
+    for name, fid in oracle.FMT.items():
+        assert ops.get_bytes_per_sample(name) == oracle.BYTES[fid]
+    assert ops.get_bytes_per_sample(3) == 0
+
+
+# --------------------------------------------------------------------------------------------
+# config 1/2: NRSC-5 chain
+# --------------------------------------------------------------------------------------------
+NRSC5 = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+
+
+def test_nrsc5_chain_cf32_and_cs16(gpu, oracle):
+    n = 1 << 20
+    raw = synth.raw_stream(n, 2.4e6, 1, "cs16")
+    want_i, want_c = oracle.Chain(**NRSC5).process(raw, want_cf32=True)
+    got_c = cf(run_gpu(gpu, raw, **dict(NRSC5, out_format="cf32")))
+    assert got_c.size == want_c.size
+    assert np.abs(got_c - want_c).max() <= TOL
+    got_i = run_gpu(gpu, raw, **NRSC5)
+    int_close(got_i, want_i)
+
+
+def test_nrsc5_small_blocks_and_ragged_calls(gpu, oracle):
+    """many workgroup blocks + calls that split groups and tiles: identical bytes"""
+    n = 300001
+    raw = synth.raw_stream(n, 2.4e6, 2, "cs16")
+    ref = run_gpu(gpu, raw, **NRSC5)
+    small = run_gpu(gpu, raw, block_samples=4096, **NRSC5)
+    assert np.array_equal(ref, small)
+    splits = [1, 1, 2, 5, 16384, 3, 100000, 2047, 2049, 65536]
+    splits.append(n - sum(splits))
+    ragged = run_gpu(gpu, raw, splits=splits, block_samples=8192, **NRSC5)
+    assert np.array_equal(ref, ragged)
+    int_close(ref, run_oracle(oracle, raw, **NRSC5))
+
+
+def test_reference_chunking_16384(gpu, oracle):
+    """the reference hands over 16384-frame chunks (include/constants.h:123)"""
+    n = 16384 * 9 + 777
+    raw = synth.raw_stream(n, 2.4e6, 3, "cs16")
+    splits = [16384] * 9 + [777]
+    got = run_gpu(gpu, raw, splits=splits, **NRSC5)
+    int_close(got, run_oracle(oracle, raw, **NRSC5))
+    assert np.array_equal(got, run_gpu(gpu, raw, **NRSC5))
+
+
+def test_empty_and_tiny_calls(gpu, oracle):
+    ch = gpu.Chain(**NRSC5)
+    assert ch.process(np.zeros(0, np.int16)).size == 0
+    raw = synth.raw_stream(5, 2.4e6, 4, "cs16")
+    outs = [ch.process(raw[2 * i:2 * i + 2]) for i in range(5)]
+    want = run_oracle(oracle, raw, **NRSC5)
+    got = np.concatenate(outs)
+    int_close(got, want, 0.0)
+
+
+@pytest.mark.parametrize("ratio_rates", [(2.4e6, 2.0e6), (2.4e6, 1.2e6), (10e6, 2.4e6), (8e6, 0.9e6), (61.44e6, 1488375.0), (2.4e6, 2.4e6)])
+@pytest.mark.parametrize("fmt", ["cs16", "cu8"])
+def test_resample_ratios(gpu, oracle, ratio_rates, fmt):
+    """S = 0 .. 5 half-band stages, both benchmark input formats"""
+    fin, fout = ratio_rates
+    n = 1 << 19
+    raw = synth.raw_stream(n, fin, 5, fmt)
+    kw = dict(in_format=fmt, out_format="cf32", input_rate_hz=fin, target_rate_hz=fout, shift_hz=-137e3)
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, block_samples=65536, **kw))
+    assert got.size == want.size
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_shift_after_resample_and_gain(gpu, oracle):
+    n = 200000
+    raw = synth.raw_stream(n, 2.4e6, 6, "cs16")
+    kw = dict(NRSC5, shift_hz=-50e3, shift_after_resample=True, gain=0.7, out_format="cf32")
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, splits=[70000, 1, 129999], **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+
+
+def test_reset_restarts_the_stream(gpu, oracle):
+    n = 100000
+    raw = synth.raw_stream(n, 2.4e6, 8, "cs16")
+    ch = gpu.Chain(**NRSC5)
+    a = ch.process(raw)
+    ch.process(raw[:2 * 12345])
+    ch.reset()
+    b = ch.process(raw)
+    assert np.array_equal(a, b)
+
+
+# --------------------------------------------------------------------------------------------
+# dc block + iq correct (config 3 front end)
+# --------------------------------------------------------------------------------------------
+def test_dc_block_and_iq_correct(gpu, oracle):
+    n = 1 << 20
+    raw = synth.raw_stream(n, 10e6, 3, "cs16")
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=10e6, target_rate_hz=2.4e6,
+              dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005)
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, block_samples=65536, **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+    ragged = cf(run_gpu(gpu, raw, splits=[3, 50000, 16384, n - 66387], block_samples=16384, **kw))
+    assert np.abs(ragged - want).max() <= TOL
+
+
+def test_dc_block_operator(gpu, oracle):
+    from iq_tool_amd import ops
+    n = 400000
+    x = synth.complex_signal(n, 2.4e6, 9)
+    alpha = np.float32(2 * np.pi * 10.0 / 2.4e6)
+    want = oracle.DcBlock(alpha).apply(x)
+    got = ops.DcBlock(2.4e6).apply(x)
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_iq_correct_operator(gpu, oracle):
+    from iq_tool_amd import ops
+    x = synth.complex_signal(50000, 2.4e6, 10)
+    want = oracle.iq_correct(x, 0.01, -0.005)
+    got = ops.iq_correct_apply(x, 0.01, -0.005)
+    assert np.abs(got - want).max() <= 1e-6
+
+
+def test_freq_shift_operator(gpu, oracle):
+    from iq_tool_amd import ops
+    x = synth.complex_signal(300000, 2.4e6, 11)
+    for shift in (200e3, -333.3e3):
+        nco = oracle.Nco(np.float32(2 * np.pi * abs(shift) / 2.4e6))
+        want = nco.mix(x, up=shift >= 0)
+        op = ops.FreqShift(shift, 2.4e6)
+        got = np.concatenate([op.apply(x[:100001]), op.apply(x[100001:])])
+        assert np.abs(got - want).max() <= 2e-6
+
+
+def test_resampler_operator(gpu, oracle):
+    from iq_tool_amd import ops
+    x = synth.complex_signal(262144, 2.4e6, 12)
+    r = np.float32(744187.5 / 2.4e6)
+    want = oracle.MsResamp(r).execute(x)
+    rs = ops.Resampler(r)
+    got = rs.execute(x)
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+    rs.reset()
+    assert np.array_equal(rs.execute(x), got)
+
+
+# --------------------------------------------------------------------------------------------
+# user filter: FIR and FFT-block kinds
+# --------------------------------------------------------------------------------------------
+def test_config3_fft_bandpass(gpu, oracle):
+    n = 1 << 20
+    raw = synth.raw_stream(n, 10e6, 3, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6,
+              dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005,
+              filters=(("passband", 158.5e3, 113e3),), filter_taps=1024)
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, **kw)
+    assert got.size == want.size and got.size % (2 * 2048) == 0
+    int_close(got, want)
+    wc = cf(run_oracle(oracle, raw, **dict(kw, out_format="cf32")))
+    gc = cf(run_gpu(gpu, raw, splits=[100000, 16384, 16384, n - 132768], **dict(kw, out_format="cf32")))
+    assert gc.size == wc.size and np.abs(gc - wc).max() <= TOL
+
+
+def test_config4_long_fir(gpu, oracle):
+    n = 1 << 21
+    raw = synth.raw_stream(n, 61.44e6, 4, "cu8")
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0,
+              filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir")
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, **kw)
+    int_close(got, want)
+    wc = cf(run_oracle(oracle, raw, **dict(kw, out_format="cf32")))
+    gc = cf(run_gpu(gpu, raw, splits=[n // 3, n - n // 3], **dict(kw, out_format="cf32")))
+    assert gc.size == wc.size and np.abs(gc - wc).max() <= TOL
+
+
+def test_filter_operator_chain_of_two(gpu, oracle):
+    from iq_tool_amd import ops
+    x = synth.complex_signal(120000, 2.4e6, 13)
+    reqs = (("lowpass", 400e3, 0.0), ("stopband", 100e3, 40e3))
+    f = oracle.Filter(oracle.make_filter_cfg(reqs), 2.4e6, 2.4e6, no_resample=True)
+    want = f.apply(x)
+    op = ops.Filter(reqs, 2.4e6)
+    got = np.concatenate([op.apply(x[:50000]), op.apply(x[50000:])])
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+
+
+def test_fft_filter_block_quantised_counts(gpu, oracle):
+    """frames_out follows floor((remainder + in) / block) * block call by call (src/filter.c:503-525)"""
+    from iq_tool_amd import ops
+    x = synth.complex_signal(40000, 2.4e6, 14)
+    reqs = (("passband", 300e3, 100e3),)
+    f = oracle.Filter(oracle.make_filter_cfg(reqs, filter_taps=129), 2.4e6, 2.4e6, no_resample=True)
+    op = ops.Filter(reqs, 2.4e6, filter_taps=129)
+    pos = 0
+    for n in (100, 200, 300, 5000, 1, 20000, 14399):
+        w = f.apply(x[pos:pos + n])
+        g = op.apply(x[pos:pos + n])
+        assert g.size == w.size and g.size % f.block == 0
+        if g.size:
+            assert np.abs(g - w).max() <= TOL
+        pos += n
+
+
+def test_create_errors(gpu):
+    from iq_tool_amd import IqgpuError
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(input_rate_hz=2.4e6, target_rate_hz=100.0)
+    assert e.value.code == -4
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(in_format=3)
+    assert e.value.code == -5
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(shift_hz=0.0, shift_after_resample=True)
+    assert e.value.code == -6
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(filters=(("lowpass", 600e3, 0.0),))        # beyond the 372 kHz output Nyquist
+    assert e.value.code == -7
+
+
+def test_capacity_error_and_counts(gpu):
+    import ctypes as C
+    ch = gpu.Chain(**NRSC5)
+    n = 100000
+    raw = synth.raw_stream(n, 2.4e6, 1, "cs16")
+    nxt = ch.next_out_frames(n)
+    assert nxt <= ch.max_out_frames(n)
+    out = np.empty(16, np.uint8)
+    got = C.c_size_t(0)
+    rc = ch._lib.iqgpu_chain_process(ch._h, raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), 16, C.byref(got))
+    assert rc == -8 and got.value == 0
+    assert ch.process(raw).size == 2 * nxt        # the failed call consumed nothing
