@@ -7,7 +7,8 @@
 //   k_fir        time-domain FIR with LDS tap tiling over the cf32 filter-input buffer
 //
 // Reference semantics and file:line citations are in DESIGN.md; the per-operator arithmetic
-// follows sample_convert.c (bit-exact: explicit round-to-nearest intrinsics, no contraction),
+// follows sample_convert.c (bit-exact: this file is compiled with -ffp-contract=off, so a*b+c is
+// two roundings unless written as fmaf(); HIP's __fmul_rn/__fadd_rn are plain operators),
 // frequency_shift.c / dc_block.c / iq_correct.c / resampler.c / filter.c call sites.
 #include <hip/hip_runtime.h>
 
@@ -220,8 +221,8 @@ __device__ __forceinline__ cf2 nco_mix(cf2 x, cf2 cs, int mode)
 {
     const float s = (mode > 0) ? cs.y : -cs.y, c = cs.x;
     cf2 y;
-    y.x = x.x * c - x.y * s;
-    y.y = x.x * s + x.y * c;
+    y.x = fmaf(x.x, c, -(x.y * s));
+    y.y = fmaf(x.x, s, x.y * c);
     return y;
 }
 
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const FrontArgs a)
                 for (int s = 0; s < 4; ++s) if (!is_hist[s]) {
                     const float re = x[s].x;
                     x[s].x = re * a.iq_magp1;
-                    x[s].y = x[s].y + a.iq_phase * re;
+                    x[s].y = fmaf(a.iq_phase, re, x[s].y);
                 }
             }
 
