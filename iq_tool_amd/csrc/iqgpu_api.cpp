@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -98,6 +99,7 @@ struct iqgpu_chain {
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
     DevBuf stage_in, stage_out;
+    bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     // profiling
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
@@ -170,6 +172,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
         return fail(IQGPU_EINVAL, "input_rate_hz must be positive");
     c->desc = *d;
     c->device = d->device_ordinal;
+    { const char *fg = getenv("IQGPU_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
 
     // ---- ratio (src/setup.c:91-122) ----
     const double in_rate = d->input_rate_hz > 0.0 ? d->input_rate_hz : 1.0;
@@ -568,8 +571,18 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
         if (filt) { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
         else      { a.out_fmt = c->desc.out_format; a.out = d_out; }
+        // wave-autonomous fast path: one half-band stage (m = 10), no dc blocker
+        const bool fast_s1 = c->resample && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
+        if (fast_s1) {
+            a.w_total_tiles = (span_samples + kWTile - 1) / kWTile;
+            a.w_tiles_per_wave = c->tiles_per_block * kTile / (16 * kWTile);
+            if (a.w_tiles_per_wave < 1) a.w_tiles_per_wave = 1;
+            a.w_warm_tiles = (int)((c->rp.history_in + kWTile - 1) / kWTile);
+            for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
+        }
         KernelTimer kt(c, IQGPU_K_FRONT);
-        HIP_TRY(launch_front(a, n_blocks, c->stream));
+        if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
+        else HIP_TRY(launch_front(a, n_blocks, c->stream));
     }
     if (c->resample) c->hist_cur ^= 1;
 

@@ -10,6 +10,9 @@ constexpr int kTile = 2048;        // input samples per workgroup tile
 constexpr int kThreads = 256;      // 4 wavefronts of 64
 constexpr int kMaxS = 12;
 constexpr int kArbHist = 16;       // 13 needed, padded
+constexpr int kWTile = 512;        // input samples per wavefront tile (k_front_s1)
+constexpr int kWaves = 12;         // wavefronts per workgroup in k_front_s1 (3 per SIMD, 1 workgroup per CU)
+constexpr int kWThreads = kWaves * 64;
 constexpr int kFirOutTile = 1024;  // outputs per workgroup tile in the FIR kernel
 constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
 
@@ -63,6 +66,11 @@ struct FrontArgs {
     int64_t     total_tiles;
     int32_t     tiles_per_block;
     int32_t     warm_tiles;
+    // geometry of the wave-autonomous fast path (k_front_s1): tiles of kWTile samples
+    int64_t     w_total_tiles;
+    int32_t     w_tiles_per_wave;
+    int32_t     w_warm_tiles;
+    float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
     // post-resample NCO
     int32_t     pnco_mode;
     uint32_t    pnco_theta0, pnco_dtheta;
@@ -73,6 +81,9 @@ struct FrontArgs {
 
 size_t front_lds_bytes(const FrontArgs &a);
 hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
+// one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
+size_t front_s1_lds_bytes();
+hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments

@@ -331,3 +331,36 @@ def test_capacity_error_and_counts(gpu):
     rc = ch._lib.iqgpu_chain_process(ch._h, raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), 16, C.byref(got))
     assert rc == -8 and got.value == 0
     assert ch.process(raw).size == 2 * nxt        # the failed call consumed nothing
+
+
+def test_fast_and_generic_front_kernels_agree(gpu, oracle, monkeypatch):
+    """k_front_s1 (wave-autonomous) and k_front (workgroup-tiled) are the same arithmetic"""
+    n = 700001
+    raw = synth.raw_stream(n, 2.4e6, 21, "cs16")
+    kw = dict(NRSC5, out_format="cf32")
+    fast = cf(run_gpu(gpu, raw, splits=[300000, 7, 400001 - 7 - 0], **kw)) if False else cf(run_gpu(gpu, raw, **kw))
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = cf(run_gpu(gpu, raw, **kw))
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert fast.size == slow.size
+    assert np.abs(fast - slow).max() <= 2e-6
+    want = cf(run_oracle(oracle, raw, **kw))
+    assert np.abs(fast - want).max() <= TOL and np.abs(slow - want).max() <= TOL
+
+
+@pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
+def test_one_stage_chain_all_input_formats(gpu, oracle, fmt):
+    """the fast path's vector loaders (2, 4, 8 bytes per frame) and its scalar fallback"""
+    n = 200000
+    if fmt == "cf32":
+        raw = synth.complex_signal(n, 2.4e6, 22).view(np.float32)
+    elif fmt in ("cs24", "cs32"):
+        rng = np.random.default_rng(23)
+        raw = rng.integers(0, 256, n * oracle.BYTES[oracle.FMT[fmt]], dtype=np.uint8)
+    else:
+        x = synth.complex_signal(n, 2.4e6, 22)
+        raw = oracle.from_cf32(x, fmt)
+    kw = dict(in_format=fmt, out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=1.0e6, shift_hz=55e3, gain=0.9)
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, splits=[65536, 3, n - 65539], block_samples=32768, **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
