@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 CHAIN = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
-BLOCK_SAMPLES = 262144
+BLOCK_SAMPLES = 0               # auto: one contiguous run of tiles per resident wavefront
 SEGMENT_LOG2 = 22              # synthetic segment generated on the host, tiled on the device
 
 

@@ -87,7 +87,7 @@ typedef struct {
     int    fft_size;                    /* config->filter_fft_size_arg (0 = auto)                           */
     /* GPU-only knobs */
     int    device_ordinal;              /* HIP device index                                                 */
-    size_t block_samples;               /* input samples per workgroup block, multiple of 2048 (0 = 262144) */
+    size_t block_samples;               /* input samples per workgroup block, multiple of 2048; 0 = auto (one run per resident wave) */
 } iqgpu_chain_desc;
 
 /* What create() derived; for diagnostics and for parity tests of the design path. */
@@ -158,6 +158,10 @@ void  *iqgpu_chain_get_stream(const iqgpu_chain *c);
 int    iqgpu_chain_synchronize(iqgpu_chain *c);
 int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets every launch with HIP events  */
 int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
+
+/* diagnostic hook: copies the chain's 64 KiB scratch (store sink; per-phase cycle counters in builds
+ * made with -DIQGPU_STAMPS) to the host and clears it */
+int    iqgpu_chain_debug_read_scratch(iqgpu_chain *c, void *host_64k);
 
 /* ---- operator-level entry points (same kernels, one operator enabled) ----
  * Names follow the reference functions they replace. Host buffers. */

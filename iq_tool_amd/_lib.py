@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libiqgpu.so")
+LIB_PATH = os.environ.get("IQGPU_LIB") or os.path.join(HERE, "lib", "libiqgpu.so")
 
 FMT = dict(cu8=8, cs8=9, cu16=10, cs16=11, cs24=12, cu32=13, cs32=14, cf32=15, sc16q11=16)
 FMT_NAME = {v: k for k, v in FMT.items()}
@@ -77,6 +77,7 @@ SYMBOLS = [
     ("iqgpu_chain_synchronize", C.c_int, [_vp]),
     ("iqgpu_chain_set_profiling", C.c_int, [_vp, C.c_int]),
     ("iqgpu_chain_get_profile", C.c_int, [_vp, C.POINTER(Profile)]),
+    ("iqgpu_chain_debug_read_scratch", C.c_int, [_vp, _vp]),
     ("iqgpu_get_bytes_per_sample", _sz, [C.c_int]),
     ("iqgpu_convert_block_to_cf32", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_float, C.c_int]),
     ("iqgpu_convert_cf32_to_block", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int]),

@@ -38,7 +38,7 @@ def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
     if force or _stale(LIB, deps):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall",
                *srcs, "-o", LIB]
         if verbose:
             print(" ".join(cmd))

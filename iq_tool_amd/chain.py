@@ -22,7 +22,7 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
               resample_ratio=0.0, gain=1.0, shift_hz=0.0, shift_after_resample=False,
               dc_block=False, iq_correct=False, iq_mag=0.0, iq_phase=0.0, no_resample=False,
               filters=(), transition_width_hz=0.0, attenuation_db=0.0, filter_taps=0,
-              filter_impl="auto", fft_size=0, device=0, block_samples=262144):
+              filter_impl="auto", fft_size=0, device=0, block_samples=0):
     lib = _lib.load()
     d = ChainDesc()
     lib.iqgpu_chain_desc_init(C.byref(d))

@@ -8,15 +8,21 @@
 //     after the table load there is no workgroup barrier at all: 12 waves per CU drift apart and
 //     cover each other's HBM / LDS latency;
 //   * raw frames arrive by one coalesced 16-byte load per lane per 256 frames, issued one tile
-//     ahead (register prefetch);
+//     ahead (register prefetch) and consumed before the next prefetch is issued, so the only
+//     vmcnt wait of the loop lands on loads that are a whole tile old;
 //   * the NCO-mixed samples are written to LDS split into even / odd streams in rows of 4 cf32
 //     padded to 48 bytes (an odd number of 16-byte slots), so that a lane that owns 4 consecutive
 //     half-band outputs reads its 24-sample window with 12 conflict-free ds_read_b128 at constant
-//     offsets and keeps it in registers (20 taps x 4 outputs x 2 components of v_fma with the tap
-//     in an SGPR);
+//     offsets and keeps it in registers (20 taps x 4 outputs, re/im packed: v_pk_fma_f32 with the
+//     tap in an SGPR pair);
 //   * the polyphase stage gives each lane the 4 half-band samples it just produced: the output
 //     (if any) that falls on each of them is found in closed form from the 24-bit phase, its 14
 //     taps come from the 256-arm table in LDS, the 18-sample window again sits in registers.
+//
+// Tiles that touch the stream history, the end of the call, or an unaligned buffer ("edge" tiles)
+// are handled by a scalar-load instantiation of the same tile routine; the host gives those tiles
+// to a few extra waves (a handful of tiles each) so that the streaming waves run a loop with no
+// special cases in it.
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -36,9 +42,8 @@ size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kWaves * kWaveLds
 struct RawChunk { uint32_t w[8]; };
 
 template <int BPS>
-__device__ __forceinline__ void load_chunk(const void *raw, int64_t j, RawChunk &r)
+__device__ __forceinline__ void load_chunk(const char *p, RawChunk &r)
 {
-    const char *p = (const char *)raw + (int64_t)BPS * j;
     if (BPS == 4) {
         const uint4 v = *(const uint4 *)p;
         r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
@@ -52,23 +57,80 @@ __device__ __forceinline__ void load_chunk(const void *raw, int64_t j, RawChunk 
     }
 }
 
-// four frames from prefetched words; arithmetic identical to unpack_one (src/sample_convert.c:75-96)
+// ---- prefetch registers of the streaming variant.  The loads are issued from inline asm so that
+// hipcc's waitcnt pass does not track them: it would wait for them with vmcnt(0), which also drains
+// the output stores issued after them.  The kernel waits by hand with the exact count instead:
+// every loop iteration issues exactly 4 VMEM instructions (stores) after its loads.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <int BPS> struct Prefetch;
+template <> struct Prefetch<4> {
+    v4u c0, c1;
+    __device__ __forceinline__ void issue(const char *base, unsigned voff)
+    {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
+    }
+    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory"); }
+    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c1) :: "memory"); }
+    __device__ __forceinline__ void get(int c, RawChunk &r) const
+    {
+        const v4u v = c ? c1 : c0;
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    }
+};
+template <> struct Prefetch<2> {
+    v2u c0, c1;
+    __device__ __forceinline__ void issue(const char *base, unsigned voff)
+    {
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
+    }
+    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory"); }
+    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c1) :: "memory"); }
+    __device__ __forceinline__ void get(int c, RawChunk &r) const
+    {
+        const v2u v = c ? c1 : c0;
+        r.w[0] = v.x; r.w[1] = v.y;
+    }
+};
+template <> struct Prefetch<8> {
+    v4u c0, c0b, c1, c1b;
+    __device__ __forceinline__ void issue(const char *base, unsigned voff)
+    {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(c0b) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2064" : "=v"(c1b) : "v"(voff), "s"(base) : "memory");
+    }
+    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c0b), "+v"(c1), "+v"(c1b) :: "memory"); }
+    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c0b), "+v"(c1), "+v"(c1b) :: "memory"); }
+    __device__ __forceinline__ void get(int c, RawChunk &r) const
+    {
+        const v4u v = c ? c1 : c0, u = c ? c1b : c0b;
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+        r.w[4] = u.x; r.w[5] = u.y; r.w[6] = u.z; r.w[7] = u.w;
+    }
+};
+
+// four frames from prefetched words; arithmetic identical to unpack_one (src/sample_convert.c:75-96).
+// unit_gain skips the multiply by 1.0f (exact).
 template <int BPS>
-__device__ __forceinline__ void unpack_chunk(const RawChunk &r, int fmt, float gain, cf2 x[4])
+__device__ __forceinline__ void unpack_chunk(const RawChunk &r, int fmt, float gain, bool unit_gain, cf2 x[4])
 {
     if (BPS == 4) {
         if (fmt == IQGPU_FMT_CU16) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                x[s].x = up_u((float)(r.w[s] & 0xffffu), 32767.5f, 1.0f / 32768.0f, gain);
-                x[s].y = up_u((float)(r.w[s] >> 16), 32767.5f, 1.0f / 32768.0f, gain);
+                x[s].x = ((float)(r.w[s] & 0xffffu) - 32767.5f) * (1.0f / 32768.0f);
+                x[s].y = ((float)(r.w[s] >> 16) - 32767.5f) * (1.0f / 32768.0f);
             }
         } else {
             const float norm = (fmt == IQGPU_FMT_CS16) ? 1.0f / 32768.0f : 1.0f / 2048.0f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                x[s].x = up_s((float)(short)(r.w[s] & 0xffffu), norm, gain);
-                x[s].y = up_s((float)(short)(r.w[s] >> 16), norm, gain);
+                x[s].x = (float)(short)(r.w[s] & 0xffffu) * norm;
+                x[s].y = (float)(short)(r.w[s] >> 16) * norm;
             }
         }
     } else if (BPS == 2) {
@@ -76,233 +138,371 @@ __device__ __forceinline__ void unpack_chunk(const RawChunk &r, int fmt, float g
         for (int s = 0; s < 4; ++s) {
             const unsigned h = r.w[s >> 1] >> ((s & 1) * 16);
             if (fmt == IQGPU_FMT_CU8) {
-                x[s].x = up_u((float)(h & 0xffu), 127.5f, 1.0f / 128.0f, gain);
-                x[s].y = up_u((float)((h >> 8) & 0xffu), 127.5f, 1.0f / 128.0f, gain);
+                x[s].x = ((float)(h & 0xffu) - 127.5f) * (1.0f / 128.0f);
+                x[s].y = ((float)((h >> 8) & 0xffu) - 127.5f) * (1.0f / 128.0f);
             } else {
-                x[s].x = up_s((float)(signed char)(h & 0xffu), 1.0f / 128.0f, gain);
-                x[s].y = up_s((float)(signed char)((h >> 8) & 0xffu), 1.0f / 128.0f, gain);
+                x[s].x = (float)(signed char)(h & 0xffu) * (1.0f / 128.0f);
+                x[s].y = (float)(signed char)((h >> 8) & 0xffu) * (1.0f / 128.0f);
             }
         }
     } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            x[s].x = __uint_as_float(r.w[2 * s]) * gain;
-            x[s].y = __uint_as_float(r.w[2 * s + 1]) * gain;
+            x[s].x = __uint_as_float(r.w[2 * s]);
+            x[s].y = __uint_as_float(r.w[2 * s + 1]);
         }
+    }
+    if (!unit_gain) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { x[s].x *= gain; x[s].y *= gain; }
     }
 }
 
-// smallest q with q * d >= x, for quotients below 2^9 (x < 2^33, d > 2^24)
-__device__ __forceinline__ uint32_t ceil_div_small(uint64_t x, uint32_t d, float inv_d)
+// smallest q with q * d >= x, for 0 < x < 2^32, 2^24 <= d <= 2^25 (quotient below 2^8): float
+// estimate (absolute error far below 1) and two branch-free corrections
+__device__ __forceinline__ uint32_t ceil_div_small(uint32_t x, uint32_t d, float inv_d)
 {
     uint32_t q = (uint32_t)((float)x * inv_d);
-    while ((uint64_t)q * d < x) ++q;
-    while (q > 0 && (uint64_t)(q - 1) * d >= x) --q;
+    q += ((uint64_t)q * d < (uint64_t)x) ? 1u : 0u;
+    q -= (q > 0 && (uint64_t)(q - 1) * d >= (uint64_t)x) ? 1u : 0u;
     return q;
 }
 
 __device__ __forceinline__ float4 ld4(const char *p) { return *(const float4 *)p; }
 
-// BPS: bytes per input frame on the vector-load path (2, 4, 8); 0 = scalar loads only
-template <int BPS>
-__global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
+// ---- packed-f32 primitives (VOP3P).  hipcc's SLP vectoriser does find v_pk_fma_f32 on its own but
+// pays for every scalar broadcast with v_mov pairs and serialises the polyphase chains; the three
+// hot inner products are therefore written with explicit op_sel forms (this file is compiled with
+// -fno-slp-vectorize).  A v2f is one {re, im} sample in an aligned VGPR pair.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc += t.lo * x   /   acc += t.hi * x      (t: a pair of real taps, x: {re, im})
+__device__ __forceinline__ void pk_fma_lo(v2f &acc, v2f t, v2f x)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    cf2   *s_nco = (cf2 *)smem;
-    float *s_arb = (float *)(smem + 1024 * 8);
-    char *XE = (char *)smem + kTabLds + wave * kWaveLds;
-    char *XO = XE + kXRows * kRowB;
-    char *HB = XO + kXRows * kRowB;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_hi(v2f &acc, v2f t, v2f x)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t), "v"(x));
+}
+// the same with the tap pair in SGPRs (wave-uniform half-band taps)
+__device__ __forceinline__ void pk_fma_lo_s(v2f &acc, v2f t, v2f x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_hi_s(v2f &acc, v2f t, v2f x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+// x * (c + j s) with cs = {c, s}:  t = {-xi s, xi c};  y = {xr c, xr s} + t
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f cs)
+{
+    v2f t, y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(x), "v"(cs));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y) : "v"(x), "v"(cs), "v"(t));
+    return y;
+}
+__device__ __forceinline__ v2f nco_phasor2(const cf2 *tab, uint32_t theta)
+{
+    return *(const v2f *)(tab + ((theta + (1u << 21)) >> 22));
+}
 
-    if (a.nco_mode != 0 || a.pnco_mode != 0)
-        for (int i = tid; i < 1024; i += kWThreads) s_nco[i] = a.nco_tab[i];
-    for (int i = tid; i < 256 * 14; i += kWThreads) s_arb[i] = a.arb_table[(i / 14) * 16 + (i % 14)];
-    for (int i = lane; i < kWaveLds / 16; i += 64) ((float4 *)XE)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+// y = x * (c + j s); the sign of s for mix-down is folded into the LDS copy of the table
+__device__ __forceinline__ cf2 cmul_tab(cf2 x, cf2 cs)
+{
+    cf2 y;
+    y.x = fmaf(x.x, cs.x, -(x.y * cs.y));
+    y.y = fmaf(x.x, cs.y, x.y * cs.x);
+    return y;
+}
 
-    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
-    const int64_t t_emit0 = gw * a.w_tiles_per_wave;
-    if (t_emit0 >= a.w_total_tiles) return;
-    int64_t t_emit1 = t_emit0 + a.w_tiles_per_wave;
-    if (t_emit1 > a.w_total_tiles) t_emit1 = a.w_total_tiles;
-    const int64_t t_begin = t_emit0 - a.w_warm_tiles;
-
-    if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
-        const int keep = a.hist_cap - (int)a.frames_in;
-        for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
+// frame -> base[idx]; base is wave-uniform, idx a small per-lane offset.  cs16: same result as
+// src/sample_convert.c:40-57 for every finite input -- +-0.5 by sign is a copysign (0 gives 0 either
+// way), truncation then int16 saturation equals float clamp then truncation.
+__device__ __forceinline__ void pack_store_at(char *base, uint32_t idx, int fmt, cf2 v)
+{
+    if (fmt == IQGPU_FMT_CS16) {
+        float p = v.x * 32767.0f, q = v.y * 32767.0f;
+        p += copysignf(0.5f, p); q += copysignf(0.5f, q);
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)p, (int)q);
+        *(s2 *)(base + 4u * idx) = pk;
+    } else if (fmt == IQGPU_FMT_CF32) {
+        *(cf2 *)(base + 8u * idx) = v;
+    } else {
+        pack_store(base, (int64_t)idx, fmt, v);
     }
+}
 
-    // output bookkeeping (uniform): first output whose half-band sample is >= this wave's first one
+__device__ __forceinline__ int out_bytes(int fmt)
+{
+    return (fmt == IQGPU_FMT_CS8 || fmt == IQGPU_FMT_CU8) ? 2 : (fmt == IQGPU_FMT_CS24) ? 6
+         : (fmt == IQGPU_FMT_CS32 || fmt == IQGPU_FMT_CU32 || fmt == IQGPU_FMT_CF32) ? 8 : 4;
+}
+
+// ---- optional in-kernel stamps (diagnostic build only: -DIQGPU_STAMPS; never in the shipped .so).
+// Per-phase cycle sums of every wave are added into a.sink[32 KiB ...] as u64 counters.
+#ifdef IQGPU_STAMPS
+#define STAMP_DECL unsigned long long st_last = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_BEGIN do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_last = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#define STAMP_FLUSH(sinkbase) do { if (lane == 0) { unsigned long long *d_ = (unsigned long long *)((char *)(sinkbase) + 32768); for (int i_ = 0; i_ < 8; ++i_) atomicAdd(d_ + i_, st_acc[i_]); } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN do { } while (0)
+#define STAMP(i) do { } while (0)
+#define STAMP_FLUSH(sinkbase) do { } while (0)
+#endif
+
+struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; char *sink; };
+
+// Tiles [t_begin, t_emit1) of kWTile frames; those from t_emit0 on produce output.
+// EDGE = false: every tile (and the one after the last, for the prefetch) lies inside the call's
+//               new, aligned frames and outside the history the call leaves behind.
+// EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
+template <int BPS, bool EDGE>
+__device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
+                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1)
+{
+    constexpr int VB = BPS ? BPS : 4;
+    char *XE = w.XE, *XO = w.XO, *HB = w.HB;
+
+    // output bookkeeping (wave-uniform): first output whose half-band sample is >= this run's first
     const uint32_t step = a.step;
     const float inv_step = 1.0f / (float)step;
     uint64_t k_tile0 = first_k_at((uint64_t)(t_emit0 * 256) << 24, a.phi0, step);
-    uint64_t delta0 = a.phi0 + k_tile0 * (uint64_t)step - ((uint64_t)(t_emit0 * 256) << 24);   // < step
+    uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - ((uint64_t)(t_emit0 * 256) << 24));   // < step
+    const int obps = out_bytes(a.out_fmt);
+    const bool unit_gain = a.gain == 1.0f;
+    const int woff = (5 + (lane >> 1)) * kRowB + (lane & 1) * 16;       // this lane's LDS write slot
 
-    const bool vec_ok = (BPS != 0) && a.raw_aligned;
-    RawChunk nxt[2];
-    bool have_next = false;
-    {
-        const int64_t j0 = t_begin * kWTile - a.rem0;
-        if (vec_ok && j0 >= 0 && j0 + kWTile <= a.frames_in && (((j0 * BPS) & 15) == 0)) {
-            load_chunk<BPS ? BPS : 4>(a.raw, j0 + 4 * lane, nxt[0]);
-            load_chunk<BPS ? BPS : 4>(a.raw, j0 + 256 + 4 * lane, nxt[1]);
-            have_next = true;
-        }
-    }
+    Prefetch<VB> pf;
+    const unsigned voff = (unsigned)(4 * VB * lane);
+    if (!EDGE) pf.issue((const char *)a.raw + (t_begin * kWTile - a.rem0) * VB, voff);
 
+    STAMP_DECL
+    STAMP_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
         const int64_t i0 = t * kWTile;
         const int64_t j0 = i0 - a.rem0;
         const bool emit = t >= t_emit0;
-        const bool fast = have_next;
-        RawChunk cur[2];
-        if (fast) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
-        {   // prefetch the next tile's frames
-            const int64_t jn = j0 + kWTile;
-            have_next = false;
-            if (t + 1 < t_emit1 && vec_ok && jn >= 0 && jn + kWTile <= a.frames_in && (((jn * BPS) & 15) == 0)) {
-                load_chunk<BPS ? BPS : 4>(a.raw, jn + 4 * lane, nxt[0]);
-                load_chunk<BPS ? BPS : 4>(a.raw, jn + 256 + 4 * lane, nxt[1]);
-                have_next = true;
-            }
-        }
 
         // ------------------------------------------------------------ pointwise -> LDS
+        cf2 x[2][4];
+        if (!EDGE) {
+            // consume the prefetched frames first: the wait for them lands here, before the next
+            // tile's loads are issued, so those stay in flight across the whole tile
+            if (t == t_begin) pf.wait_first(); else pf.wait_steady();
+            STAMP(0);
+            {
+                RawChunk r0, r1;
+                pf.get(0, r0); pf.get(1, r1);
+                unpack_chunk<VB>(r0, a.in_fmt, a.gain, unit_gain, x[0]);
+                unpack_chunk<VB>(r1, a.in_fmt, a.gain, unit_gain, x[1]);
+            }
+            // x[][] must be complete before the registers are handed back to the memory pipe
+            asm volatile("" : "+v"(x[0][0].x), "+v"(x[0][3].y), "+v"(x[1][0].x), "+v"(x[1][3].y));
+            pf.issue((const char *)a.raw + (j0 + kWTile) * VB, voff);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int l4 = 256 * c + 4 * lane;
-            const int64_t j = j0 + l4;
-            cf2 x[4];
-            bool is_hist[4] = {false, false, false, false};
-            bool is_new[4] = {true, true, true, true};
-            if (fast) {
-                unpack_chunk<BPS ? BPS : 4>(cur[c], a.in_fmt, a.gain, x);
-            } else {
+            for (int c = 0; c < 2; ++c) {
+                if (a.iq_enable) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int64_t js = j + s;
-                    if (js < 0) {
-                        const int64_t h = (int64_t)a.hist_cap + js;
-                        x[s] = (h >= 0) ? a.hist_in[h] : cf2{0.0f, 0.0f};
-                        is_hist[s] = true; is_new[s] = false;
-                    } else if (js >= a.frames_in) {
-                        x[s] = cf2{0.0f, 0.0f};
-                        is_new[s] = false;
-                    } else {
-                        x[s] = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                    for (int s = 0; s < 4; ++s) {
+                        const float re = x[c][s].x;
+                        x[c][s].x = re * a.iq_magp1;
+                        x[c][s].y = fmaf(a.iq_phase, re, x[c][s].y);
+                    }
+                }
+                if (a.nco_mode != 0) {
+                    uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, nco_phasor2(w.nco, th));
+                        x[c][s] = cf2{y.x, y.y};
+                        th += a.nco_dtheta;
                     }
                 }
             }
-            if (a.iq_enable) {
+        } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) if (!is_hist[s]) {
-                    const float re = x[s].x;
-                    x[s].x = re * a.iq_magp1;
-                    x[s].y = fmaf(a.iq_phase, re, x[s].y);
-                }
-            }
-            if (a.nco_mode != 0) {
-                uint32_t th = a.nco_theta0 + (uint32_t)(i0 + l4) * a.nco_dtheta;
+            for (int c = 0; c < 2; ++c) {
+                const int l4 = 256 * c + 4 * lane;
+                const int64_t j = j0 + l4;
+                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if (!is_hist[s]) x[s] = nco_mix(x[s], nco_phasor(s_nco, th), a.nco_mode);
+                    const int64_t js = j + s;
+                    cf2 v{0.0f, 0.0f};
+                    if (js < 0) {
+                        const int64_t h = (int64_t)a.hist_cap + js;
+                        if (h >= 0) v = a.hist_in[h];                 // already fully processed
+                    } else if (js < a.frames_in) {
+                        v = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                        if (a.iq_enable) {
+                            const float re = v.x;
+                            v.x = re * a.iq_magp1;
+                            v.y = fmaf(a.iq_phase, re, v.y);
+                        }
+                        if (a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
+                        const int64_t back = a.frames_in - js;          // 1 .. hist_cap for kept frames
+                        if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
+                    }
+                    x[c][s] = v;
                     th += a.nco_dtheta;
                 }
             }
-            if (emit && j + 4 > a.frames_in - (int64_t)a.hist_cap) {
+        }
+#if defined(IQGPU_ABL) && IQGPU_ABL >= 6
+        if (EDGE || x[0][0].x == 12345.678f)
+#endif
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int64_t back = a.frames_in - (j + s);
-                    if (is_new[s] && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = x[s];
-                }
-            }
-            const int off = (5 + 32 * c + (lane >> 1)) * kRowB + (lane & 1) * 16;
-            *(float4 *)(XE + off) = make_float4(x[0].x, x[0].y, x[2].x, x[2].y);
-            *(float4 *)(XO + off) = make_float4(x[1].x, x[1].y, x[3].x, x[3].y);
+        for (int c = 0; c < 2; ++c) {
+            const int off = woff + 32 * c * kRowB;
+            *(float4 *)(XE + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
+            *(float4 *)(XO + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(1);
 
         // ------------------------------------------------------------ half-band: 4 outputs per lane
+#if defined(IQGPU_ABL) && IQGPU_ABL >= 5
+        if (EDGE)
+#endif
         {
             const char *we = XE + lane * kRowB;
-            cf2 E[24];
+            v2f E[24];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const float4 v0 = ld4(we + r * kRowB), v1 = ld4(we + r * kRowB + 16);
-                E[4 * r + 0] = cf2{v0.x, v0.y}; E[4 * r + 1] = cf2{v0.z, v0.w};
-                E[4 * r + 2] = cf2{v1.x, v1.y}; E[4 * r + 3] = cf2{v1.z, v1.w};
+                E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
+                E[4 * r + 2] = v2f{v1.x, v1.y}; E[4 * r + 3] = v2f{v1.z, v1.w};
             }
             const char *wo = XO + lane * kRowB;
             const float4 o0 = ld4(wo + 2 * kRowB + 16), o1 = ld4(wo + 3 * kRowB);
-            float ar[4] = {0.5f * o0.x, 0.5f * o0.z, 0.5f * o1.x, 0.5f * o1.z};
-            float ai[4] = {0.5f * o0.y, 0.5f * o0.w, 0.5f * o1.y, 0.5f * o1.w};
+            v2f acc[4] = {v2f{0.5f * o0.x, 0.5f * o0.y}, v2f{0.5f * o0.z, 0.5f * o0.w},
+                          v2f{0.5f * o1.x, 0.5f * o1.y}, v2f{0.5f * o1.z, 0.5f * o1.w}};
+            const v2f *hbp = (const v2f *)a.hb0;          // 10 SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
-            for (int q = 0; q < 20; ++q) {
-                const float h = a.hb0[q];
+            for (int q2 = 0; q2 < 10; ++q2) {
+                const v2f tp = hbp[q2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ar[r] = fmaf(h, E[20 + r - q].x, ar[r]);
-                    ai[r] = fmaf(h, E[20 + r - q].y, ai[r]);
-                }
+                for (int r = 0; r < 4; ++r) pk_fma_lo_s(acc[r], tp, E[20 + r - 2 * q2]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk_fma_hi_s(acc[r], tp, E[19 + r - 2 * q2]);
             }
             char *ph = HB + (lane + 4) * kRowB;
-            *(float4 *)ph = make_float4(ar[0], ai[0], ar[1], ai[1]);
-            *(float4 *)(ph + 16) = make_float4(ar[2], ai[2], ar[3], ai[3]);
+            *(float4 *)ph = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+            *(float4 *)(ph + 16) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
         }
         __builtin_amdgcn_wave_barrier();
 
         // ------------------------------------------------------------ polyphase + pack
-        if (emit) {
+        // The streaming variant runs this stage on warm-up tiles too (with every hit masked off) and
+        // always executes its 4 store instructions -- lanes without an output write to a small
+        // L2-resident sink -- so that the loop body is branch-free and hipcc can wait for the
+        // prefetched frames with vmcnt(4) instead of draining the stores with vmcnt(0).
+#if defined(IQGPU_ABL) && IQGPU_ABL >= 4
+        if (EDGE && emit) {
+#else
+        if (!EDGE || emit) {
+#endif
             const int64_t q_tile0 = t * 256;
-            if (q_tile0 < a.n_groups) {
+            if (!EDGE || q_tile0 < a.n_groups) {
                 const char *wh = HB + lane * kRowB;
-                cf2 H[18];
+                v2f H[18];
                 {
                     const float4 v = ld4(wh + 16);
-                    H[0] = cf2{v.x, v.y}; H[1] = cf2{v.z, v.w};
+                    H[0] = v2f{v.x, v.y}; H[1] = v2f{v.z, v.w};
                 }
 #pragma unroll
                 for (int r = 1; r < 5; ++r) {
                     const float4 v0 = ld4(wh + r * kRowB), v1 = ld4(wh + r * kRowB + 16);
-                    H[4 * r - 2] = cf2{v0.x, v0.y}; H[4 * r - 1] = cf2{v0.z, v0.w};
-                    H[4 * r + 0] = cf2{v1.x, v1.y}; H[4 * r + 1] = cf2{v1.z, v1.w};
+                    H[4 * r - 2] = v2f{v0.x, v0.y}; H[4 * r - 1] = v2f{v0.z, v0.w};
+                    H[4 * r + 0] = v2f{v1.x, v1.y}; H[4 * r + 1] = v2f{v1.z, v1.w};
                 }
-                // first output at or after this lane's first half-band sample (4*lane)
-                const uint64_t tgt = (uint64_t)(4 * lane) << 24;
+                // first output at or after this lane's first half-band sample (4 * lane)
+                const uint32_t tgt = (uint32_t)(4 * lane) << 24;
                 uint32_t n0 = 0;
                 if (tgt > delta0) n0 = ceil_div_small(tgt - delta0, step, inv_step);
-                uint32_t Pl = (uint32_t)(delta0 + (uint64_t)n0 * step - tgt);     // phase relative to 4*lane
-                uint32_t kk = n0;
+                uint32_t Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);   // phase relative to 4*lane
+                // the (at most one) output on each of the 4 samples: slot hit, arm, taps
+                bool hit[4];
+                v2f tp[4][7];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool hit = (Pl >> 24) == (uint32_t)r;
-                    const int arm = (int)((Pl >> 16) & 255u);
-                    const float2 *tp = (const float2 *)(s_arb + arm * 14);
-                    float yr = 0.0f, yi = 0.0f;
+                    hit[r] = (Pl >> 24) == (uint32_t)r;
+                    // 7 x ds_read_b64 of the arm's 14 taps (56-byte rows; issued from asm so that they
+                    // are not fused into half-rate ds_read2_b64)
+                    const unsigned arm = (Pl >> 16) & 255u;
+                    const unsigned row = w.arb_lds + (arm ^ (arm >> 5)) * 56u;
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(tp[r][0]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(tp[r][1]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(tp[r][2]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(tp[r][3]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(tp[r][4]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:40" : "=v"(tp[r][5]) : "v"(row));
+                    asm volatile("ds_read_b64 %0, %1 offset:48" : "=v"(tp[r][6]) : "v"(row));
+                    if (hit[r]) Pl += step;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(3);
+                v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
-                    for (int n2 = 0; n2 < 7; ++n2) {
-                        const float2 tt = tp[n2];
-                        yr = fmaf(tt.x, H[14 + r - 2 * n2].x, yr); yi = fmaf(tt.x, H[14 + r - 2 * n2].y, yi);
-                        yr = fmaf(tt.y, H[13 + r - 2 * n2].x, yr); yi = fmaf(tt.y, H[13 + r - 2 * n2].y, yi);
+                for (int n2 = 0; n2 < 7; ++n2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk_fma_lo(y[r], tp[r][n2], H[14 + r - 2 * n2]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk_fma_hi(y[r], tp[r][n2], H[13 + r - 2 * n2]);
+                }
+                STAMP(4);
+                // half-band samples of this tile that exist in this call
+                uint32_t q_lim = 256u;
+                if (EDGE) { const int64_t left = a.n_groups - q_tile0; if (left < 256) q_lim = (uint32_t)left; }
+                char *obase = (char *)a.out + (int64_t)k_tile0 * obps;
+                const uint32_t pth0 = a.pnco_theta0 + (uint32_t)k_tile0 * a.pnco_dtheta;
+                uint32_t kk = n0;
+                if (EDGE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (hit[r] && (uint32_t)(4 * lane + r) < q_lim) {
+                            v2f yy = y[r];
+                            if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
+                            pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
+                        }
+                        kk += hit[r] ? 1u : 0u;
                     }
-                    if (hit && (q_tile0 + 4 * lane + r) < a.n_groups) {
-                        const uint64_t k = k_tile0 + kk;
-                        cf2 y{yr, yi};
-                        if (a.pnco_mode != 0)
-                            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
-                        pack_store(a.out, (int64_t)k, a.out_fmt, y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v2f yy = y[r];
+                        if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
+                        const bool real = hit[r] && emit;
+#if defined(IQGPU_ABL) && IQGPU_ABL == 1      // ablation: no stores at all
+                        asm volatile("" :: "v"(yy), "v"(real));
+#elif defined(IQGPU_ABL) && IQGPU_ABL == 2    // ablation: every lane stores to the sink
+                        pack_store_at(w.sink, (uint32_t)lane, a.out_fmt, cf2{yy.x, yy.y});
+#elif defined(IQGPU_ABL) && IQGPU_ABL == 3    // ablation: dense store (wrong data placement, same bytes)
+                        pack_store_at(obase, (uint32_t)(lane + 64 * r), a.out_fmt, cf2{yy.x, yy.y});
+#else
+                        pack_store_at(real ? obase : w.sink, real ? kk : (uint32_t)lane, a.out_fmt, cf2{yy.x, yy.y});
+#endif
+                        kk += hit[r] ? 1u : 0u;
                     }
-                    if (hit) { Pl += step; ++kk; }
                 }
             }
-            // outputs of this tile: those with phase below 256 * 2^24
-            const uint32_t n_tile = ceil_div_small(((uint64_t)1 << 32) - delta0, step, inv_step);
-            k_tile0 += n_tile;
-            delta0 = delta0 + (uint64_t)n_tile * step - ((uint64_t)1 << 32);
+            // outputs of this tile, ceil((2^32 - delta0) / step) = floor((2^32 - 1 - delta0) / step) + 1
+            const uint32_t xm = 0xffffffffu - delta0;
+            uint32_t nfl = (uint32_t)((float)xm * inv_step);
+            nfl -= ((uint64_t)nfl * step > (uint64_t)xm) ? 1u : 0u;
+            nfl += ((uint64_t)(nfl + 1) * step <= (uint64_t)xm) ? 1u : 0u;
+            const uint32_t nt = nfl + 1u;
+            if (emit) {
+                k_tile0 += nt;
+                delta0 = (uint32_t)((uint64_t)delta0 + (uint64_t)nt * step - ((uint64_t)1 << 32));
+            }
         }
 
+        STAMP(5);
         // ------------------------------------------------------------ slide the windows
         {
             float4 ve, vo, vh;
@@ -313,14 +513,69 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
             if (lane < 12) *(float4 *)(HB + lane * 16) = vh;
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(6);
+    }
+    STAMP_FLUSH(a.sink);
+}
+
+// BPS: bytes per input frame on the vector-load path (2, 4, 8); 0 = no vector path for this format
+template <int BPS>
+__global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cf2   *s_nco = (cf2 *)smem;
+    float *s_arb = (float *)(smem + 1024 * 8);
+    WaveLds w;
+    w.XE = (char *)smem + kTabLds + wave * kWaveLds;
+    w.XO = w.XE + kXRows * kRowB;
+    w.HB = w.XO + kXRows * kRowB;
+    w.nco = s_nco; w.arb = s_arb;
+    w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;   // LDS byte address
+    w.sink = (char *)a.sink + (((unsigned)blockIdx.x * kWaves + (unsigned)wave) & 31u) * 1024u;   // lower 32 KiB (upper half: diagnostics)
+
+    if (a.nco_mode != 0 || a.pnco_mode != 0) {
+        const float sgn = (a.nco_mode < 0 || a.pnco_mode < 0) ? -1.0f : 1.0f;   // mix down: conj(phasor)
+        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x, sgn * v.y}; }
+    }
+    // polyphase taps: arm a lives in row a ^ (a >> 5).  The arms that the lanes of one gather touch
+    // form an arithmetic progression (mod 256); with plain 56-byte rows that lands 3.3x the cycles of
+    // a conflict-free ds_read_b64 on MI355X for the NRSC-5 step, with the XOR-folded rows 1.1x
+    // (tools/lds_gather_bench.hip).
+    for (int i = tid; i < 256 * 14; i += kWThreads) {
+        const int arm = i / 14, k = i % 14;
+        s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
+    }
+    for (int i = lane; i < kWaveLds / 16; i += 64) ((float4 *)w.XE)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+    if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
+        const int keep = a.hist_cap - (int)a.frames_in;
+        for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
+    }
+
+    if (gw < a.w_n_edge) {
+        // edge work: tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) in runs of w_edge_tpw
+        int64_t t0, t1;
+        if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
+        else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        run_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+    } else {
+        const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
+        if (g >= a.w_fast_g1) return;
+        const int64_t t0 = g * a.w_tiles_per_wave;
+        if (BPS != 0) run_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
     }
 }
 
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 {
     const size_t lds = front_s1_lds_bytes();
-    const int64_t n_sub = (a.w_total_tiles + a.w_tiles_per_wave - 1) / a.w_tiles_per_wave;
-    const unsigned grid = (unsigned)((n_sub + kWaves - 1) / kWaves);
+    const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
+    const unsigned grid = (unsigned)((n_items + kWaves - 1) / kWaves);
+    if (grid == 0) return hipSuccess;
     int cls;
     switch (a.in_fmt) {
     case IQGPU_FMT_CS8: case IQGPU_FMT_CU8: cls = 2; break;
@@ -341,6 +596,41 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     else IQGPU_LAUNCH_S1(0);
 #undef IQGPU_LAUNCH_S1
     return hipGetLastError();
+}
+
+// Splits the call's tiles into streaming sub-blocks (all tiles vector-loadable) and edge runs.
+void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tpw)
+{
+    const int64_t total = a.w_total_tiles;
+    int vb;
+    switch (a.in_fmt) {
+    case IQGPU_FMT_CS8: case IQGPU_FMT_CU8: vb = 2; break;
+    case IQGPU_FMT_CS16: case IQGPU_FMT_CU16: case IQGPU_FMT_SC16Q11: vb = 4; break;
+    case IQGPU_FMT_CF32: vb = 8; break;
+    default: vb = 0; break;
+    }
+    a.w_tiles_per_wave = tiles_per_wave;
+    a.w_warm_tiles = warm_tiles;
+    a.w_edge_tpw = edge_tpw;
+    int64_t g0 = 0, g1 = 0;
+    // (cs24 output takes six byte stores per frame: the streaming loop counts on one)
+    if (vb != 0 && a.out_fmt != IQGPU_FMT_CS24 && a.raw_aligned && (((int64_t)a.rem0 * vb) & 15) == 0) {
+        // tile t is streamable iff 512 t - rem0 >= 0 and 512 (t + 1) - rem0 <= frames_in - hist_cap
+        const int64_t t_min = (a.rem0 + kWTile - 1) / kWTile;
+        const int64_t lim = a.frames_in - (int64_t)a.hist_cap + a.rem0;
+        const int64_t t_max = lim >= kWTile ? lim / kWTile - 1 : -1;              // last streamable tile
+        // sub-block g touches tiles [g tpw - warm, (g + 1) tpw] (one past its end for the prefetch)
+        g0 = (t_min + warm_tiles + tiles_per_wave - 1) / tiles_per_wave;
+        g1 = (t_max >= 0) ? (t_max / tiles_per_wave) : 0;                          // g1 * tpw <= t_max
+        if (g1 < g0) g1 = g0;
+    }
+    a.w_fast_g0 = g0; a.w_fast_g1 = g1;
+    if (g1 > g0) { a.w_edge_ta = g0 * tiles_per_wave; a.w_edge_tb = g1 * tiles_per_wave; }
+    else { a.w_edge_ta = total; a.w_edge_tb = total; }
+    if (a.w_edge_ta > total) a.w_edge_ta = total;
+    if (a.w_edge_tb > total) a.w_edge_tb = total;
+    a.w_n_edge1 = (a.w_edge_ta + edge_tpw - 1) / edge_tpw;
+    a.w_n_edge = a.w_n_edge1 + (total - a.w_edge_tb + edge_tpw - 1) / edge_tpw;
 }
 
 } // namespace iqgpu

@@ -81,6 +81,8 @@ struct iqgpu_chain {
     // geometry
     int S = 0, D = 1, TG = kTile;
     int warm_tiles = 0, hist_cap = 0, tiles_per_block = 128;
+    bool auto_block = true;      // block_samples == 0: size the per-wave runs from the call and the CU count
+    int n_cu = 256;
     uint32_t n_est = 0;
     int lvl_off[kMaxS + 2] = {0};
     int tap_off[kMaxS] = {0};
@@ -96,6 +98,7 @@ struct iqgpu_chain {
     cf2 *d_nco_tab = nullptr; float *d_arb = nullptr; float *d_hb = nullptr; cf2 *d_ftaps = nullptr;
     cf2 *d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
     cd2 *d_dc_state = nullptr;
+    void *d_sink = nullptr;      // store sink of k_front_s1
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
     DevBuf stage_in, stage_out;
@@ -130,7 +133,7 @@ extern "C" void iqgpu_chain_desc_init(iqgpu_chain_desc *d)
     d->out_format = IQGPU_FMT_CS16;
     d->gain = 1.0f;              // src/main.c:145
     d->no_resample = 0;
-    d->block_samples = 262144;
+    d->block_samples = 0;        // auto: one contiguous run per resident wavefront
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,6 +148,7 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_ftaps) (void)hipFree(c->d_ftaps);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_dc_state) (void)hipFree(c->d_dc_state);
+    if (c->d_sink) (void)hipFree(c->d_sink);
     c->dc_agg.release(); c->dc_carry.release();
     c->fbuf[0].release(); c->fbuf[1].release();
     c->stage_in.release(); c->stage_out.release();
@@ -228,6 +232,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     }
 
     // ---- geometry ----
+    c->auto_block = d->block_samples == 0;
     size_t block = d->block_samples ? d->block_samples : 262144;
     if (block % kTile != 0 || block == 0) return fail(IQGPU_EINVAL, "block_samples must be a multiple of %d", kTile);
     c->tiles_per_block = (int)(block / kTile);
@@ -269,6 +274,10 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
 #define CREATE_RC(expr) do { rc = (expr); if (rc != IQGPU_OK) goto bad; } while (0)
     {
         CREATE_TRY(hipSetDevice(c->device));
+        {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+        }
         CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         std::vector<cfloat> tab(1024);
@@ -292,6 +301,8 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
         CREATE_TRY(hipMalloc((void **)&c->d_dc_state, sizeof(cd2)));
         CREATE_TRY(hipMemset(c->d_dc_state, 0, sizeof(cd2)));
+        CREATE_TRY(hipMalloc(&c->d_sink, 64 * 1024));
+        CREATE_TRY(hipMemset(c->d_sink, 0, 64 * 1024));
         if (c->fp.enabled) {
             // the filter-input buffer starts as ntaps-1 zeros of history
             const size_t h = c->fp.taps.size() - 1;
@@ -575,10 +586,23 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         const bool fast_s1 = c->resample && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
         if (fast_s1) {
             a.w_total_tiles = (span_samples + kWTile - 1) / kWTile;
-            a.w_tiles_per_wave = c->tiles_per_block * kTile / (16 * kWTile);
-            if (a.w_tiles_per_wave < 1) a.w_tiles_per_wave = 1;
-            a.w_warm_tiles = (int)((c->rp.history_in + kWTile - 1) / kWTile);
+            // per-wave run length: with block_samples = 0 every resident wave (12 per CU, one
+            // workgroup per CU) gets ONE run, so the launch is a single balanced round with one
+            // warm-up tile per wave; an explicit block_samples gives runs of block_samples / 16
+            int64_t tpw64;
+            if (c->auto_block) {
+                const int64_t slots = (int64_t)c->n_cu * kWaves;
+                tpw64 = (a.w_total_tiles + slots - 1) / slots;
+                if (tpw64 < 16) tpw64 = 16;
+            } else {
+                tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
+            }
+            if (tpw64 < 1) tpw64 = 1;
+            if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
+            const int tpw = (int)tpw64;
+            plan_front_s1(a, tpw, (int)((c->rp.history_in + kWTile - 1) / kWTile), 4);
             for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
+            a.sink = c->d_sink;
         }
         KernelTimer kt(c, IQGPU_K_FRONT);
         if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
@@ -693,6 +717,16 @@ extern "C" int iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p)
     drain_events(c);
     *p = c->prof;
     memset(&c->prof, 0, sizeof(c->prof));
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_debug_read_scratch(iqgpu_chain *c, void *host_64k)
+{
+    if (!c || !host_64k) return fail(IQGPU_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host_64k, c->d_sink, 64 * 1024, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->d_sink, 0, 64 * 1024));
     return IQGPU_OK;
 }
 

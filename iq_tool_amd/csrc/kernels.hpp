@@ -70,7 +70,12 @@ struct FrontArgs {
     int64_t     w_total_tiles;
     int32_t     w_tiles_per_wave;
     int32_t     w_warm_tiles;
+    int32_t     w_edge_tpw;     // tiles per wave for edge runs
+    int64_t     w_fast_g0, w_fast_g1;   // streaming sub-blocks [g0, g1): tiles [g tpw, (g+1) tpw)
+    int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
+    int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
+    void       *sink;         // 64 KiB scratch that absorbs the stores of lanes without an output
     // post-resample NCO
     int32_t     pnco_mode;
     uint32_t    pnco_theta0, pnco_dtheta;
@@ -84,6 +89,8 @@ hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
+// fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set)
+void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tiles_per_wave);
 
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
