@@ -57,62 +57,6 @@ __device__ __forceinline__ void load_chunk(const char *p, RawChunk &r)
     }
 }
 
-// ---- prefetch registers of the streaming variant.  The loads are issued from inline asm so that
-// hipcc's waitcnt pass does not track them: it would wait for them with vmcnt(0), which also drains
-// the output stores issued after them.  The kernel waits by hand with the exact count instead:
-// every loop iteration issues exactly 4 VMEM instructions (stores) after its loads.
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-template <int BPS> struct Prefetch;
-template <> struct Prefetch<4> {
-    v4u c0, c1;
-    __device__ __forceinline__ void issue(const char *base, unsigned voff)
-    {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
-    }
-    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory"); }
-    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c1) :: "memory"); }
-    __device__ __forceinline__ void get(int c, RawChunk &r) const
-    {
-        const v4u v = c ? c1 : c0;
-        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
-    }
-};
-template <> struct Prefetch<2> {
-    v2u c0, c1;
-    __device__ __forceinline__ void issue(const char *base, unsigned voff)
-    {
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
-    }
-    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory"); }
-    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c1) :: "memory"); }
-    __device__ __forceinline__ void get(int c, RawChunk &r) const
-    {
-        const v2u v = c ? c1 : c0;
-        r.w[0] = v.x; r.w[1] = v.y;
-    }
-};
-template <> struct Prefetch<8> {
-    v4u c0, c0b, c1, c1b;
-    __device__ __forceinline__ void issue(const char *base, unsigned voff)
-    {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c0) : "v"(voff), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(c0b) : "v"(voff), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(c1) : "v"(voff), "s"(base) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2064" : "=v"(c1b) : "v"(voff), "s"(base) : "memory");
-    }
-    __device__ __forceinline__ void wait_first() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c0b), "+v"(c1), "+v"(c1b) :: "memory"); }
-    __device__ __forceinline__ void wait_steady() { asm volatile("s_waitcnt vmcnt(4)" : "+v"(c0), "+v"(c0b), "+v"(c1), "+v"(c1b) :: "memory"); }
-    __device__ __forceinline__ void get(int c, RawChunk &r) const
-    {
-        const v4u v = c ? c1 : c0, u = c ? c1b : c0b;
-        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
-        r.w[4] = u.x; r.w[5] = u.y; r.w[6] = u.z; r.w[7] = u.w;
-    }
-};
-
 // four frames from prefetched words; arithmetic identical to unpack_one (src/sample_convert.c:75-96).
 // unit_gain skips the multiply by 1.0f (exact).
 template <int BPS>
@@ -254,7 +198,52 @@ __device__ __forceinline__ int out_bytes(int fmt)
 #define STAMP_FLUSH(sinkbase) do { } while (0)
 #endif
 
-struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; char *sink; };
+struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };
+
+// For the lane's four half-band samples 4*lane .. 4*lane+3 of a tile whose first output has phase
+// delta0: which of them carry an output (hit), and the gather of that output's 14 taps (7 x
+// ds_read_b64 from the arm's 56-byte row; asm, so that they are not fused into half-rate
+// ds_read2_b64).  Returns with every tap landed.
+__device__ __forceinline__ void issue_taps(const WaveLds &w, int lane, uint32_t delta0, uint32_t step, float inv_step,
+                                           uint32_t &n0, bool hit[4], v2f tp[4][7])
+{
+    const uint32_t tgt = (uint32_t)(4 * lane) << 24;
+    n0 = 0;
+    if (tgt > delta0) n0 = ceil_div_small(tgt - delta0, step, inv_step);
+    uint32_t Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);   // phase relative to 4*lane
+    unsigned row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        hit[r] = (Pl >> 24) == (uint32_t)r;
+        const unsigned arm = (Pl >> 16) & 255u;
+        row[r] = w.arb_lds + (arm ^ (arm >> 5)) * 56u;
+        if (hit[r]) Pl += step;
+    }
+    // Two asm blocks with nothing between them; the second ends with the wait, so no instruction of
+    // the compiler's can touch a tap register while its read is in flight (tools/check_isa.py).
+    asm volatile(
+        "ds_read_b64 %0, %14\n\tds_read_b64 %1, %14 offset:8\n\tds_read_b64 %2, %14 offset:16\n\t"
+        "ds_read_b64 %3, %14 offset:24\n\tds_read_b64 %4, %14 offset:32\n\tds_read_b64 %5, %14 offset:40\n\t"
+        "ds_read_b64 %6, %14 offset:48\n\t"
+        "ds_read_b64 %7, %15\n\tds_read_b64 %8, %15 offset:8\n\tds_read_b64 %9, %15 offset:16\n\t"
+        "ds_read_b64 %10, %15 offset:24\n\tds_read_b64 %11, %15 offset:32\n\tds_read_b64 %12, %15 offset:40\n\t"
+        "ds_read_b64 %13, %15 offset:48"
+        : "=&v"(tp[0][0]), "=&v"(tp[0][1]), "=&v"(tp[0][2]), "=&v"(tp[0][3]), "=&v"(tp[0][4]), "=&v"(tp[0][5]), "=&v"(tp[0][6]),
+          "=&v"(tp[1][0]), "=&v"(tp[1][1]), "=&v"(tp[1][2]), "=&v"(tp[1][3]), "=&v"(tp[1][4]), "=&v"(tp[1][5]), "=&v"(tp[1][6])
+        : "v"(row[0]), "v"(row[1]));
+    asm volatile(
+        "ds_read_b64 %0, %14\n\tds_read_b64 %1, %14 offset:8\n\tds_read_b64 %2, %14 offset:16\n\t"
+        "ds_read_b64 %3, %14 offset:24\n\tds_read_b64 %4, %14 offset:32\n\tds_read_b64 %5, %14 offset:40\n\t"
+        "ds_read_b64 %6, %14 offset:48\n\t"
+        "ds_read_b64 %7, %15\n\tds_read_b64 %8, %15 offset:8\n\tds_read_b64 %9, %15 offset:16\n\t"
+        "ds_read_b64 %10, %15 offset:24\n\tds_read_b64 %11, %15 offset:32\n\tds_read_b64 %12, %15 offset:40\n\t"
+        "ds_read_b64 %13, %15 offset:48\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(tp[2][0]), "=&v"(tp[2][1]), "=&v"(tp[2][2]), "=&v"(tp[2][3]), "=&v"(tp[2][4]), "=&v"(tp[2][5]), "=&v"(tp[2][6]),
+          "=&v"(tp[3][0]), "=&v"(tp[3][1]), "=&v"(tp[3][2]), "=&v"(tp[3][3]), "=&v"(tp[3][4]), "=&v"(tp[3][5]), "=&v"(tp[3][6])
+        : "v"(row[2]), "v"(row[3])
+        : "memory");
+}
 
 // Tiles [t_begin, t_emit1) of kWTile frames; those from t_emit0 on produce output.
 // EDGE = false: every tile (and the one after the last, for the prefetch) lies inside the call's
@@ -276,9 +265,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     const bool unit_gain = a.gain == 1.0f;
     const int woff = (5 + (lane >> 1)) * kRowB + (lane & 1) * 16;       // this lane's LDS write slot
 
-    Prefetch<VB> pf;
-    const unsigned voff = (unsigned)(4 * VB * lane);
-    if (!EDGE) pf.issue((const char *)a.raw + (t_begin * kWTile - a.rem0) * VB, voff);
+    // register prefetch of the next tile's frames (compiler-managed loads: hipcc waits for them with
+    // vmcnt(0) at the top of the next iteration, a whole tile after they were issued)
+    RawChunk nxt[2];
+    if (!EDGE) {
+        const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * VB + 4 * VB * lane;
+        load_chunk<VB>(src, nxt[0]);
+        load_chunk<VB>(src + 256 * VB, nxt[1]);
+    }
 
     STAMP_DECL
     STAMP_BEGIN;
@@ -292,17 +286,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         if (!EDGE) {
             // consume the prefetched frames first: the wait for them lands here, before the next
             // tile's loads are issued, so those stay in flight across the whole tile
-            if (t == t_begin) pf.wait_first(); else pf.wait_steady();
+            unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
+            unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             STAMP(0);
             {
-                RawChunk r0, r1;
-                pf.get(0, r0); pf.get(1, r1);
-                unpack_chunk<VB>(r0, a.in_fmt, a.gain, unit_gain, x[0]);
-                unpack_chunk<VB>(r1, a.in_fmt, a.gain, unit_gain, x[1]);
+                const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
+                load_chunk<VB>(src, nxt[0]);
+                load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
-            // x[][] must be complete before the registers are handed back to the memory pipe
-            asm volatile("" : "+v"(x[0][0].x), "+v"(x[0][3].y), "+v"(x[1][0].x), "+v"(x[1][3].y));
-            pf.issue((const char *)a.raw + (j0 + kWTile) * VB, voff);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (a.iq_enable) {
@@ -352,9 +343,6 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 }
             }
         }
-#if defined(IQGPU_ABL) && IQGPU_ABL >= 6
-        if (EDGE || x[0][0].x == 12345.678f)
-#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int off = woff + 32 * c * kRowB;
@@ -365,9 +353,6 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         STAMP(1);
 
         // ------------------------------------------------------------ half-band: 4 outputs per lane
-#if defined(IQGPU_ABL) && IQGPU_ABL >= 5
-        if (EDGE)
-#endif
         {
             const char *we = XE + lane * kRowB;
             v2f E[24];
@@ -397,15 +382,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         __builtin_amdgcn_wave_barrier();
 
         // ------------------------------------------------------------ polyphase + pack
-        // The streaming variant runs this stage on warm-up tiles too (with every hit masked off) and
-        // always executes its 4 store instructions -- lanes without an output write to a small
-        // L2-resident sink -- so that the loop body is branch-free and hipcc can wait for the
-        // prefetched frames with vmcnt(4) instead of draining the stores with vmcnt(0).
-#if defined(IQGPU_ABL) && IQGPU_ABL >= 4
-        if (EDGE && emit) {
-#else
-        if (!EDGE || emit) {
-#endif
+        if (emit) {
             const int64_t q_tile0 = t * 256;
             if (!EDGE || q_tile0 < a.n_groups) {
                 const char *wh = HB + lane * kRowB;
@@ -420,31 +397,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     H[4 * r - 2] = v2f{v0.x, v0.y}; H[4 * r - 1] = v2f{v0.z, v0.w};
                     H[4 * r + 0] = v2f{v1.x, v1.y}; H[4 * r + 1] = v2f{v1.z, v1.w};
                 }
-                // first output at or after this lane's first half-band sample (4 * lane)
-                const uint32_t tgt = (uint32_t)(4 * lane) << 24;
+                // (gathered right before use: values written by asm loads must not sit in registers
+                // that the register allocator may copy before the wait below)
                 uint32_t n0 = 0;
-                if (tgt > delta0) n0 = ceil_div_small(tgt - delta0, step, inv_step);
-                uint32_t Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);   // phase relative to 4*lane
-                // the (at most one) output on each of the 4 samples: slot hit, arm, taps
                 bool hit[4];
                 v2f tp[4][7];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hit[r] = (Pl >> 24) == (uint32_t)r;
-                    // 7 x ds_read_b64 of the arm's 14 taps (56-byte rows; issued from asm so that they
-                    // are not fused into half-rate ds_read2_b64)
-                    const unsigned arm = (Pl >> 16) & 255u;
-                    const unsigned row = w.arb_lds + (arm ^ (arm >> 5)) * 56u;
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(tp[r][0]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(tp[r][1]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(tp[r][2]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(tp[r][3]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(tp[r][4]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:40" : "=v"(tp[r][5]) : "v"(row));
-                    asm volatile("ds_read_b64 %0, %1 offset:48" : "=v"(tp[r][6]) : "v"(row));
-                    if (hit[r]) Pl += step;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_taps(w, lane, delta0, step, inv_step, n0, hit, tp);
                 STAMP(3);
                 v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
@@ -461,33 +419,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 char *obase = (char *)a.out + (int64_t)k_tile0 * obps;
                 const uint32_t pth0 = a.pnco_theta0 + (uint32_t)k_tile0 * a.pnco_dtheta;
                 uint32_t kk = n0;
-                if (EDGE) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (hit[r] && (uint32_t)(4 * lane + r) < q_lim) {
-                            v2f yy = y[r];
-                            if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
-                            pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
-                        }
-                        kk += hit[r] ? 1u : 0u;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; ++r) {
+                    if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
                         if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
-                        const bool real = hit[r] && emit;
-#if defined(IQGPU_ABL) && IQGPU_ABL == 1      // ablation: no stores at all
-                        asm volatile("" :: "v"(yy), "v"(real));
-#elif defined(IQGPU_ABL) && IQGPU_ABL == 2    // ablation: every lane stores to the sink
-                        pack_store_at(w.sink, (uint32_t)lane, a.out_fmt, cf2{yy.x, yy.y});
-#elif defined(IQGPU_ABL) && IQGPU_ABL == 3    // ablation: dense store (wrong data placement, same bytes)
-                        pack_store_at(obase, (uint32_t)(lane + 64 * r), a.out_fmt, cf2{yy.x, yy.y});
-#else
-                        pack_store_at(real ? obase : w.sink, real ? kk : (uint32_t)lane, a.out_fmt, cf2{yy.x, yy.y});
-#endif
-                        kk += hit[r] ? 1u : 0u;
+                        pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
                     }
+                    kk += hit[r] ? 1u : 0u;
                 }
             }
             // outputs of this tile, ceil((2^32 - delta0) / step) = floor((2^32 - 1 - delta0) / step) + 1
@@ -496,10 +435,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             nfl -= ((uint64_t)nfl * step > (uint64_t)xm) ? 1u : 0u;
             nfl += ((uint64_t)(nfl + 1) * step <= (uint64_t)xm) ? 1u : 0u;
             const uint32_t nt = nfl + 1u;
-            if (emit) {
-                k_tile0 += nt;
-                delta0 = (uint32_t)((uint64_t)delta0 + (uint64_t)nt * step - ((uint64_t)1 << 32));
-            }
+            k_tile0 += nt;
+            delta0 = (uint32_t)((uint64_t)delta0 + (uint64_t)nt * step - ((uint64_t)1 << 32));
         }
 
         STAMP(5);
@@ -533,7 +470,6 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
     w.HB = w.XO + kXRows * kRowB;
     w.nco = s_nco; w.arb = s_arb;
     w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;   // LDS byte address
-    w.sink = (char *)a.sink + (((unsigned)blockIdx.x * kWaves + (unsigned)wave) & 31u) * 1024u;   // lower 32 KiB (upper half: diagnostics)
 
     if (a.nco_mode != 0 || a.pnco_mode != 0) {
         const float sgn = (a.nco_mode < 0 || a.pnco_mode < 0) ? -1.0f : 1.0f;   // mix down: conj(phasor)

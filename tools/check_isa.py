@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Static check of the hand-written asm in k_front_s1 (iq_tool_amd/csrc/front_wave.hip).
+
+The polyphase tap gather issues its 28 ds_read_b64 from two adjacent inline-asm blocks and waits for
+them with an `s_waitcnt lgkmcnt(0)` at the end of the second block.  hipcc does not know that the
+destination registers of asm loads are still in flight, so no instruction of its own may sit
+between the two blocks (it could read or copy a tap register before the data has landed).  This
+script compiles front_wave.hip to gfx950 ISA and verifies for every instantiation that
+  (1) each gather consists of two asm blocks with no instruction between them,
+  (2) the second block ends with s_waitcnt lgkmcnt(0),
+  (3) no asm global_load / buffer_load is left in the file (loads are compiler-managed).
+Exit code 0 = ok.  Run by __graft_entry__.build() and tests/test_host_logic.py."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_wave.hip")
+
+
+def compile_isa():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "fw.s")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+               "--cuda-device-only", "-S", SRC, "-o", out]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return open(out).read().split("\n")
+
+
+def asm_blocks(lines):
+    """[(start, end, [instructions])] for every ;;#ASMSTART .. ;;#ASMEND region"""
+    out, i = [], 0
+    while i < len(lines):
+        if lines[i].strip().startswith(";;#ASMSTART"):
+            j = i + 1
+            body = []
+            while not lines[j].strip().startswith(";;#ASMEND"):
+                if lines[j].strip():
+                    body.append(lines[j].strip())
+                j += 1
+            out.append((i, j, body))
+            i = j
+        i += 1
+    return out
+
+
+def check(lines):
+    errors = []
+    funcs, cur = {}, None
+    for idx, l in enumerate(lines):
+        m = re.match(r"(_ZN5iqgpu10k_front_s1ILi(\d)EEEvNS_9FrontArgsE):", l)
+        if m:
+            cur = m.group(2)
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(l)
+            if "s_endpgm" in l:
+                cur = None
+    if not funcs:
+        errors.append("no k_front_s1 instantiation found")
+    n_gathers = 0
+    for bps, fl in sorted(funcs.items()):
+        blocks = asm_blocks(fl)
+        for (_, _, body) in blocks:
+            for ins in body:
+                if re.match(r"(global|buffer|flat)_load", ins):
+                    errors.append("k_front_s1<%s>: asm VMEM load found: %s" % (bps, ins))
+        gather = [b for b in blocks if b[2] and all(x.startswith("ds_read_b64") or x.startswith("s_waitcnt") for x in b[2])
+                  and any(x.startswith("ds_read_b64") for x in b[2])]
+        if len(gather) % 2 != 0:
+            errors.append("k_front_s1<%s>: odd number of tap-gather asm blocks (%d)" % (bps, len(gather)))
+            continue
+        for a, b in zip(gather[0::2], gather[1::2]):
+            n_gathers += 1
+            between = [x.strip() for x in fl[a[1] + 1:b[0]] if x.strip() and not x.strip().startswith(";")]
+            if between:
+                errors.append("k_front_s1<%s>: instructions between the two gather blocks: %s" % (bps, between[:3]))
+            if sum(1 for x in a[2] if x.startswith("ds_read_b64")) != 14 or sum(1 for x in b[2] if x.startswith("ds_read_b64")) != 14:
+                errors.append("k_front_s1<%s>: gather blocks do not hold 14 + 14 reads" % bps)
+            if not b[2][-1].startswith("s_waitcnt lgkmcnt(0)"):
+                errors.append("k_front_s1<%s>: second gather block does not end with s_waitcnt lgkmcnt(0)" % bps)
+            if any(x.startswith("s_waitcnt") for x in a[2]):
+                errors.append("k_front_s1<%s>: unexpected wait inside the first gather block" % bps)
+    return errors, n_gathers
+
+
+def main():
+    errors, n = check(compile_isa())
+    for e in errors:
+        print("FAIL", e)
+    print("check_isa: %d tap gathers checked: %s" % (n, "ok" if not errors and n > 0 else "FAILED"))
+    return 0 if (not errors and n > 0) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
