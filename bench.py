@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--log2-frames", type=int, default=28, help="frames per step and GPU (default 2^28 = 1 GiB of cs16)")
     ap.add_argument("--cpu-frames-log2", type=int, default=28, help="bounded CPU-baseline sample (2^28 = one step's batch, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), reported as roofline.traffic")
+    ap.add_argument("--traffic-bytes", type=float, default=1421606298.0,
+                    help="HBM bytes per k_front launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes); reported as roofline.traffic when the workload is the default 2^28 frames")
     return ap.parse_args()
 
 
@@ -166,7 +166,7 @@ def main():
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES,
                        "sharding": "independent stream per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic_bytes,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic_bytes if args.log2_frames == 28 else None,
                          "kernel": "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * 4 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
