@@ -2,7 +2,7 @@
 //
 // This is the product's own statement of the design rules the reference gets from liquid-dsp
 // and from src/filter.c; the SPEC it follows is DESIGN.md section "SPEC".  It shares no code
-// with oracle/ (the oracle is an independent C restatement used only by tests).
+// with the parity oracle (an independent C restatement that only the tests use).
 #pragma once
 
 #include <cstdint>

@@ -123,7 +123,15 @@ extern "C" int iqgpu_device_count(void)
     return n;
 }
 
-extern "C" size_t iqgpu_get_bytes_per_sample(int format) { return bytes_per_frame(format); }
+extern "C" size_t iqgpu_get_bytes_per_sample(int format)
+{
+    switch (format) { // the reference also sizes its real scalar formats (include/common_types.h:33-37)
+    case 1: case 2: return 1;           // U8, S8
+    case 3: case 4: return 2;           // U16, S16
+    case 5: case 6: case 7: return 4;   // U32, S32, F32
+    default: return bytes_per_frame(format);
+    }
+}
 
 extern "C" void iqgpu_chain_desc_init(iqgpu_chain_desc *d)
 {

@@ -29,9 +29,12 @@ typedef ORC_ACC acc_t;
  * sample_convert                                    ref: src/sample_convert.c:102-309
  * ---------------------------------------------------------------------------------------- */
 
-size_t orc_bytes_per_sample(int fmt) /* ref: sample_convert.c:102-122 (complex formats) */
+size_t orc_bytes_per_sample(int fmt) /* ref: sample_convert.c:102-122 */
 {
     switch (fmt) {
+    case 1: case 2: return 1;            /* U8, S8   (real scalar formats: sized, never converted) */
+    case 3: case 4: return 2;            /* U16, S16 */
+    case 5: case 6: case 7: return 4;    /* U32, S32, F32 */
     case ORC_FMT_CS8: case ORC_FMT_CU8: return 2;
     case ORC_FMT_CS16: case ORC_FMT_CU16: case ORC_FMT_SC16Q11: return 4;
     case ORC_FMT_CS24: return 6;
@@ -871,7 +874,8 @@ orc_chain *orc_chain_create(const orc_chain_desc *d, int *err)
     c->d = *d;
     c->ratio = (float)(target / d->input_rate_hz); /* ref: setup.c:107 */
     if (!isfinite(c->ratio) || c->ratio < 0.001f || c->ratio > 1000.0f) { *err = -10; free(c); return NULL; }
-    if (!orc_bytes_per_sample(d->in_format) || !orc_bytes_per_sample(d->out_format)) { *err = -11; free(c); return NULL; }
+    if (d->in_format < ORC_FMT_CU8 || d->out_format < ORC_FMT_CU8 ||
+        !orc_bytes_per_sample(d->in_format) || !orc_bytes_per_sample(d->out_format)) { *err = -11; free(c); return NULL; }
     if (d->dc_block_enable) { /* ref: dc_block.c:32 */
         float alpha = (float)(2.0 * M_PI * 10.0f / d->input_rate_hz);
         c->dc = orc_dcblock_create(alpha, d->dc_f32_literal);

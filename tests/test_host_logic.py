@@ -1,0 +1,230 @@
+"""CPU tests of the host side: the C ABI library loads and exports everything include/iqgpu.h
+declares, struct layouts match the ctypes mirror, the create-time design path equals the oracle's,
+errors carry the reference's codes, the product never touches oracle/, the hand-written asm passes
+its static check, and the N > 1 shard/timing logic of bench.py works over gloo (world_size 2).
+No compute entry point is called here (there is no GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "iqgpu.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import iq_tool_amd
+    return iq_tool_amd.load()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(iqgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from iq_tool_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 38
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (iqgpu_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert set(names) == bound, (set(names) ^ bound)
+    assert lib.iqgpu_abi_version() == 1
+
+
+def test_struct_layouts_match_ctypes(tmp_path):
+    from iq_tool_amd import _lib
+    prog = textwrap.dedent("""
+        #include <stdio.h>
+        #include <stddef.h>
+        #include "iqgpu.h"
+        int main(void) {
+            printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(iqgpu_chain_desc), offsetof(iqgpu_chain_desc, shift_hz),
+                   offsetof(iqgpu_chain_desc, filters), offsetof(iqgpu_chain_desc, block_samples),
+                   sizeof(iqgpu_chain_info), offsetof(iqgpu_chain_info, arb_step), sizeof(iqgpu_profile));
+            return 0;
+        }""")
+    src = tmp_path / "layout.c"
+    src.write_text(prog)
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    D, I, P = _lib.ChainDesc, _lib.ChainInfo, _lib.Profile
+    want = [C.sizeof(D), D.shift_hz.offset, D.filters.offset, D.block_samples.offset, C.sizeof(I), I.arb_step.offset, C.sizeof(P)]
+    assert got == want
+
+
+def probe(lib, **kw):
+    from iq_tool_amd import _lib
+    from iq_tool_amd.chain import make_desc
+    d = make_desc(**kw)
+    info = _lib.ChainInfo()
+    ft = np.zeros(2 * 20000, np.float32)
+    hb = np.zeros(4096, np.float32)
+    arb = np.zeros(3584, np.float32)
+    rc = lib.iqgpu_design_probe(C.byref(d), C.byref(info), ft.ctypes.data_as(C.c_void_p), 20000,
+                                hb.ctypes.data_as(C.c_void_p), 4096, arb.ctypes.data_as(C.c_void_p), 3584)
+    return rc, info, ft.view(np.complex64), hb, arb
+
+
+@pytest.mark.parametrize("rates", [(2.4e6, 744187.5), (10e6, 2.4e6), (61.44e6, 1488375.0), (2.4e6, 2.0e6), (2.4e6, 2.4e6), (8e6, 8e3)])
+def test_resampler_design_equals_oracle(lib, oracle, rates):
+    rc, info, _, hb, arb = probe(lib, input_rate_hz=rates[0], target_rate_hz=rates[1], shift_hz=200e3)
+    assert rc == 0
+    r = np.float32(rates[1] / rates[0])
+    m = oracle.MsResamp(r)
+    assert info.ratio == r and info.interp == 0
+    assert info.num_halfband_stages == m.S and info.arb_step == m.step and info.rate_arb == m.rate_arb
+    assert [info.stage_m[k] for k in range(m.S)] == [m.stage_m(k) for k in range(m.S)]
+    o = 0
+    for k in range(m.S):
+        t = m.stage_taps(k)
+        assert np.array_equal(hb[o:o + t.size], t)
+        o += t.size
+    assert np.array_equal(arb, m.arb_proto())
+    nco = oracle.Nco(np.float32(2 * np.pi * 200e3 / rates[0]))
+    assert info.nco_dtheta == nco.dtheta_u32
+
+
+def test_filter_design_equals_oracle(lib, oracle):
+    cases = [
+        (dict(input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
+         oracle.make_filter_cfg((("passband", 158.5e3, 113e3),), filter_taps=1025), 10e6, 2.4e6, False),
+        (dict(input_rate_hz=61.44e6, target_rate_hz=1488375.0, filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
+         oracle.make_filter_cfg((("lowpass", 300e3, 0.0),), filter_taps=4097, impl="fir"), 61.44e6, 1488375.0, False),
+        (dict(input_rate_hz=2.4e6, no_resample=True, filters=(("highpass", 100e3, 0.0), ("stopband", 400e3, 50e3), ("lowpass", 900e3, 0.0))),
+         oracle.make_filter_cfg((("highpass", 100e3, 0.0), ("stopband", 400e3, 50e3), ("lowpass", 900e3, 0.0))), 2.4e6, 2.4e6, True),
+        (dict(input_rate_hz=2.4e6, no_resample=True, filters=(("passband", -300e3, 100e3),), transition_width_hz=20e3, attenuation_db=70.0, filter_impl="fft", fft_size=2048),
+         oracle.make_filter_cfg((("passband", -300e3, 100e3),), transition_width_hz=20e3, attenuation_db=70.0, impl="fft", fft_size=2048), 2.4e6, 2.4e6, True),
+    ]
+    for kw, cfg, fin, fout, nores in cases:
+        rc, info, ft, _, _ = probe(lib, **kw)
+        assert rc == 0, lib.iqgpu_last_error()
+        f = oracle.Filter(cfg, fin, fout, no_resample=nores)
+        assert (bool(info.filter_post_resample), info.filter_impl, info.filter_ntaps, info.filter_block) == (f.post, f.impl, f.ntaps, f.block)
+        assert np.array_equal(ft[:f.ntaps].view(np.float32), f.taps().view(np.float32))
+
+
+def test_dc_alpha_and_history(lib):
+    rc, info, *_ = probe(lib, input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True)
+    assert rc == 0
+    assert info.dc_alpha == np.float32(2.0 * np.pi * 10.0 / 10e6)
+    assert info.history_samples >= 2 * (2 * 13 + 40) + 20          # two stages: 2*(2*13+4*10)+4*5
+
+
+def test_error_codes_follow_the_reference_fatal_paths(lib):
+    def code(**kw):
+        rc, *_ = probe(lib, **kw)
+        return rc, lib.iqgpu_last_error().decode()
+    assert code(input_rate_hz=2.4e6, target_rate_hz=100.0)[0] == -4            # ratio < 1e-3  (src/setup.c:109)
+    assert code(input_rate_hz=2.4e6, target_rate_hz=2.4e9 * 2)[0] == -4
+    assert code(in_format=3)[0] == -5                                          # real scalar format: unhandled
+    assert code(out_format=0)[0] == -5
+    rc, msg = code(shift_hz=0.0, shift_after_resample=True)
+    assert rc == -6 and "shift-after-resample" in msg
+    assert code(shift_hz=2.4e6 * 5.1)[0] == -6                                 # SHIFT_FACTOR_LIMIT
+    rc, msg = code(filters=(("lowpass", 600e3, 0.0),))
+    assert rc == -7 and "Nyquist" in msg
+    assert code(no_resample=True, filters=(("passband", 50e3, 20e3),), filter_taps=1025, fft_size=1024)[0] == -7
+    assert code(input_rate_hz=2.4e6, target_rate_hz=4.8e6)[0] == -10           # interpolation: not built yet
+    assert code(input_rate_hz=2.4e6, target_rate_hz=2.4e6, filters=(("lowpass", 100e3, 0.0),))[0] == -10
+    assert code(block_samples=1000)[0] == -1
+
+
+def test_create_without_device_fails_loudly(lib):
+    import iq_tool_amd
+    if lib.iqgpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(iq_tool_amd.IqgpuError) as e:
+        iq_tool_amd.Chain(shift_hz=200e3)
+    assert e.value.code == -2
+    from iq_tool_amd import ops
+    with pytest.raises(iq_tool_amd.IqgpuError):
+        ops.convert_block_to_cf32(np.zeros(8, np.int16), "cs16")
+    assert ops.get_bytes_per_sample("cs16") == 4        # pure table, no device needed
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    env = dict(os.environ, IQGPU_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", "import iq_tool_amd; iq_tool_amd.load()"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "iq_tool_amd")
+    bad = []
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".c")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"pyoracle|iq_oracle|liboracle|from oracle|import oracle|oracle/", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    hdr = open(HEADER).read()
+    assert "oracle" not in hdr
+
+
+def test_hand_written_asm_static_check():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_next_out_frames_closed_form_matches_oracle_counts(oracle):
+    """the count law the host uses: K(Q) = ceil(Q 2^24 / step), Q = floor(N / 2^S)"""
+    r = np.float32(744187.5 / 2.4e6)
+    m = oracle.MsResamp(r)
+    rng = np.random.default_rng(3)
+    x = np.zeros(1, np.complex64)
+    tot_in = tot_out = 0
+    for n in rng.integers(0, 5000, 40):
+        got = m.execute(np.zeros(int(n), np.complex64)).size
+        tot_in += int(n)
+        tot_out += got
+        q = tot_in >> m.S
+        assert tot_out == -(-(q << 24) // m.step)
+
+
+# --------------------------------------------------------------------------------------------
+# N > 1: independent shards, barrier + max-over-ranks timing (gloo, world_size 2)
+# --------------------------------------------------------------------------------------------
+WORKER = """
+import os, sys, time
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import bench
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+plan = bench.shard_plan(world, rank, 1 << 20)
+assert plan["first_frame"] == rank << 20 and plan["frames"] == 1 << 20 and plan["seed"] == 10 + rank
+calls = []
+def step():
+    calls.append(1)
+    time.sleep(0.05 if rank == 0 else 0.15)      # rank 1 is the slow shard
+dt = bench.timed_region(dist, lambda: None, step, 3)
+assert len(calls) == 3
+assert 0.44 <= dt < 2.0, dt                       # the MAX over ranks: 3 x 0.15 s on both ranks
+print("rank", rank, "ok", round(dt, 3))
+dist.destroy_process_group()
+"""
+
+
+def test_sharding_and_max_reduce_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok" in o for o in outs)
