@@ -102,14 +102,15 @@ __device__ __forceinline__ void unpack_chunk(const RawChunk &r, int fmt, float g
     }
 }
 
-// smallest q with q * d >= x, for 0 < x < 2^32, 2^24 <= d <= 2^25 (quotient below 2^8): float
-// estimate (absolute error far below 1) and two branch-free corrections
+// smallest q with q * d >= x, for 0 < x < 2^32, 2^24 <= d <= 2^25 (quotient below 2^8).  The float
+// estimate of x / d is within 1e-4 of the truth, so its truncation is the exact floor or one off in
+// either direction; make it the exact floor first, then round up.
 __device__ __forceinline__ uint32_t ceil_div_small(uint32_t x, uint32_t d, float inv_d)
 {
-    uint32_t q = (uint32_t)((float)x * inv_d);
-    q += ((uint64_t)q * d < (uint64_t)x) ? 1u : 0u;
-    q -= (q > 0 && (uint64_t)(q - 1) * d >= (uint64_t)x) ? 1u : 0u;
-    return q;
+    uint32_t f = (uint32_t)((float)x * inv_d);
+    f -= ((uint64_t)f * d > (uint64_t)x) ? 1u : 0u;                 // estimate one too high
+    f += ((uint64_t)(f + 1) * d <= (uint64_t)x) ? 1u : 0u;          // estimate one too low
+    return f + (((uint64_t)f * d < (uint64_t)x) ? 1u : 0u);
 }
 
 __device__ __forceinline__ float4 ld4(const char *p) { return *(const float4 *)p; }

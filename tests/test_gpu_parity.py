@@ -398,9 +398,8 @@ def test_golden_nrsc5_fixture(gpu):
 # --------------------------------------------------------------------------------------------
 def test_full_size_count_law_split_invariance_and_spot_parity(gpu, oracle):
     """configs[1] at its real size, device-resident: (1) frames_out obeys the closed form,
-    (2) one call == two calls of ragged sizes (checksum of the output bytes), (3) windows of the
-    output equal the oracle run on the matching input window, (4) the output is a pure function
-    of the input: a second chain gives identical bytes."""
+    (2) one call == two calls of ragged sizes (checksum of the output bytes), (3) the first 2^25 frames'
+    worth of output equals the oracle's."""
     import hashlib
     from iq_tool_amd.chain import DeviceBuffer
     frames = 1 << 28
@@ -428,20 +427,8 @@ def test_full_size_count_law_split_invariance_and_spot_parity(gpu, oracle):
     out2 = d_out.download(n1 * 4)
     assert hashlib.sha256(out2.tobytes()).hexdigest() == h1
 
-    # spot parity: the stream start, and a window deep inside (input period 2^22, warm-up 4096 frames)
-    o = oracle.Chain(**NRSC5)
-    want0 = o.process(seg[:2 * 200000])
-    int_close(out1.view(np.int16)[:want0.size], want0)
-    start = 37 * (1 << 22) + 1000                                    # even: group aligned
-    win = np.concatenate([seg, seg])[2 * 1000:2 * (1000 + 300000)]
-    wo = oracle.Chain(**NRSC5).process(win)
-    k0 = -(-((start >> 1) << 24) // step)                           # first output of the window in the full stream
-    got = out1.view(np.int16)[2 * k0:2 * k0 + wo.size]
-    # the oracle window starts from reset state: skip its warm-up (40 outputs), and align phases:
-    # the full stream's output k0 + j and the window's output j' coincide only if the polyphase phase
-    # matches, which it does not in general -- so compare the DC-free statistics instead
-    assert got.size == wo.size
-    pw = np.mean(got.astype(np.float64) ** 2)
-    po = np.mean(wo[80:].astype(np.float64) ** 2)
-    assert abs(pw / po - 1.0) < 0.02
+    # parity with the oracle over the first 2^25 frames of the very same stream (10.4 M outputs,
+    # 16 k tiles deep into the per-wave runs of the full-size launch)
+    want = oracle.Chain(**NRSC5).process(np.tile(seg, 8))
+    int_close(out1.view(np.int16)[:want.size], want)
     d_in.free(); d_out.free()
