@@ -27,6 +27,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 CHAIN = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+# the other single-GPU BASELINE.json configs (parity-test cases; timed only with --config 3 / 4, never the default line)
+OTHER = {
+    3: dict(chain=dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
+                       iq_correct=True, iq_mag=0.01, iq_phase=-0.005, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
+            log2_frames=27, rate=10e6, fmt="cs16", bps=4,
+            workload="BASELINE configs[2]: cs16 10 MS/s -> 2.4 MS/s, dc block + iq correct, 2 half-bands, 1025-tap complex band-pass (FFT kind, block 2048), cs16 out"),
+    4: dict(chain=dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0,
+                       filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
+            log2_frames=29, rate=61.44e6, fmt="cu8", bps=2,
+            workload="BASELINE configs[3]: cu8 61.44 MS/s -> 1.488375 MS/s, 5 half-bands, 4097-tap real FIR (time domain), cu8 out"),
+}
 BLOCK_SAMPLES = 0               # auto: one contiguous run of tiles per resident wavefront
 SEGMENT_LOG2 = 22              # synthetic segment generated on the host, tiled on the device
 
@@ -39,6 +50,7 @@ def parse():
     ap.add_argument("--log2-frames", type=int, default=28, help="frames per step and GPU (default 2^28 = 1 GiB of cs16)")
     ap.add_argument("--cpu-frames-log2", type=int, default=28, help="bounded CPU-baseline sample (2^28 = one step's batch, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="2 = BASELINE configs[1] (the metric's config, default); 3 / 4 = configs[2] / configs[3], secondary timings")
     ap.add_argument("--traffic-bytes", type=float, default=1421606298.0,
                     help="HBM bytes per k_front launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes); reported as roofline.traffic when the workload is the default 2^28 frames")
     return ap.parse_args()
@@ -116,18 +128,24 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    chain_kw, rate, fmt, in_bps, workload = CHAIN, 2.4e6, "cs16", 4, None
+    if args.config != 2:
+        o = OTHER[args.config]
+        chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
+        if args.log2_frames == 28:
+            args.log2_frames = o["log2_frames"]
     frames = 1 << args.log2_frames
     plan = shard_plan(world, rank, frames)
     seg_frames = min(frames, 1 << SEGMENT_LOG2)
-    seg = synth.raw_stream(seg_frames, 2.4e6, plan["seed"], "cs16")          # int16 [2*seg_frames]
+    seg = synth.raw_stream(seg_frames, rate, plan["seed"], fmt)               # interleaved I,Q integers
     d_seg = torch.from_numpy(seg).to(dev)
-    d_in = d_seg.repeat(frames // seg_frames).contiguous()                     # 4 B per frame, resident in HBM
+    d_in = d_seg.repeat(frames // seg_frames).contiguous()                     # resident in HBM
     del d_seg
 
-    chain = iq_tool_amd.Chain(device=local_rank, block_samples=BLOCK_SAMPLES, **CHAIN)
+    chain = iq_tool_amd.Chain(device=local_rank, block_samples=BLOCK_SAMPLES, **chain_kw)
     chain.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     cap_frames = chain.max_out_frames(frames)
-    d_out = torch.empty(cap_frames * 4, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(cap_frames * chain.out_bytes, dtype=torch.uint8, device=dev)
     out_frames = []
 
     def step():
@@ -151,7 +169,7 @@ def main():
     front = prof["front"]
     k_ms = front["ms"] / max(front["launches"], 1)
     n_out_avg = float(np.mean(out_frames)) if out_frames else 0.0
-    alg_bytes = frames * 4 + n_out_avg * 4            # in_bytes + r * out_bytes per input frame
+    alg_bytes = frames * in_bps + n_out_avg * chain.out_bytes   # in_bytes + r * out_bytes per input frame
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
     if rank == 0:
@@ -169,9 +187,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic_bytes if args.log2_frames == 28 else None,
                          "kernel": "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "read_only_frac": round(frames * 4 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
+                         "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config != 2:
+            line["config"]["workload"] = workload
+            line["roofline"]["traffic"] = None
+            line["roofline"]["note"] = "front kernel only; per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
         else:
             line["cpu_baseline"] = None

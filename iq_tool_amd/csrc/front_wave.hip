@@ -164,14 +164,18 @@ __device__ __forceinline__ cf2 cmul_tab(cf2 x, cf2 cs)
 // frame -> base[idx]; base is wave-uniform, idx a small per-lane offset.  cs16: same result as
 // src/sample_convert.c:40-57 for every finite input -- +-0.5 by sign is a copysign (0 gives 0 either
 // way), truncation then int16 saturation equals float clamp then truncation.
+__device__ __forceinline__ uint32_t pack_cs16(cf2 v)
+{
+    float p = v.x * 32767.0f, q = v.y * 32767.0f;
+    p += copysignf(0.5f, p); q += copysignf(0.5f, q);
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)p, (int)q);
+    return __builtin_bit_cast(uint32_t, pk);
+}
 __device__ __forceinline__ void pack_store_at(char *base, uint32_t idx, int fmt, cf2 v)
 {
     if (fmt == IQGPU_FMT_CS16) {
-        float p = v.x * 32767.0f, q = v.y * 32767.0f;
-        p += copysignf(0.5f, p); q += copysignf(0.5f, q);
-        typedef short s2 __attribute__((ext_vector_type(2)));
-        const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)p, (int)q);
-        *(s2 *)(base + 4u * idx) = pk;
+        *(uint32_t *)(base + 4u * idx) = pack_cs16(v);
     } else if (fmt == IQGPU_FMT_CF32) {
         *(cf2 *)(base + 8u * idx) = v;
     } else {
@@ -275,6 +279,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         load_chunk<VB>(src + 256 * VB, nxt[1]);
     }
 
+    // cs16 output of the streaming variant: a tile's four packed dwords are held in registers and
+    // stored at the top of the NEXT iteration, right after the wait for the prefetched frames, so
+    // that this wait (vmcnt(0)) only ever covers loads and stores issued a whole tile earlier
+    const bool defer = !EDGE && a.out_fmt == IQGPU_FMT_CS16;
+    uint32_t pend_val[4] = {0, 0, 0, 0}, pend_idx[4] = {~0u, ~0u, ~0u, ~0u};
+    char *pend_base = (char *)a.out;
     STAMP_DECL
     STAMP_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
@@ -290,6 +300,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
             unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             STAMP(0);
+            if (defer) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pend_idx[r] != ~0u) { *(uint32_t *)(pend_base + 4u * pend_idx[r]) = pend_val[r]; pend_idx[r] = ~0u; }
+            }
             {
                 const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
                 load_chunk<VB>(src, nxt[0]);
@@ -425,10 +440,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
                         if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
-                        pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
+                        if (defer) { pend_val[r] = pack_cs16(cf2{yy.x, yy.y}); pend_idx[r] = kk; }
+                        else pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
                 }
+                pend_base = obase;
             }
             // outputs of this tile, ceil((2^32 - delta0) / step) = floor((2^32 - 1 - delta0) / step) + 1
             const uint32_t xm = 0xffffffffu - delta0;
@@ -452,6 +469,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
+    }
+    if (defer) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (pend_idx[r] != ~0u) *(uint32_t *)(pend_base + 4u * pend_idx[r]) = pend_val[r];
     }
     STAMP_FLUSH(a.sink);
 }
