@@ -310,25 +310,37 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 load_chunk<VB>(src, nxt[0]);
                 load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
+            if (a.iq_enable) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (a.iq_enable) {
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const float re = x[c][s].x;
                         x[c][s].x = re * a.iq_magp1;
                         x[c][s].y = fmaf(a.iq_phase, re, x[c][s].y);
                     }
-                }
-                if (a.nco_mode != 0) {
+            }
+            if (a.nco_mode != 0) {
+                // all eight table lookups first, then the eight complex multiplies: one LDS round
+                // trip per tile instead of eight
+                v2f cs[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
                     uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, nco_phasor2(w.nco, th));
-                        x[c][s] = cf2{y.x, y.y};
-                        th += a.nco_dtheta;
-                    }
+                    for (int s = 0; s < 4; ++s) { cs[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
                 }
+                // (an empty asm that consumes all eight values: keeps hipcc's scheduler from sinking each
+                // lookup next to its multiply, which costs a full LDS round trip per sample)
+                asm volatile("" : "+v"(cs[0][0]), "+v"(cs[0][1]), "+v"(cs[0][2]), "+v"(cs[0][3]),
+                                  "+v"(cs[1][0]), "+v"(cs[1][1]), "+v"(cs[1][2]), "+v"(cs[1][3]));
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, cs[c][s]);
+                        x[c][s] = cf2{y.x, y.y};
+                    }
             }
         } else {
 #pragma unroll
@@ -510,6 +522,11 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
     __syncthreads();
 
     const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+#ifdef IQGPU_STAGGER
+    // de-synchronise the 12 waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
+    // otherwise march through them in lockstep, so that LDS time and VALU time add up
+    for (int i = 0; i < wave * IQGPU_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
+#endif
     if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
         const int keep = a.hist_cap - (int)a.frames_in;
         for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
