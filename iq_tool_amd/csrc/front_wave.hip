@@ -472,12 +472,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         STAMP(5);
         // ------------------------------------------------------------ slide the windows
         {
-            float4 ve, vo, vh;
-            if (lane < 15) { ve = ld4(XE + 64 * kRowB + lane * 16); vo = ld4(XO + 64 * kRowB + lane * 16); }
-            if (lane < 12) vh = ld4(HB + 64 * kRowB + lane * 16);
+            // the last 5 (XE, XO) / 4 (HB) rows become the history rows of the next tile.  One dword per
+            // lane: a ds_write_b32 costs 4 LDS cycles whatever the lane count, a ds_write_b128 13.
+            float ve = 0.f, vo = 0.f, vh = 0.f;
+            if (lane < 60) { ve = *(const float *)(XE + 64 * kRowB + lane * 4); vo = *(const float *)(XO + 64 * kRowB + lane * 4); }
+            if (lane < 48) vh = *(const float *)(HB + 64 * kRowB + lane * 4);
             __builtin_amdgcn_wave_barrier();
-            if (lane < 15) { *(float4 *)(XE + lane * 16) = ve; *(float4 *)(XO + lane * 16) = vo; }
-            if (lane < 12) *(float4 *)(HB + lane * 16) = vh;
+            if (lane < 60) { *(float *)(XE + lane * 4) = ve; *(float *)(XO + lane * 4) = vo; }
+            if (lane < 48) *(float *)(HB + lane * 4) = vh;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(6);

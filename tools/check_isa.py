@@ -3,10 +3,11 @@
 
 The polyphase tap gather issues its 28 ds_read_b64 from two adjacent inline-asm blocks and waits for
 them with an `s_waitcnt lgkmcnt(0)` at the end of the second block.  hipcc does not know that the
-destination registers of asm loads are still in flight, so no instruction of its own may sit
-between the two blocks (it could read or copy a tap register before the data has landed).  This
+destination registers of asm loads are still in flight, so no instruction of its own that
+sits between the two blocks may touch a tap register before the data has landed.  This
 script compiles front_wave.hip to gfx950 ISA and verifies for every instantiation that
-  (1) each gather consists of two asm blocks with no instruction between them,
+  (1) each gather consists of two asm blocks and no instruction between them reads, copies or
+      overwrites a register that the first block's reads are still filling,
   (2) the second block ends with s_waitcnt lgkmcnt(0),
   (3) no asm global_load / buffer_load is left in the file (loads are compiler-managed).
 Exit code 0 = ok.  Run by __graft_entry__.build() and tests/test_host_logic.py."""
@@ -74,9 +75,21 @@ def check(lines):
             continue
         for a, b in zip(gather[0::2], gather[1::2]):
             n_gathers += 1
+            # registers that the first block's reads are still filling
+            inflight = set()
+            for ins in a[2]:
+                m = re.match(r"ds_read_b64 v\[(\d+):(\d+)\]", ins)
+                if m:
+                    inflight |= set(range(int(m.group(1)), int(m.group(2)) + 1))
             between = [x.strip() for x in fl[a[1] + 1:b[0]] if x.strip() and not x.strip().startswith(";")]
-            if between:
-                errors.append("k_front_s1<%s>: instructions between the two gather blocks: %s" % (bps, between[:3]))
+            for ins in between:
+                touched = set()
+                for m in re.finditer(r"v\[(\d+):(\d+)\]", ins):
+                    touched |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                for m in re.finditer(r"\bv(\d+)\b", ins):
+                    touched.add(int(m.group(1)))
+                if touched & inflight:
+                    errors.append("k_front_s1<%s>: `%s` touches a tap register that is still in flight" % (bps, ins))
             if sum(1 for x in a[2] if x.startswith("ds_read_b64")) != 14 or sum(1 for x in b[2] if x.startswith("ds_read_b64")) != 14:
                 errors.append("k_front_s1<%s>: gather blocks do not hold 14 + 14 reads" % bps)
             if not b[2][-1].startswith("s_waitcnt lgkmcnt(0)"):
