@@ -96,6 +96,7 @@ struct iqgpu_chain {
     // device state
     hipStream_t own_stream = nullptr, stream = nullptr;
     cf2 *d_nco_tab = nullptr; float *d_arb = nullptr; float *d_hb = nullptr; cf2 *d_ftaps = nullptr;
+    cf2 *d_hfreq = nullptr, *d_twiddle = nullptr; int fft_log2n = 0;   // overlap-save path of FFT-kind filters
     cf2 *d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
     cd2 *d_dc_state = nullptr;
     void *d_sink = nullptr;      // store sink of k_front_s1
@@ -154,6 +155,8 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_arb) (void)hipFree(c->d_arb);
     if (c->d_hb) (void)hipFree(c->d_hb);
     if (c->d_ftaps) (void)hipFree(c->d_ftaps);
+    if (c->d_hfreq) (void)hipFree(c->d_hfreq);
+    if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_dc_state) (void)hipFree(c->d_dc_state);
     if (c->d_sink) (void)hipFree(c->d_sink);
@@ -307,6 +310,28 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             }
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
+        if (c->fp.enabled && c->fp.block > 0 && 2 * (int64_t)c->fp.block <= kMaxFftN && (c->fp.block & (c->fp.block - 1)) == 0 && !c->force_generic) {
+            // H = FFT_N(taps) / N and the twiddle table, in double on the host (once per chain)
+            const int N = 2 * (int)c->fp.block;
+            int lg = 0; while ((1 << lg) < N) ++lg;
+            c->fft_log2n = lg;
+            std::vector<cf2> tw((size_t)N), hf((size_t)N);
+            const double w0 = -2.0 * 3.14159265358979323846 / (double)N;
+            for (int k = 0; k < N; ++k) tw[(size_t)k] = cf2{(float)std::cos(w0 * k), (float)std::sin(w0 * k)};
+            const size_t L = c->fp.taps.size();
+            for (int p = 0; p < N; ++p) {
+                double hr = 0.0, hi = 0.0;
+                for (size_t k = 0; k < L; ++k) {
+                    const int idx = (int)(((int64_t)p * (int64_t)k) % N);
+                    const double cr = std::cos(w0 * idx), ci = std::sin(w0 * idx);
+                    hr += c->fp.taps[k].re * cr - c->fp.taps[k].im * ci;
+                    hi += c->fp.taps[k].re * ci + c->fp.taps[k].im * cr;
+                }
+                hf[(size_t)p] = cf2{(float)(hr / N), (float)(hi / N)};
+            }
+            CREATE_RC(upload(&c->d_twiddle, tw.data(), tw.size()));
+            CREATE_RC(upload(&c->d_hfreq, hf.data(), hf.size()));
+        }
         CREATE_TRY(hipMalloc((void **)&c->d_dc_state, sizeof(cd2)));
         CREATE_TRY(hipMemset(c->d_dc_state, 0, sizeof(cd2)));
         CREATE_TRY(hipMalloc(&c->d_sink, 64 * 1024));
@@ -625,7 +650,18 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         fa.n_emit = p.n_emit;
         fa.pnco_mode = c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
         fa.out_fmt = c->desc.out_format; fa.out = d_out;
-        { KernelTimer kt(c, IQGPU_K_FILTER); HIP_TRY(launch_fir(fa, c->stream)); }
+        if (c->d_hfreq) {
+            FftConvArgs ca{};
+            ca.fbuf = fcur; ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
+            ca.block = (int)c->fp.block; ca.log2n = c->fft_log2n; ca.n_emit = p.n_emit;
+            ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
+            ca.out_fmt = fa.out_fmt; ca.out = fa.out;
+            KernelTimer kt(c, IQGPU_K_FILTER);
+            HIP_TRY(launch_fftconv(ca, c->stream));
+        } else {
+            KernelTimer kt(c, IQGPU_K_FILTER);
+            HIP_TRY(launch_fir(fa, c->stream));
+        }
         // next call's buffer front: history (L-1) + still-pending samples
         const size_t keep = L1 + (size_t)p.fpending_next;
         int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;

@@ -137,6 +137,26 @@ struct FirArgs {
 };
 hipError_t launch_fir(const FirArgs &a, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// k_fftconv: FFT-kind user filter as overlap-save block convolution in LDS (fftconv.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxFftN = 8192;     // 2 x N cf32 ping-pong = 128 KiB of LDS
+struct FftConvArgs {
+    const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]
+    const cf2 *hfreq;         // FFT_N(taps) / N
+    const cf2 *twiddle;       // exp(-2 pi i k / N), k < N
+    int32_t    ntaps;
+    int32_t    block;         // B = fftfilt block size; N = 2 B
+    int32_t    log2n;
+    int64_t    n_emit;        // a whole number of blocks
+    int32_t    pnco_mode;
+    uint32_t   pnco_theta0, pnco_dtheta;
+    const cf2 *nco_tab;
+    int32_t    out_fmt;
+    void      *out;
+};
+hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s);
+
 // dst[i] = src[i], i < n (cf32)
 hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);
 

@@ -303,6 +303,24 @@ def test_fft_filter_block_quantised_counts(gpu, oracle):
         pos += n
 
 
+@pytest.mark.parametrize("taps,fft_size", [(33, 0), (129, 1024), (1025, 0), (2049, 8192)])
+def test_fft_overlap_save_kernel_agrees_with_direct_form(gpu, oracle, monkeypatch, taps, fft_size):
+    """k_fftconv (overlap-save in LDS) and k_fir (direct form) are the same linear convolution"""
+    from iq_tool_amd import ops
+    x = synth.complex_signal(300000, 2.4e6, 15)
+    reqs = (("passband", 250e3, 120e3),)
+    kw = dict(filter_taps=taps, filter_impl="fft", fft_size=fft_size)
+    f = oracle.Filter(oracle.make_filter_cfg(reqs, filter_taps=taps, impl="fft", fft_size=fft_size), 2.4e6, 2.4e6, no_resample=True)
+    want = f.apply(x)
+    op = ops.Filter(reqs, 2.4e6, **kw)
+    got = np.concatenate([op.apply(x[:77777]), op.apply(x[77777:])])
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    direct = ops.Filter(reqs, 2.4e6, **kw).apply(x)
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert got.size == want.size == direct.size and got.size % f.block == 0
+    assert np.abs(got - want).max() <= TOL and np.abs(direct - want).max() <= TOL
+
+
 def test_create_errors(gpu):
     from iq_tool_amd import IqgpuError
     with pytest.raises(IqgpuError) as e:
