@@ -1,14 +1,17 @@
 // fftconv.hip -- k_fftconv: block convolution for the FFT-kind user filter (fftfilt_crcf / fftfilt_cccf,
 // src/filter.c:339-342, 464-526) as overlap-SAVE in LDS.
 //
-// liquid's fftfilt is overlap-add with a 2n-point FFT per n-sample block (SPEC B.3); any exact linear
-// convolution is result-equivalent, only the block-quantised output count is observable and that is
-// applied by the host (plan_call).  Here one 256-thread workgroup owns one block of B = n outputs:
-//   window  = the 2B filter-input samples ending with the block (the first B are its history),
-//   X       = FFT_2B(window)            Stockham autosort, radix 4 (+ one radix-2 pass), ping-pong in LDS
-//   Y       = IFFT_2B(X . H)            H = FFT_2B(taps) / 2B, computed once on the host in double
-//   outputs = Y[B .. 2B)                (valid because taps - 1 <= B), then [post NCO] and pack.
-// Twiddles come from a 2B-entry table in global memory (L2-resident; double-precision values
+// liquid's fftfilt is overlap-add with a 2n-point FFT per n-sample block and firfilt is the direct form
+// (SPEC B.3); both are the same linear convolution, only fftfilt's block-quantised output COUNT is
+// observable and that is applied by the host (plan_call).  So the kernel's transform size N is a
+// free tuning choice, independent of the reference's block size, and long FIR-kind filters take
+// this path too.  One workgroup owns V = N - (L-1) consecutive outputs:
+//   window  = the N filter-input samples ending with them (the first L-1 are history),
+//   X       = FFT_N(window)             Stockham autosort, radix 4 (+ one radix-2 pass), ping-pong in LDS
+//   Y       = IFFT_N(X . H)             H = FFT_N(taps) / N, computed once on the host in double
+//   outputs = Y[L-1 .. N)               (the part of the circular convolution without wrap-around),
+//                                       then [post NCO] and pack.
+// Twiddles come from an N-entry table in global memory (L2-resident; double-precision values
 // rounded to float -- v_sin/v_cos are not accurate enough for the 1e-5 budget).
 #include <hip/hip_runtime.h>
 
@@ -26,11 +29,11 @@ __device__ __forceinline__ cf2 cmulf(cf2 a, cf2 b)
 // one Stockham pass of radix R (4 or 2) over N points: src -> dst, sub-transform size Ns -> Ns*R.
 // tw[k] = exp(-2 pi i k / N)
 template <int R>
-__device__ __forceinline__ void stockham_pass(const cf2 *src, cf2 *dst, const cf2 *tw, int N, int Ns, int tid)
+__device__ __forceinline__ void stockham_pass(const cf2 *src, cf2 *dst, const cf2 *tw, int N, int Ns, int tid, int nthr)
 {
     const int nb = N / R;
     const int tstride = N / (Ns * R);                 // table step of this pass
-    for (int j = tid; j < nb; j += kThreads) {
+    for (int j = tid; j < nb; j += nthr) {
         const int k = j & (Ns - 1);
         cf2 v[R];
 #pragma unroll
@@ -56,18 +59,18 @@ __device__ __forceinline__ void stockham_pass(const cf2 *src, cf2 *dst, const cf
 }
 
 // forward transform of the N points in buf0 (ping-pong with buf1); returns the buffer holding the result
-__device__ __forceinline__ cf2 *fft_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int N, int log2n, int tid)
+__device__ __forceinline__ cf2 *fft_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int N, int log2n, int tid, int nthr)
 {
     cf2 *src = buf0, *dst = buf1;
     int Ns = 1;
     if (log2n & 1) {
-        stockham_pass<2>(src, dst, tw, N, Ns, tid);
+        stockham_pass<2>(src, dst, tw, N, Ns, tid, nthr);
         __syncthreads();
         Ns = 2;
         cf2 *t = src; src = dst; dst = t;
     }
     while (Ns < N) {
-        stockham_pass<4>(src, dst, tw, N, Ns, tid);
+        stockham_pass<4>(src, dst, tw, N, Ns, tid, nthr);
         __syncthreads();
         Ns *= 4;
         cf2 *t = src; src = dst; dst = t;
@@ -75,35 +78,35 @@ __device__ __forceinline__ cf2 *fft_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int
     return src;
 }
 
-__global__ __launch_bounds__(kThreads) void k_fftconv(const FftConvArgs a)
+__global__ __launch_bounds__(kFftMaxThreads) void k_fftconv(const FftConvArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int B = a.block, N = 2 * B;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N = 1 << a.log2n, L1 = a.ntaps - 1, V = N - L1;
     cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + N;
     cf2 *s_nco = buf1 + N;                                  // only when the post NCO is on
-    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += kThreads) s_nco[i] = a.nco_tab[i];
+    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += nthr) s_nco[i] = a.nco_tab[i];
 
-    const int64_t blk = blockIdx.x;
-    // window sample p <-> filter-input stream index s = blk*B - B + p <-> fbuf[(ntaps-1) + s]
-    const int64_t base = (int64_t)(a.ntaps - 1) + blk * B - B;
-    for (int p = tid; p < N; p += kThreads) {
-        const int64_t fi = base + p;
-        buf0[p] = (fi >= 0) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+    // window sample p <-> filter-input stream index s = blk*V - L1 + p <-> fbuf[L1 + s]
+    const int64_t o0 = (int64_t)blockIdx.x * V;
+    for (int p = tid; p < N; p += nthr) {
+        const int64_t fi = o0 + p;
+        buf0[p] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
     }
     __syncthreads();
-    cf2 *X = fft_lds(buf0, buf1, a.twiddle, N, a.log2n, tid);
+    cf2 *X = fft_lds(buf0, buf1, a.twiddle, N, a.log2n, tid, nthr);
     cf2 *other = (X == buf0) ? buf1 : buf0;
     // Y = conj(FFT(conj(X . H))), H already carries the 1/N
-    for (int p = tid; p < N; p += kThreads) {
+    for (int p = tid; p < N; p += nthr) {
         const cf2 z = cmulf(X[p], a.hfreq[p]);
         X[p] = cf2{z.x, -z.y};
     }
     __syncthreads();
-    cf2 *Y = fft_lds(X, other, a.twiddle, N, a.log2n, tid);
-    const int64_t o0 = blk * B;
-    for (int i = tid; i < B; i += kThreads) {
-        cf2 y = Y[B + i];
+    cf2 *Y = fft_lds(X, other, a.twiddle, N, a.log2n, tid, nthr);
+    const int64_t left = a.n_emit - o0;
+    const int nv = left < (int64_t)V ? (int)left : V;
+    for (int i = tid; i < nv; i += nthr) {
+        cf2 y = Y[L1 + i];
         y.y = -y.y;
         const int64_t k = o0 + i;
         if (a.pnco_mode != 0)
@@ -115,13 +118,17 @@ __global__ __launch_bounds__(kThreads) void k_fftconv(const FftConvArgs a)
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
 {
     if (a.n_emit <= 0) return hipSuccess;
-    const unsigned nb = (unsigned)(a.n_emit / a.block);      // n_emit is a whole number of blocks
-    const size_t lds = (size_t)4 * a.block * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
+    const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
+    if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
+    const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
+    const size_t lds = (size_t)2 * N * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fftconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_fftconv, dim3(nb), dim3(kThreads), lds, s, a);
+    int nthr = a.threads > 0 ? a.threads : (N >= 8192 ? 1024 : (N >= 4096 ? 512 : 256));
+    if (nthr > kFftMaxThreads) nthr = kFftMaxThreads;
+    hipLaunchKernelGGL(k_fftconv, dim3(nb), dim3(nthr), lds, s, a);
     return hipGetLastError();
 }
 

@@ -96,7 +96,7 @@ struct iqgpu_chain {
     // device state
     hipStream_t own_stream = nullptr, stream = nullptr;
     cf2 *d_nco_tab = nullptr; float *d_arb = nullptr; float *d_hb = nullptr; cf2 *d_ftaps = nullptr;
-    cf2 *d_hfreq = nullptr, *d_twiddle = nullptr; int fft_log2n = 0;   // overlap-save path of FFT-kind filters
+    cf2 *d_hfreq = nullptr, *d_twiddle = nullptr; int fft_log2n = 0, fft_threads = 0;   // overlap-save path of FFT-kind filters
     cf2 *d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
     cd2 *d_dc_state = nullptr;
     void *d_sink = nullptr;      // store sink of k_front_s1
@@ -310,22 +310,34 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             }
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
-        if (c->fp.enabled && c->fp.block > 0 && 2 * (int64_t)c->fp.block <= kMaxFftN && (c->fp.block & (c->fp.block - 1)) == 0 && !c->force_generic) {
-            // H = FFT_N(taps) / N and the twiddle table, in double on the host (once per chain)
-            const int N = 2 * (int)c->fp.block;
-            int lg = 0; while ((1 << lg) < N) ++lg;
+        // overlap-save path: every FFT-kind filter, and FIR-kind ones long enough that two transforms
+        // per window beat the direct form (the two are the same linear convolution, SPEC B.3)
+        const size_t Lt = c->fp.taps.size();
+        if (c->fp.enabled && !c->force_generic && Lt >= 2 && 2 * (Lt - 1) <= (size_t)kMaxFftN &&
+            (c->fp.block > 0 || Lt >= (size_t)kFftMinTaps)) {
+            // N = 4 (L-1) rounded up to a power of two in [256, 4096] (two workgroups per CU), 8192 only
+            // when the taps need it; measured on config 3: N 4096 0.61 ms, N 8192 0.70 ms
+            int lg = 8;
+            while ((size_t)(1 << lg) < 4 * (Lt - 1) && (1 << lg) < 4096) ++lg;
+            while ((size_t)(1 << lg) < 2 * (Lt - 1)) ++lg;
+            if (const char *e = getenv("IQGPU_FFT_LOG2N")) { const int v = atoi(e); if (v >= 1 && (1 << v) <= kMaxFftN && (size_t)(1 << v) >= 2 * (Lt - 1)) lg = v; }
+            if (const char *e = getenv("IQGPU_FFT_THREADS")) c->fft_threads = atoi(e);
+            const int N = 1 << lg;
             c->fft_log2n = lg;
-            std::vector<cf2> tw((size_t)N), hf((size_t)N);
+            // H = FFT_N(taps) / N and the twiddle table, in double on the host (once per chain)
+            std::vector<double> ct((size_t)N), st((size_t)N);
             const double w0 = -2.0 * 3.14159265358979323846 / (double)N;
-            for (int k = 0; k < N; ++k) tw[(size_t)k] = cf2{(float)std::cos(w0 * k), (float)std::sin(w0 * k)};
-            const size_t L = c->fp.taps.size();
+            for (int k = 0; k < N; ++k) { ct[(size_t)k] = std::cos(w0 * k); st[(size_t)k] = std::sin(w0 * k); }
+            std::vector<cf2> tw((size_t)N), hf((size_t)N);
+            for (int k = 0; k < N; ++k) tw[(size_t)k] = cf2{(float)ct[(size_t)k], (float)st[(size_t)k]};
             for (int p = 0; p < N; ++p) {
                 double hr = 0.0, hi = 0.0;
-                for (size_t k = 0; k < L; ++k) {
-                    const int idx = (int)(((int64_t)p * (int64_t)k) % N);
-                    const double cr = std::cos(w0 * idx), ci = std::sin(w0 * idx);
+                unsigned idx = 0;                                  // p k mod N
+                for (size_t k = 0; k < Lt; ++k) {
+                    const double cr = ct[idx], ci = st[idx];
                     hr += c->fp.taps[k].re * cr - c->fp.taps[k].im * ci;
                     hi += c->fp.taps[k].re * ci + c->fp.taps[k].im * cr;
+                    idx = (idx + (unsigned)p) & (unsigned)(N - 1);
                 }
                 hf[(size_t)p] = cf2{(float)(hr / N), (float)(hi / N)};
             }
@@ -652,8 +664,9 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         fa.out_fmt = c->desc.out_format; fa.out = d_out;
         if (c->d_hfreq) {
             FftConvArgs ca{};
-            ca.fbuf = fcur; ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
-            ca.block = (int)c->fp.block; ca.log2n = c->fft_log2n; ca.n_emit = p.n_emit;
+            ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
+            ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
+            ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = p.n_emit;
             ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
             ca.out_fmt = fa.out_fmt; ca.out = fa.out;
             KernelTimer kt(c, IQGPU_K_FILTER);

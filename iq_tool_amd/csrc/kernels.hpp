@@ -15,6 +15,7 @@ constexpr int kWaves = 12;         // wavefronts per workgroup in k_front_s1 (3 
 constexpr int kWThreads = kWaves * 64;
 constexpr int kFirOutTile = 1024;  // outputs per workgroup tile in the FIR kernel
 constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
+constexpr int kFftMinTaps = 96;    // FIR-kind filters at least this long run as overlap-save (k_fftconv)
 
 struct cf2 { float x, y; };
 struct cd2 { double x, y; };
@@ -141,14 +142,16 @@ hipError_t launch_fir(const FirArgs &a, hipStream_t s);
 // k_fftconv: FFT-kind user filter as overlap-save block convolution in LDS (fftconv.hip)
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxFftN = 8192;     // 2 x N cf32 ping-pong = 128 KiB of LDS
+constexpr int kFftMaxThreads = 1024;
 struct FftConvArgs {
     const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]
+    int64_t    fbuf_len;      // valid cf32 entries in fbuf
     const cf2 *hfreq;         // FFT_N(taps) / N
     const cf2 *twiddle;       // exp(-2 pi i k / N), k < N
     int32_t    ntaps;
-    int32_t    block;         // B = fftfilt block size; N = 2 B
-    int32_t    log2n;
-    int64_t    n_emit;        // a whole number of blocks
+    int32_t    log2n;         // N = 1 << log2n >= 2 (ntaps - 1); each workgroup emits N - (ntaps - 1) outputs
+    int32_t    threads;       // 0 = auto
+    int64_t    n_emit;
     int32_t    pnco_mode;
     uint32_t   pnco_theta0, pnco_dtheta;
     const cf2 *nco_tab;
