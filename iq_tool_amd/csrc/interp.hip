@@ -1,0 +1,161 @@
+// interp.hip -- k_interp: msresamp_crcf for ratios r >= 1 (src/resampler.c:27, 51; SPEC B.6):
+//   arbitrary 256-arm polyphase resampler at rate_arb in [1, 2]  ->  S half-band interpolators
+//   -> [post NCO] -> pack.
+// It runs behind the pointwise front stage (and the pre-resample user filter, src/filter.c:43-92
+// places the filter BEFORE the resampler whenever the chain does not decimate), on a cf32 buffer
+// laid out like the filter's: [hist samples of the previous calls][this call's new samples].
+//
+// Every stage is a pure function of the stream position, so a workgroup rebuilds what it needs:
+// for a tile of kInterpTile final outputs it walks the cascade backwards once (ext[s] = extra
+// samples of level s in front of the tile; host, make_interp_geometry) and then forwards through
+// LDS, level by level:
+//   level 0      = arbitrary-resampler outputs k:  P_k = phi0 + k step (24-bit fraction),
+//                  input index q = P_k >> 24, arm = (P_k >> 16) & 255, 14 taps ending at x[q]
+//   level s+1[u] = u even: level s[i - m]                                   (delay branch)
+//                  u odd : sum_t h[2t+1] level s[i - 2m + 1 + t], i = u>>1  (filter branch)
+// Outputs with k < 0 belong to earlier calls and are recomputed from the history samples;
+// before the start of the stream everything is zero, as the reference's zeroed windows are.
+#include <hip/hip_runtime.h>
+
+#include "../../include/iqgpu.h"
+#include "dsp_device.hpp"
+#include "kernels.hpp"
+
+namespace iqgpu {
+
+__global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int S = a.S;
+    cf2   *s_nco = (cf2 *)smem;                              // 1024 {cos, sin}
+    float *s_arb = (float *)(s_nco + 1024);                  // [256][16]
+    float *s_hb  = s_arb + 256 * 16;                         // branch taps of every stage
+    cf2   *s_in  = (cf2 *)(s_hb + ((a.n_hb_taps + 3) & ~3)); // staged resampler input
+    cf2   *s_lvl = s_in + a.in_cap;                          // levels 0 .. S-1 (level S goes to memory)
+
+    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += kThreads) s_nco[i] = a.nco_tab[i];
+    for (int i = tid; i < 256 * 16; i += kThreads) s_arb[i] = a.arb_table[i];
+    for (int i = tid; i < a.n_hb_taps; i += kThreads) s_hb[i] = a.hb_taps[i];
+
+    const int n0 = kInterpTile >> S;                         // resampler outputs per tile
+    const int64_t step = (int64_t)a.step;
+    const int64_t phi = (int64_t)a.phi0;
+
+    for (int64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        __syncthreads();                                     // previous tile done with the LDS
+        const int64_t j0 = t * kInterpTile;                  // first final output of the tile
+        const int64_t k0 = j0 >> S;
+        // ---- stage the input window of resampler outputs [k0 - ext0, k0 + n0) ----
+        const int64_t k_lo = k0 - a.ext[0];
+        const int n_k = n0 + a.ext[0];
+        const int64_t q_base = ((phi + k_lo * step) >> 24) - (kArbWin - 1);
+        int64_t q_top = (phi + (k_lo + n_k - 1) * step) >> 24;
+        if (q_top > a.n_in - 1) q_top = a.n_in - 1;
+        const int n_q = (int)(q_top - q_base + 1);
+        for (int i = tid; i < n_q; i += kThreads) {
+            const int64_t bi = q_base + i + a.hist;          // index into xbuf
+            s_in[i] = (bi >= 0) ? a.xbuf[bi] : cf2{0.0f, 0.0f};
+        }
+        __syncthreads();
+        // ---- level 0: arbitrary resampler ----
+        for (int i = tid; i < n_k; i += kThreads) {
+            const int64_t k = k_lo + i;
+            const int64_t P = phi + k * step;
+            const int64_t q = P >> 24;
+            cf2 y{0.0f, 0.0f};
+            if (q <= q_top) {                                // later inputs have not arrived yet
+                const int arm = (int)((P >> 16) & 255);
+                const cf2 *w = s_in + (int)(q - q_base);
+                const float *tp = s_arb + arm * 16;
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+                for (int n = 0; n < kArbWin; ++n) {
+                    const cf2 sv = w[-n];
+                    ar = fmaf(tp[n], sv.x, ar); ai = fmaf(tp[n], sv.y, ai);
+                }
+                y = cf2{ar, ai};
+            }
+            if (S == 0) {
+                if (k < a.n_arb) {                           // ext[0] = 0: k >= 0
+                    if (a.pnco_mode != 0)
+                        y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
+                    pack_store(a.out, k, a.out_fmt, y);
+                }
+            } else {
+                s_lvl[a.lvl_off[0] + i] = y;
+            }
+        }
+        // ---- half-band interpolators ----
+        for (int s = 0; s < S; ++s) {
+            __syncthreads();
+            const int m = a.m[s];
+            const cf2 *src = s_lvl + a.lvl_off[s];
+            const float *taps = s_hb + a.tap_off[s];
+            const bool last = (s + 1 == S);
+            const int e1 = last ? 0 : a.ext[s + 1];
+            const int n1 = (kInterpTile >> (S - s - 1)) + e1;
+            const int64_t u_lo = (j0 >> (S - s - 1)) - e1;            // first index at level s+1
+            const int64_t i_base = (j0 >> (S - s)) - a.ext[s];        // level-s index of src[0]
+            cf2 *dst = last ? nullptr : s_lvl + a.lvl_off[s + 1];
+            for (int idx = tid; idx < n1; idx += kThreads) {
+                const int64_t u = u_lo + idx;
+                const int li = (int)((u >> 1) - i_base);
+                cf2 y;
+                if ((u & 1) == 0) {
+                    y = src[li - m];
+                } else {
+                    const cf2 *p = src + li - 2 * m + 1;
+                    float ar = 0.0f, ai = 0.0f;
+                    for (int q = 0; q < 2 * m; ++q) {
+                        const cf2 sv = p[q];
+                        ar = fmaf(taps[q], sv.x, ar); ai = fmaf(taps[q], sv.y, ai);
+                    }
+                    y = cf2{ar, ai};
+                }
+                if (last) {
+                    if (u < a.n_emit) {
+                        if (a.pnco_mode != 0)
+                            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)u * a.pnco_dtheta), a.pnco_mode);
+                        pack_store(a.out, u, a.out_fmt, y);
+                    }
+                } else {
+                    dst[idx] = y;
+                }
+            }
+        }
+    }
+}
+
+// ext[s], LDS offsets and capacities for a chain of S interpolators with semi-lengths m[0..S)
+// (run order: m[0] is the lowest-rate stage).  Returns the input history the kernel needs.
+int make_interp_geometry(InterpArgs &a)
+{
+    const int S = a.S;
+    a.ext[S] = 0;
+    for (int s = S - 1; s >= 0; --s) a.ext[s] = (a.ext[s + 1] + 1) / 2 + 2 * a.m[s] - 1;
+    int off = 0;
+    for (int s = 0; s < S; ++s) {
+        a.lvl_off[s] = off;
+        off += (kInterpTile >> (S - s)) + a.ext[s];
+        off = (off + 1) & ~1;
+    }
+    a.lvl_off[S] = off;
+    const uint64_t n_k = (uint64_t)((kInterpTile >> S) + a.ext[0]);
+    a.in_cap = (int)((((n_k * a.step) >> 24) + kArbWin + 4) & ~(uint64_t)1);
+    return (int)((((uint64_t)a.ext[0] * a.step) >> 24) + 1 + kArbWin);
+}
+
+hipError_t launch_interp(const InterpArgs &a, int n_cu, hipStream_t s)
+{
+    if (a.n_emit <= 0) return hipSuccess;
+    const size_t lds = 1024 * sizeof(cf2) + 256 * 16 * sizeof(float) + (size_t)((a.n_hb_taps + 3) & ~3) * sizeof(float) +
+                       (size_t)(a.in_cap + a.lvl_off[a.S]) * sizeof(cf2);
+    int64_t grid = a.n_tiles;
+    const int64_t cap = (int64_t)n_cu * 4;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_interp, dim3((unsigned)grid), dim3(kThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

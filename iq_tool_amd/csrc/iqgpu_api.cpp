@@ -63,6 +63,21 @@ struct DevBuf {
         cap = want;
         return IQGPU_OK;
     }
+    // grow, keeping the first keep_bytes (synchronises the stream once per growth)
+    int ensure_keep(size_t bytes, size_t keep_bytes, hipStream_t s)
+    {
+        if (bytes <= cap) return IQGPU_OK;
+        DevBuf nb;
+        int rc = nb.ensure(bytes); if (rc) return rc;
+        if (p && keep_bytes) {
+            if (hipMemcpyAsync(nb.p, p, keep_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                nb.release(); return fail(IQGPU_EHIP, "device copy failed while growing a stream buffer");
+            }
+        }
+        release();
+        p = nb.p; cap = nb.cap;
+        return IQGPU_OK;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -72,6 +87,8 @@ struct iqgpu_chain {
     float ratio = 1.0f;
     double target_rate = 0.0;
     bool resample = false;
+    bool decim = false;          // resampler fused into the front kernel (r < 1, filter after it or none)
+    bool late = false;           // resampler behind the front stage / pre filter: k_interp (r >= 1)
     ResamplePlan rp;
     FilterPlan fp;
     // operator constants
@@ -102,6 +119,10 @@ struct iqgpu_chain {
     void *d_sink = nullptr;      // store sink of k_front_s1
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
+    DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
+    InterpArgs ia{};              // geometry of the r >= 1 path
+    int ihist = 0;
+    float *d_ihb = nullptr;
     DevBuf stage_in, stage_out;
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     // profiling
@@ -156,12 +177,14 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_hb) (void)hipFree(c->d_hb);
     if (c->d_ftaps) (void)hipFree(c->d_ftaps);
     if (c->d_hfreq) (void)hipFree(c->d_hfreq);
+    if (c->d_ihb) (void)hipFree(c->d_ihb);
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_dc_state) (void)hipFree(c->d_dc_state);
     if (c->d_sink) (void)hipFree(c->d_sink);
     c->dc_agg.release(); c->dc_carry.release();
     c->fbuf[0].release(); c->fbuf[1].release();
+    c->ibuf[0].release(); c->ibuf[1].release();
     c->stage_in.release(); c->stage_out.release();
     for (auto &pe : c->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -227,19 +250,31 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     std::string err;
     if (c->resample) {
         if (!make_resample_plan(c->ratio, 60.0f, c->rp, err)) return fail(IQGPU_ERATIO, "%s", err.c_str());
-        if (c->rp.interp) return fail(IQGPU_EUNSUPPORTED, "interpolating ratios (r > 1) are not built yet (ratio %.6f)", (double)c->ratio);
         if (c->rp.S >= kMaxS) return fail(IQGPU_ERATIO, "too many half-band stages");
-        c->S = c->rp.S;
     }
-    c->D = 1 << c->S;
-    c->TG = kTile >> c->S;
 
     // ---- user filter (src/filter.c:138-393) ----
     {
         int rc = make_filter_plan(*d, in_rate, c->target_rate, c->fp, err);
         if (rc != IQGPU_OK) return fail(rc, "%s", err.c_str());
-        if (c->fp.enabled && c->resample && !c->fp.post_resample)
-            return fail(IQGPU_EUNSUPPORTED, "pre-resample user filter together with a resampler is not built yet");
+    }
+    // r < 1 decimates inside the front kernel (filter, if any, behind it); otherwise the filter
+    // comes first (src/filter.c:43-92) and the resampler runs last, in k_interp
+    c->late = c->resample && (c->rp.interp || (c->fp.enabled && !c->fp.post_resample));
+    c->decim = c->resample && !c->late;
+    c->S = c->decim ? c->rp.S : 0;
+    c->D = 1 << c->S;
+    c->TG = kTile >> c->S;
+    if (c->late) {
+        InterpArgs &ia = c->ia;
+        ia.S = c->rp.S; ia.step = c->rp.step;
+        int off = 0;
+        for (int s2 = 0; s2 < ia.S; ++s2) {      // run order of the interpolators: lowest rate first
+            const HalfbandStage &st = c->rp.stages[(size_t)(ia.S - 1 - s2)];
+            ia.m[s2] = st.m; ia.tap_off[s2] = off; off += 2 * st.m;
+        }
+        ia.n_hb_taps = off;
+        c->ihist = (make_interp_geometry(ia) + 15) & ~15;
     }
 
     // ---- geometry ----
@@ -247,7 +282,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     size_t block = d->block_samples ? d->block_samples : 262144;
     if (block % kTile != 0 || block == 0) return fail(IQGPU_EINVAL, "block_samples must be a multiple of %d", kTile);
     c->tiles_per_block = (int)(block / kTile);
-    if (c->resample) {
+    if (c->decim) {
         c->warm_tiles = (int)((c->rp.history_in + kTile - 1) / kTile);
         if (c->warm_tiles < 1) c->warm_tiles = 1;
         c->hist_cap = c->warm_tiles * kTile + c->D;
@@ -294,7 +329,19 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         std::vector<cfloat> tab(1024);
         nco_fill_sincos(tab.data());
         CREATE_RC(upload(&c->d_nco_tab, (const cf2 *)tab.data(), 1024));
-        if (c->resample) {
+        if (c->late) {
+            CREATE_RC(upload(&c->d_arb, c->rp.arb_table.data(), c->rp.arb_table.size()));
+            std::vector<float> hb;
+            for (int s2 = 0; s2 < c->ia.S; ++s2)
+                for (float v : c->rp.stages[(size_t)(c->ia.S - 1 - s2)].branch) hb.push_back(v);
+            if (hb.empty()) hb.push_back(0.0f);
+            CREATE_RC(upload(&c->d_ihb, hb.data(), hb.size()));
+            for (int i = 0; i < 2; ++i) {
+                CREATE_RC(c->ibuf[i].ensure(((size_t)c->ihist + 1) * sizeof(cf2)));
+                CREATE_TRY(hipMemset(c->ibuf[i].p, 0, c->ibuf[i].cap));
+            }
+        }
+        if (c->decim) {
             CREATE_RC(upload(&c->d_arb, c->rp.arb_table.data(), c->rp.arb_table.size()));
             std::vector<float> hb;
             for (int i = 0; i < c->S; ++i) {
@@ -395,7 +442,7 @@ extern "C" int iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *i
         }
         if (hb_taps) {
             size_t o = 0;
-            for (int i = 0; i < c->S; ++i)
+            for (int i = 0; i < c->rp.S; ++i)
                 for (float v : c->rp.stages[(size_t)i].proto) { if (o < cap_hb) hb_taps[o] = v; ++o; }
         }
         if (arb_proto && c->resample) {
@@ -419,8 +466,8 @@ static void fill_info(const iqgpu_chain *c, iqgpu_chain_info *info)
     memset(info, 0, sizeof(*info));
     info->ratio = c->ratio;
     info->interp = c->rp.interp ? 1 : 0;
-    info->num_halfband_stages = c->S;
-    for (int i = 0; i < c->S && i < 16; ++i) info->stage_m[i] = c->rp.stages[(size_t)i].m;
+    info->num_halfband_stages = c->resample ? c->rp.S : 0;
+    for (int i = 0; i < info->num_halfband_stages && i < 16; ++i) info->stage_m[i] = c->rp.stages[(size_t)i].m;
     info->rate_arb = c->rp.rate_arb;
     info->arb_step = c->rp.step;
     info->nco_dtheta = c->nco_dtheta;
@@ -445,8 +492,10 @@ extern "C" int iqgpu_chain_get_filter_taps(const iqgpu_chain *c, float *re_im, s
 // ------------------------------------------------------------------------------------------------
 struct CallPlan {
     int64_t n_groups = 0;      // complete 2^S groups this call
-    int64_t n_res = 0;         // resampler (or pass-through) outputs this call
+    int64_t n_res = 0;         // front-kernel outputs this call (resampled, or one per input)
     int64_t n_emit = 0;        // frames written to the caller
+    int64_t n_x = 0;           // r >= 1 path: samples entering k_interp (after the pre filter)
+    int64_t n_arb = 0;         //              polyphase outputs; n_emit = n_arb << S
     uint64_t phi_next = 0;
     int rem_next = 0;
     uint64_t fpending_next = 0;
@@ -455,7 +504,22 @@ struct CallPlan {
 static CallPlan plan_call(const iqgpu_chain *c, size_t frames_in)
 {
     CallPlan p;
-    if (c->resample) {
+    if (c->late) {
+        p.n_res = (int64_t)frames_in;
+        p.n_x = p.n_res;
+        if (c->fp.enabled && c->fp.block) { // src/filter.c:503-525
+            const uint64_t total = c->fpending + (uint64_t)p.n_res;
+            p.n_x = (int64_t)((total / c->fp.block) * c->fp.block);
+            p.fpending_next = total - (uint64_t)p.n_x;
+        }
+        const uint64_t span = (uint64_t)p.n_x << 24;
+        const uint64_t step = c->rp.step;
+        if (span > c->phi) { p.n_arb = (int64_t)((span - c->phi + step - 1) / step); p.phi_next = c->phi + (uint64_t)p.n_arb * step - span; }
+        else { p.n_arb = 0; p.phi_next = c->phi - span; }
+        p.n_emit = p.n_arb << c->ia.S;
+        return p;
+    }
+    if (c->decim) {
         const uint64_t avail = (uint64_t)c->rem + frames_in;
         p.n_groups = (int64_t)(avail >> c->S);
         p.rem_next = (int)(avail & (uint64_t)(c->D - 1));
@@ -491,6 +555,7 @@ extern "C" size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames
     size_t cap = (size_t)std::ceil((double)frames_in * r) + 128;
     if (cap < frames_in) cap = frames_in;
     if (c->fp.enabled && c->fp.block) cap += c->fp.block;
+    if (c->late) cap += ((size_t)2 << c->ia.S) + (c->fp.block ? (size_t)std::ceil((double)c->fp.block * r) : 0);
     return cap;
 }
 
@@ -590,6 +655,13 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         }
         fcur = (cf2 *)c->fbuf[c->fcur].p;
     }
+    // ---- k_interp input buffer (r >= 1 path) ----
+    cf2 *icur = nullptr;
+    if (c->late) {
+        int rc = c->ibuf[c->icur].ensure_keep(((size_t)c->ihist + (size_t)p.n_x + 1) * sizeof(cf2), (size_t)c->ihist * sizeof(cf2), c->stream);
+        if (rc) return rc;
+        icur = (cf2 *)c->ibuf[c->icur].p;
+    }
 
     // ---- front kernel ----
     {
@@ -614,7 +686,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         // phase of i_rel = 0, i.e. rem samples before the first new sample
         a.nco_theta0 = c->nco_theta - (uint32_t)c->rem * c->nco_dtheta;
         a.nco_tab = c->d_nco_tab;
-        a.mode = c->resample ? 1 : 0;
+        a.mode = c->decim ? 1 : 0;
         a.S = c->S;
         for (int i = 0; i < c->S; ++i) { a.m[i] = c->rp.stages[(size_t)i].m; a.tap_off[i] = c->tap_off[i]; }
         for (int i = 0; i <= c->S + 1; ++i) a.lvl_off[i] = c->lvl_off[i];
@@ -622,13 +694,14 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         a.step = c->rp.step; a.n_est = c->n_est; a.phi0 = c->phi;
         a.n_groups = p.n_groups; a.n_out = p.n_res;
         a.total_tiles = total_tiles; a.tiles_per_block = c->tiles_per_block; a.warm_tiles = c->warm_tiles;
-        const bool nco_in_front = !filt;                 // with a filter stage the post NCO runs after it
-        a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
         a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
-        if (filt) { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
-        else      { a.out_fmt = c->desc.out_format; a.out = d_out; }
+        const bool nco_in_front = !filt && !c->late;     // otherwise the post NCO runs in the last stage
+        a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
+        if (filt)         { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
+        else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
+        else              { a.out_fmt = c->desc.out_format; a.out = d_out; }
         // wave-autonomous fast path: one half-band stage (m = 10), no dc blocker
-        const bool fast_s1 = c->resample && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
+        const bool fast_s1 = c->decim && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
         if (fast_s1) {
             a.w_total_tiles = (span_samples + kWTile - 1) / kWTile;
             // per-wave run length: with block_samples = 0 every resident wave (12 per CU, one
@@ -653,20 +726,22 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
         else HIP_TRY(launch_front(a, n_blocks, c->stream));
     }
-    if (c->resample) c->hist_cur ^= 1;
+    if (c->decim) c->hist_cur ^= 1;
 
     // ---- filter stage ----
     if (filt) {
         FirArgs fa{};
         fa.fbuf = fcur; fa.taps = c->d_ftaps; fa.ntaps = (int)c->fp.taps.size(); fa.is_complex = c->fp.is_complex ? 1 : 0;
-        fa.n_emit = p.n_emit;
-        fa.pnco_mode = c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
-        fa.out_fmt = c->desc.out_format; fa.out = d_out;
+        const int64_t n_filt = c->late ? p.n_x : p.n_emit;
+        fa.n_emit = n_filt;
+        fa.pnco_mode = c->late ? 0 : c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
+        if (c->late) { fa.out_fmt = IQGPU_FMT_CF32; fa.out = icur + c->ihist; }
+        else         { fa.out_fmt = c->desc.out_format; fa.out = d_out; }
         if (c->d_hfreq) {
             FftConvArgs ca{};
             ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
             ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
-            ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = p.n_emit;
+            ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = n_filt;
             ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
             ca.out_fmt = fa.out_fmt; ca.out = fa.out;
             KernelTimer kt(c, IQGPU_K_FILTER);
@@ -679,9 +754,25 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         const size_t keep = L1 + (size_t)p.fpending_next;
         int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;
         { KernelTimer kt(c, IQGPU_K_MOVE);
-          HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + p.n_emit, (int64_t)keep, c->stream)); }
+          HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream)); }
         c->fcur ^= 1;
         c->fpending = p.fpending_next;
+    }
+
+    // ---- resampler behind the front stage / pre filter ----
+    if (c->late) {
+        InterpArgs ia = c->ia;
+        ia.xbuf = icur; ia.hist = c->ihist; ia.n_in = p.n_x;
+        ia.phi0 = c->phi; ia.n_arb = p.n_arb; ia.n_emit = p.n_emit;
+        ia.n_tiles = (p.n_emit + kInterpTile - 1) / kInterpTile;
+        ia.hb_taps = c->d_ihb; ia.arb_table = c->d_arb;
+        ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
+        ia.out_fmt = c->desc.out_format; ia.out = d_out;
+        { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
+        int rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
+        { KernelTimer kt(c, IQGPU_K_MOVE);
+          HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
+        c->icur ^= 1;
     }
 
     // ---- advance the stream position ----
@@ -724,7 +815,8 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
-    if (c->resample)
+    if (c->late) HIP_TRY(hipMemsetAsync(c->ibuf[c->icur].p, 0, (size_t)c->ihist * sizeof(cf2), c->stream));
+    if (c->decim)
         for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2), c->stream));
     if (c->fp.enabled) {
         // the filter object's history is cleared; the FFT remainder is NOT (src/filter.c:417-436):

@@ -160,6 +160,40 @@ struct FftConvArgs {
 };
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// k_interp: msresamp for r >= 1 -- arbitrary polyphase, then S half-band interpolators,
+//           [post NCO], pack (interp.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int kInterpTile = 2048;  // final outputs per workgroup tile
+constexpr int kArbWin = 14;        // taps per polyphase arm
+struct InterpArgs {
+    const cf2 *xbuf;          // [hist samples of earlier calls][n_in new samples]
+    int32_t    hist;
+    int64_t    n_in;
+    uint64_t   phi0;          // phase of output k = 0 relative to new sample 0
+    uint32_t   step;
+    int64_t    n_arb;         // polyphase outputs of this call
+    int64_t    n_emit;        // n_arb << S
+    int64_t    n_tiles;
+    int32_t    S;
+    int32_t    m[kMaxS];      // run order: [0] = lowest rate
+    int32_t    tap_off[kMaxS];
+    int32_t    ext[kMaxS + 1];     // samples of level s rebuilt in front of a tile
+    int32_t    lvl_off[kMaxS + 1]; // LDS offsets (cf32) of levels 0..S-1; [S] = total
+    int32_t    in_cap;        // staged input window (cf32)
+    int32_t    n_hb_taps;
+    const float *hb_taps;     // filter-branch taps h[2t+1] of every stage
+    const float *arb_table;   // [256][16]
+    int32_t    pnco_mode;
+    uint32_t   pnco_theta0, pnco_dtheta;
+    const cf2 *nco_tab;
+    int32_t    out_fmt;
+    void      *out;
+};
+// fills ext / lvl_off / in_cap from S, m[], step; returns the input history (samples) k_interp needs
+int make_interp_geometry(InterpArgs &a);
+hipError_t launch_interp(const InterpArgs &a, int n_cu, hipStream_t s);
+
 // dst[i] = src[i], i < n (cf32)
 hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);
 

@@ -244,6 +244,61 @@ def test_resampler_operator(gpu, oracle):
     assert np.array_equal(rs.execute(x), got)
 
 
+@pytest.mark.parametrize("r", [1.0, 1.37, 2.0, 2.5, 5.3, 47.9])
+def test_resampler_operator_interpolating(gpu, oracle, r):
+    """r >= 1: arbitrary stage first, then the half-band interpolators (k_interp)"""
+    from iq_tool_amd import ops
+    n = 60000 if r < 10 else 9000
+    x = synth.complex_signal(n, 2.4e6, 16)
+    r = np.float32(r)
+    m = oracle.MsResamp(r)
+    want = m.execute(x)
+    rs = ops.Resampler(r)
+    got = np.concatenate([rs.execute(x[:1]), rs.execute(x[1:20001]), rs.execute(x[20001:20003]), rs.execute(x[20003:])])
+    assert got.size == want.size and got.size % (1 << m.S) == 0
+    assert np.abs(got - want).max() <= TOL
+    rs.reset()
+    assert np.abs(rs.execute(x) - want).max() <= TOL
+
+
+@pytest.mark.parametrize("fmt_in,fmt_out", [("cs16", "cs16"), ("cu8", "cf32")])
+def test_chain_interpolating_with_post_shift(gpu, oracle, fmt_in, fmt_out):
+    n = 150000
+    raw = synth.raw_stream(n, 250e3, 17, fmt_in)
+    kw = dict(in_format=fmt_in, out_format=fmt_out, input_rate_hz=250e3, target_rate_hz=2.4e6,
+              dc_block=True, shift_hz=-300e3, shift_after_resample=True)
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, splits=[16384, 1, 70000, n - 86385], **kw)
+    assert got.size == want.size
+    if fmt_out == "cf32":
+        assert np.abs(cf(got) - cf(want)).max() <= TOL
+    else:
+        int_close(got, want)
+
+
+@pytest.mark.parametrize("impl,taps", [("fir", 0), ("fft", 0), ("fft", 257), ("fir", 301)])
+def test_chain_pre_filter_then_interpolation(gpu, oracle, impl, taps):
+    """not decimating -> the user filter runs BEFORE the resampler (src/filter.c:43-92)"""
+    n = 200000
+    raw = synth.raw_stream(n, 1.0e6, 18, "cs16")
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=1.0e6, target_rate_hz=3.3e6, shift_hz=50e3,
+              filters=(("passband", 120e3, 90e3), ("lowpass", 200e3, 0.0)), filter_impl=impl, filter_taps=taps)
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, splits=[5, 99995, 100000], **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+
+
+def test_chain_filter_then_unit_ratio_resampler(gpu, oracle):
+    """target rate == input rate with the resampler left on: filter first, then msresamp at r = 1"""
+    n = 100000
+    raw = synth.raw_stream(n, 2.4e6, 19, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=2.4e6,
+              filters=(("lowpass", 300e3, 0.0),))
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, splits=[33333, 66667], **kw)
+    int_close(got, want)
+
+
 # --------------------------------------------------------------------------------------------
 # user filter: FIR and FFT-block kinds
 # --------------------------------------------------------------------------------------------

@@ -136,8 +136,8 @@ def test_error_codes_follow_the_reference_fatal_paths(lib):
     rc, msg = code(filters=(("lowpass", 600e3, 0.0),))
     assert rc == -7 and "Nyquist" in msg
     assert code(no_resample=True, filters=(("passband", 50e3, 20e3),), filter_taps=1025, fft_size=1024)[0] == -7
-    assert code(input_rate_hz=2.4e6, target_rate_hz=4.8e6)[0] == -10           # interpolation: not built yet
-    assert code(input_rate_hz=2.4e6, target_rate_hz=2.4e6, filters=(("lowpass", 100e3, 0.0),))[0] == -10
+    assert code(input_rate_hz=2.4e6, target_rate_hz=4.8e6)[0] == 0             # interpolation
+    assert code(input_rate_hz=2.4e6, target_rate_hz=2.4e6, filters=(("lowpass", 100e3, 0.0),))[0] == 0   # filter, then r = 1
     assert code(block_samples=1000)[0] == -1
 
 
