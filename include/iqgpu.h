@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IQGPU_ABI_VERSION 1
+#define IQGPU_ABI_VERSION 2
 
 /* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
 enum {
@@ -88,7 +88,31 @@ typedef struct {
     /* GPU-only knobs */
     int    device_ordinal;              /* HIP device index                                                 */
     size_t block_samples;               /* input samples per workgroup block, multiple of 2048; 0 = auto (one run per resident wave) */
+    /* output AGC, between the post NCO and the pack (src/post_processor.c:55-57, src/agc.c) */
+    int    agc_enable;                  /* config->output_agc.enable                                        */
+    int    agc_profile;                 /* IQGPU_AGC_*  (config->output_agc.profile); only DIGITAL is built  */
+    float  agc_target;                  /* config->output_agc.target_level_arg (0 = AGC_DIGITAL_PEAK_TARGET) */
+    int    agc_clock;                   /* IQGPU_AGC_CLOCK_*: what stands in for get_monotonic_time_sec()    */
+    uint32_t agc_chunk_frames;          /* input frames per reference chunk, 0 = 16384 (PIPELINE_CHUNK_BASE_SAMPLES): */
+                                        /*   every process() call is cut into chunks of this many input frames, */
+                                        /*   counted from the start of the call, and agc_apply sees one chunk at a time */
 } iqgpu_chain_desc;
+
+/* AgcProfile, include/common_types.h:77-82 */
+enum { IQGPU_AGC_OFF = 0, IQGPU_AGC_DX = 1, IQGPU_AGC_LOCAL = 2, IQGPU_AGC_DIGITAL = 3 };
+/* SAMPLES: time of the output stream (samples_seen / target_rate) -- deterministic, and equal to the
+ * wall clock when the reference runs in real time.  WALL: CLOCK_MONOTONIC read once per process() call. */
+enum { IQGPU_AGC_CLOCK_SAMPLES = 0, IQGPU_AGC_CLOCK_WALL = 1 };
+
+/* AppResources' AGC fields (include/app_context.h:227-231) */
+typedef struct {
+    int      locked;
+    float    peak_memory;
+    float    current_gain;
+    int      reserved;
+    double   last_strong_peak_time;
+    uint64_t samples_seen;
+} iqgpu_agc_state;
 
 /* What create() derived; for diagnostics and for parity tests of the design path. */
 typedef struct {
@@ -108,7 +132,7 @@ typedef struct {
 } iqgpu_chain_info;
 
 /* Per-kernel device time accumulated by HIP events on the chain's stream (profiling mode only). */
-enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_COUNT = 8 };
+enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_AGC = 5, IQGPU_K_COUNT = 8 };
 typedef struct {
     uint64_t launches[IQGPU_K_COUNT];
     double   ms[IQGPU_K_COUNT];
@@ -146,6 +170,8 @@ int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t f
 int    iqgpu_chain_reset(iqgpu_chain *c);
 /* what the I/Q optimiser thread publishes (src/iq_correct.c:141-152 reads them once per chunk) */
 int    iqgpu_chain_set_iq_factors(iqgpu_chain *c, float mag, float phase);
+/* synchronises the chain's stream and reports the AGC state (agc.c keeps it in AppResources) */
+int    iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st);
 /* upper bound on frames_out for a call with frames_in frames (>= ceil(n*max(1,r))+128 (+ FFT block),
  * the reference's buffer rule src/pipeline.c:246-258) */
 size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames_in);

@@ -32,7 +32,14 @@ class ChainDesc(C.Structure):
                 ("n_filters", C.c_int), ("filters", FilterReq * 5),
                 ("transition_width_hz", C.c_float), ("attenuation_db", C.c_float),
                 ("filter_taps", C.c_int), ("filter_impl", C.c_int), ("fft_size", C.c_int),
-                ("device_ordinal", C.c_int), ("block_samples", C.c_size_t)]
+                ("device_ordinal", C.c_int), ("block_samples", C.c_size_t),
+                ("agc_enable", C.c_int), ("agc_profile", C.c_int), ("agc_target", C.c_float),
+                ("agc_clock", C.c_int), ("agc_chunk_frames", C.c_uint32)]
+
+
+class AgcState(C.Structure):
+    _fields_ = [("locked", C.c_int), ("peak_memory", C.c_float), ("current_gain", C.c_float),
+                ("reserved", C.c_int), ("last_strong_peak_time", C.c_double), ("samples_seen", C.c_uint64)]
 
 
 class ChainInfo(C.Structure):
@@ -69,6 +76,7 @@ SYMBOLS = [
     ("iqgpu_chain_process", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_process_device", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_reset", C.c_int, [_vp]),
+    ("iqgpu_chain_get_agc_state", C.c_int, [_vp, C.POINTER(AgcState)]),
     ("iqgpu_chain_set_iq_factors", C.c_int, [_vp, C.c_float, C.c_float]),
     ("iqgpu_chain_max_out_frames", _sz, [_vp, _sz]),
     ("iqgpu_chain_next_out_frames", _sz, [_vp, _sz]),

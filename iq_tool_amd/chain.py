@@ -7,8 +7,10 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BYTES_PER_FRAME, FILTER, FILTER_IMPL, FMT, ChainDesc, ChainInfo, FilterReq,
+from ._lib import (BYTES_PER_FRAME, FILTER, FILTER_IMPL, FMT, AgcState, ChainDesc, ChainInfo, FilterReq,
                    IqgpuError, Profile, check)
+
+AGC_PROFILE = {"off": 0, "dx": 1, "local": 2, "digital": 3}
 
 _NP_VIEW = {8: np.uint8, 9: np.int8, 10: np.uint16, 11: np.int16, 16: np.int16, 12: np.uint8,
             13: np.uint32, 14: np.int32, 15: np.float32}
@@ -22,7 +24,8 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
               resample_ratio=0.0, gain=1.0, shift_hz=0.0, shift_after_resample=False,
               dc_block=False, iq_correct=False, iq_mag=0.0, iq_phase=0.0, no_resample=False,
               filters=(), transition_width_hz=0.0, attenuation_db=0.0, filter_taps=0,
-              filter_impl="auto", fft_size=0, device=0, block_samples=0):
+              filter_impl="auto", fft_size=0, device=0, block_samples=0,
+              agc=False, agc_profile="digital", agc_target=0.0, agc_clock="samples", agc_chunk_frames=0):
     lib = _lib.load()
     d = ChainDesc()
     lib.iqgpu_chain_desc_init(C.byref(d))
@@ -53,6 +56,11 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
     d.fft_size = int(fft_size)
     d.device_ordinal = int(device)
     d.block_samples = int(block_samples)
+    d.agc_enable = int(bool(agc))
+    d.agc_profile = AGC_PROFILE[agc_profile] if isinstance(agc_profile, str) else int(agc_profile)
+    d.agc_target = float(agc_target)
+    d.agc_clock = {"samples": 0, "wall": 1}[agc_clock] if isinstance(agc_clock, str) else int(agc_clock)
+    d.agc_chunk_frames = int(agc_chunk_frames)
     return d
 
 
@@ -116,6 +124,13 @@ class Chain:
 
     def reset(self):
         check(self._lib.iqgpu_chain_reset(self._h))
+
+    def agc_state(self):
+        """dict of the AGC fields the reference keeps in AppResources (synchronises)"""
+        st = AgcState()
+        check(self._lib.iqgpu_chain_get_agc_state(self._h, C.byref(st)))
+        return dict(locked=bool(st.locked), peak_memory=st.peak_memory, gain=st.current_gain,
+                    last_strong_peak_time=st.last_strong_peak_time, samples_seen=st.samples_seen)
 
     def set_iq_factors(self, mag, phase):
         check(self._lib.iqgpu_chain_set_iq_factors(self._h, mag, phase))

@@ -1,0 +1,148 @@
+// agc.hip -- output AGC, "digital" profile: agc_apply of src/agc.c:85-222, which the reference runs
+// once per chunk between the post NCO and convert_cf32_to_block (src/post_processor.c:55-57).
+//
+// The gain of a chunk depends on the chunk's OWN peak (look-ahead, agc.c:119-141), so the chain's
+// last stage writes cf32 and three small kernels finish the job:
+//   k_agc_peak   max |x|^2 per chunk (double: exact products, so sqrt gives cabsf's value),
+//   k_agc_scan   one wavefront walks the chunks: scanning phase = prefix max (parallel), locked
+//                phase = speculate "gain unchanged" over 64 chunks at a time and serialise only at the
+//                chunks that ratchet or creep,
+//   k_agc_apply  x * gain[chunk] -> pack.
+// Chunk boundaries in the output come from agc_out_end() (kernels.hpp), the same closed form the
+// host uses for frames_out.
+#include <hip/hip_runtime.h>
+
+#include "../../include/iqgpu.h"
+#include "dsp_device.hpp"
+#include "kernels.hpp"
+
+namespace iqgpu {
+
+// include/constants.h:184-192
+constexpr float kAgcLockTime = 2.0f, kAgcHangTime = 4.0f, kAgcRecovery = 1.0005f, kAgcLower = 0.75f;
+
+__global__ __launch_bounds__(kThreads) void k_agc_peak(const AgcArgs a)
+{
+    const int c = blockIdx.x;
+    const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+    const int64_t len = e - b;
+    if (len <= 0) return;
+    const int64_t per = (len + a.splits - 1) / a.splits;
+    const int64_t lo = b + (int64_t)blockIdx.y * per;
+    int64_t hi = lo + per; if (hi > e) hi = e;
+    double m = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const cf2 v = a.x[i];
+        const double d = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        m = d > m ? d : m;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(m, k); m = o > m ? o : m; }
+    // non-negative doubles order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(a.peak2 + c, (unsigned long long)__double_as_longlong(m));
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
+
+__global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
+{
+    const int lane = threadIdx.x;
+    AgcState st = *a.state;
+    const float target = a.target;
+    int64_t end_prev = 0;
+    for (int c0 = 0; c0 < a.geom.n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const bool valid = c < a.geom.n_chunks;
+        const int64_t e_i = agc_out_end(a.geom, valid ? c : a.geom.n_chunks - 1);
+        int64_t b_i = __shfl_up(e_i, 1);
+        if (lane == 0) b_i = end_prev;
+        const bool active = valid && e_i > b_i;                   // empty chunks never reach agc_apply
+        const uint64_t seen_i = st.seen + (uint64_t)(b_i - end_prev);
+        const float pk = active ? (float)sqrt(__longlong_as_double((long long)a.peak2[c])) : 0.0f;
+        const double t_i = a.clock_wall ? a.t_wall : (double)seen_i / a.rate;
+        float gain_i = st.gain;
+        int cur = 0;
+
+        if (!st.locked) {                                         // agc.c:117-160
+            float run = pk;                                       // inclusive prefix max
+#pragma unroll
+            for (int k = 1; k < 64; k <<= 1) { const float o = __shfl_up(run, k); if (lane >= k) run = fmaxf(run, o); }
+            run = fmaxf(run, st.peak_memory);
+            const bool lock_here = active && ((double)seen_i / a.rate > (double)kAgcLockTime);
+            const unsigned long long lm = __ballot(lock_here);
+            const int first = lm ? __ffsll((long long)lm) - 1 : 64;
+            const float safe = run < 1e-4f ? 1e-4f : run;
+            gain_i = target / safe;
+            const int last = first < 64 ? first : 63;
+            st.peak_memory = __shfl(run, last);
+            if (first < 64) {
+                st.locked = 1;
+                st.gain = __shfl(gain_i, first);
+                st.last_strong = shfl_d(t_i, first);
+            }
+            cur = first + 1;
+        }
+        while (cur < 64) {                                        // agc.c:165-215, gain st.gain entering lane cur
+            const float g = st.gain;
+            const bool cand = active && lane >= cur;
+            const float outp = pk * g;
+            const bool ratchet = cand && outp > 1.0f;
+            const bool healthy = cand && !ratchet && outp > target * kAgcLower;
+            const unsigned long long hmask = __ballot(healthy);
+            const unsigned long long before = hmask & ((1ull << lane) - 1ull);
+            double ls = st.last_strong;                           // last "strong" time seen by this chunk
+            const int src = before ? 63 - __clzll((long long)before) : lane;
+            const double t_src = shfl_d(t_i, src);
+            if (before) ls = t_src;
+            const bool creep = cand && !ratchet && !healthy && (t_i - ls > (double)kAgcHangTime);
+            const unsigned long long chg = __ballot(ratchet || creep);
+            const int first = chg ? __ffsll((long long)chg) - 1 : 64;
+            if (lane >= cur && lane < first) gain_i = g;
+            const unsigned long long hm2 = first < 64 ? (hmask & ((1ull << first) - 1ull)) : hmask;
+            if (hm2) st.last_strong = shfl_d(t_i, 63 - __clzll((long long)hm2));
+            if (first < 64) {
+                const bool is_ratchet = (__ballot(ratchet) >> first) & 1ull;
+                const float pk_f = __shfl(pk, first);
+                if (is_ratchet) { st.gain = 0.99f / pk_f; st.last_strong = shfl_d(t_i, first); }
+                else st.gain = g * kAgcRecovery;
+                if (lane == first) gain_i = st.gain;
+            }
+            cur = first + 1;
+        }
+        if (valid) a.gain[c] = gain_i;
+        const int64_t e_last = __shfl(e_i, 63);
+        st.seen += (uint64_t)(e_last - end_prev);
+        end_prev = e_last;
+    }
+    if (lane == 0) *a.state = st;
+}
+
+__global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
+{
+    const int c = blockIdx.x;
+    const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+    const int64_t len = e - b;
+    if (len <= 0) return;
+    const int64_t per = (len + a.splits - 1) / a.splits;
+    const int64_t lo = b + (int64_t)blockIdx.y * per;
+    int64_t hi = lo + per; if (hi > e) hi = e;
+    const float g = a.gain[c];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const cf2 v = a.x[i];
+        pack_store(a.out, i, a.out_fmt, cf2{v.x * g, v.y * g});   // samples[i] *= gain (complex * real)
+    }
+}
+
+hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
+{
+    if (a.geom.n_chunks <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(a.peak2, 0, (size_t)a.geom.n_chunks * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)a.geom.n_chunks, (unsigned)a.splits);
+    if (a.n_out > 0) hipLaunchKernelGGL(k_agc_peak, grid, dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_agc_scan, dim3(1), dim3(64), 0, s, a);
+    if (a.n_out > 0) hipLaunchKernelGGL(k_agc_apply, grid, dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

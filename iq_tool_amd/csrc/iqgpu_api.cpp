@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,6 +23,13 @@ using namespace iqgpu;
 // error reporting
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+
+static double monotonic_sec() // get_monotonic_time_sec, src/utils.c
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -119,6 +127,10 @@ struct iqgpu_chain {
     void *d_sink = nullptr;      // store sink of k_front_s1
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
+    // output AGC (digital profile)
+    bool agc = false; float agc_target = 0.9f; int64_t agc_chunk = 16384;
+    AgcState *d_agc_state = nullptr; AgcState agc_init{};
+    DevBuf abuf, agc_peak, agc_gain;
     DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
     InterpArgs ia{};              // geometry of the r >= 1 path
     int ihist = 0;
@@ -178,6 +190,8 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_ftaps) (void)hipFree(c->d_ftaps);
     if (c->d_hfreq) (void)hipFree(c->d_hfreq);
     if (c->d_ihb) (void)hipFree(c->d_ihb);
+    if (c->d_agc_state) (void)hipFree(c->d_agc_state);
+    c->abuf.release(); c->agc_peak.release(); c->agc_gain.release();
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_dc_state) (void)hipFree(c->d_dc_state);
@@ -265,6 +279,17 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     c->S = c->decim ? c->rp.S : 0;
     c->D = 1 << c->S;
     c->TG = kTile >> c->S;
+    // ---- output AGC (src/agc.c:21-83, src/config.c:306-330) ----
+    if (d->agc_enable) {
+        if (d->agc_profile != IQGPU_AGC_DIGITAL)
+            return fail(IQGPU_EUNSUPPORTED, "output AGC profile %d: only the 'digital' profile is built (dx / local are liquid agc_crcf, a per-sample nonlinear recurrence)", d->agc_profile);
+        if (d->agc_target != 0.0f && (d->agc_target <= 0.0f || d->agc_target > 1.0f))
+            return fail(IQGPU_EINVAL, "Invalid AGC target level %.2f. Must be between 0.0 and 1.0.", (double)d->agc_target);
+        if (d->agc_clock != IQGPU_AGC_CLOCK_SAMPLES && d->agc_clock != IQGPU_AGC_CLOCK_WALL) return fail(IQGPU_EINVAL, "agc_clock must be IQGPU_AGC_CLOCK_SAMPLES or IQGPU_AGC_CLOCK_WALL");
+        c->agc = true;
+        c->agc_target = d->agc_target > 0.0f ? d->agc_target : 0.9f;      // AGC_DIGITAL_PEAK_TARGET
+        c->agc_chunk = d->agc_chunk_frames ? (int64_t)d->agc_chunk_frames : 16384;   // PIPELINE_CHUNK_BASE_SAMPLES
+    }
     if (c->late) {
         InterpArgs &ia = c->ia;
         ia.S = c->rp.S; ia.step = c->rp.step;
@@ -355,6 +380,11 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
                 CREATE_TRY(hipMalloc((void **)&c->d_hist[i], (size_t)c->hist_cap * sizeof(cf2)));
                 CREATE_TRY(hipMemset(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2)));
             }
+        }
+        if (c->agc) {
+            CREATE_TRY(hipMalloc((void **)&c->d_agc_state, sizeof(AgcState)));
+            c->agc_init = AgcState{0, 0.05f, 1.0f, 0, c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0, 0};
+            CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
         // overlap-save path: every FFT-kind filter, and FIR-kind ones long enough that two transforms
@@ -616,6 +646,15 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
 
     const bool filt = c->fp.enabled;
     const size_t L1 = filt ? c->fp.taps.size() - 1 : 0;
+    const uint64_t fpending0 = c->fpending;
+
+    // with the AGC on, the last stage leaves cf32 in abuf and k_agc_apply packs
+    void *fin_out = d_out;
+    int fin_fmt = c->desc.out_format;
+    if (c->agc) {
+        int rc = c->abuf.ensure(((size_t)p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
+        fin_out = c->abuf.p; fin_fmt = IQGPU_FMT_CF32;
+    }
 
     // ---- geometry of this call ----
     const int64_t span_samples = (int64_t)c->rem + (int64_t)frames_in;
@@ -699,7 +738,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
         if (filt)         { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
         else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
-        else              { a.out_fmt = c->desc.out_format; a.out = d_out; }
+        else              { a.out_fmt = fin_fmt; a.out = fin_out; }
         // wave-autonomous fast path: one half-band stage (m = 10), no dc blocker
         const bool fast_s1 = c->decim && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
         if (fast_s1) {
@@ -736,7 +775,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         fa.n_emit = n_filt;
         fa.pnco_mode = c->late ? 0 : c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
         if (c->late) { fa.out_fmt = IQGPU_FMT_CF32; fa.out = icur + c->ihist; }
-        else         { fa.out_fmt = c->desc.out_format; fa.out = d_out; }
+        else         { fa.out_fmt = fin_fmt; fa.out = fin_out; }
         if (c->d_hfreq) {
             FftConvArgs ca{};
             ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
@@ -767,12 +806,37 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         ia.n_tiles = (p.n_emit + kInterpTile - 1) / kInterpTile;
         ia.hb_taps = c->d_ihb; ia.arb_table = c->d_arb;
         ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
-        ia.out_fmt = c->desc.out_format; ia.out = d_out;
+        ia.out_fmt = fin_fmt; ia.out = fin_out;
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
         int rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
         { KernelTimer kt(c, IQGPU_K_MOVE);
           HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
         c->icur ^= 1;
+    }
+
+    // ---- output AGC: agc_apply per reference chunk (src/post_processor.c:55-57) ----
+    if (c->agc) {
+        AgcArgs ga{};
+        AgcGeom &g = ga.geom;
+        g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
+        g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
+        g.mode = c->late ? 2 : (c->decim ? 1 : 0);
+        g.rem = c->rem; g.S = c->late ? c->ia.S : c->S; g.phi = c->phi; g.step = c->rp.step;
+        g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
+        if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
+        int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
+        rc = c->agc_gain.ensure((size_t)g.n_chunks * sizeof(float)); if (rc) return rc;
+        ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
+        ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p; ga.state = c->d_agc_state;
+        ga.target = c->agc_target; ga.rate = c->target_rate;
+        ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
+        ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;
+        const int64_t avg = p.n_emit / g.n_chunks + 1;
+        int64_t splits = (avg + 16383) / 16384; if (splits > 1024) splits = 1024;
+        ga.splits = (int)splits;
+        ga.out_fmt = c->desc.out_format; ga.out = d_out;
+        KernelTimer kt(c, IQGPU_K_AGC);
+        HIP_TRY(launch_agc(ga, c->stream));
     }
 
     // ---- advance the stream position ----
@@ -815,6 +879,10 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
+    if (c->agc) { // agc_reset, src/agc.c:224-238
+        c->agc_init.last_strong = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0;
+        HIP_TRY(hipMemcpyAsync(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice, c->stream));
+    }
     if (c->late) HIP_TRY(hipMemsetAsync(c->ibuf[c->icur].p, 0, (size_t)c->ihist * sizeof(cf2), c->stream));
     if (c->decim)
         for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2), c->stream));
@@ -824,6 +892,17 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
         const size_t L1 = c->fp.taps.size() - 1;
         HIP_TRY(hipMemsetAsync(c->fbuf[c->fcur].p, 0, L1 * sizeof(cf2), c->stream));
     }
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st)
+{
+    if (!c || !st) return fail(IQGPU_EINVAL, "iqgpu_chain_get_agc_state: NULL argument");
+    if (!c->agc) return fail(IQGPU_EINVAL, "the chain has no output AGC");
+    static_assert(sizeof(iqgpu_agc_state) == sizeof(AgcState), "AGC state layout");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(st, c->d_agc_state, sizeof(AgcState), hipMemcpyDeviceToHost));
     return IQGPU_OK;
 }
 

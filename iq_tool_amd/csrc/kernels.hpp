@@ -194,6 +194,70 @@ struct InterpArgs {
 int make_interp_geometry(InterpArgs &a);
 hipError_t launch_interp(const InterpArgs &a, int n_cu, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// Output AGC, "digital" profile (agc.hip): per-chunk peak -> gain scan over chunks -> scale + pack
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+#define IQGPU_HD __host__ __device__
+#else
+#define IQGPU_HD
+#endif
+// How one process() call maps its input chunks (chunk_frames input frames each, counted from the
+// start of the call) to ranges of its output: closed form, so kernels and host agree without a table.
+struct AgcGeom {
+    int64_t  frames_in;
+    int64_t  chunk_frames;
+    int32_t  n_chunks;
+    int32_t  mode;         // 0 = one output per input, 1 = decimating front kernel, 2 = k_interp path
+    int32_t  rem;          // mode 1: samples of the open 2^S group before the call
+    int32_t  S;            // mode 1: group shift; mode 2: interpolator stages
+    uint64_t phi;          // resampler phase at the start of the call
+    uint32_t step;
+    uint32_t block;        // fftfilt block size (0 = none)
+    uint64_t fpending;     // samples waiting in front of the block filter
+};
+// outputs of the call produced by its chunks 0 .. c (c = -1 -> 0)
+IQGPU_HD inline int64_t agc_out_end(const AgcGeom &g, int64_t c)
+{
+    if (c < 0) return 0;
+    int64_t f = (c + 1) * g.chunk_frames;
+    if (f > g.frames_in) f = g.frames_in;
+    uint64_t n = (uint64_t)f;
+    if (g.mode == 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // pre filter, then resampler
+    if (g.mode != 0) {
+        const uint64_t span = (g.mode == 1 ? (((uint64_t)g.rem + n) >> g.S) : n) << 24;
+        n = span > g.phi ? (span - g.phi + g.step - 1) / g.step : 0;
+        if (g.mode == 2) n <<= g.S;
+    }
+    if (g.mode != 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // filter behind the resampler
+    return (int64_t)n;
+}
+
+struct AgcState {          // == iqgpu_agc_state
+    int32_t  locked;
+    float    peak_memory;
+    float    gain;
+    int32_t  reserved;
+    double   last_strong;
+    uint64_t seen;
+};
+struct AgcArgs {
+    AgcGeom    geom;
+    const cf2 *x;             // the call's output samples before the AGC (cf32)
+    int64_t    n_out;
+    unsigned long long *peak2;// [n_chunks] max |x|^2 per chunk, double bits (zeroed before k_agc_peak)
+    float     *gain;          // [n_chunks]
+    AgcState  *state;
+    float      target;
+    double     rate;          // config->target_rate
+    int32_t    clock_wall;    // 1: every chunk of the call sees time t_wall
+    double     t_wall;
+    int32_t    splits;        // workgroups per chunk
+    int32_t    out_fmt;
+    void      *out;
+};
+hipError_t launch_agc(const AgcArgs &a, hipStream_t s);   // peak, scan, apply
+
 // dst[i] = src[i], i < n (cf32)
 hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);
 

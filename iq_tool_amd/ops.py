@@ -8,6 +8,7 @@ parity tests can be written per operator the way the reference's own API is cut:
     FreqShift.apply / reset_nco                                            src/frequency_shift.c:86-107
     Resampler.execute / reset  (create_resampler, resampler_execute)       src/resampler.c:20-53
     Filter.apply / reset       (filter_create, filter_apply)               src/filter.c:138-526
+    Agc.apply / reset          (agc_create, agc_apply, "digital" profile)  src/agc.c:21-238
 """
 import ctypes as C
 
@@ -91,3 +92,19 @@ class Filter(_Cf32Op):
         super().__init__(input_rate_hz=rate_hz, no_resample=True, filters=tuple(filters), **kw)
 
     apply = _Cf32Op._run
+
+
+class Agc(_Cf32Op):
+    """agc_create / agc_apply / agc_reset with the "digital" profile.  One apply() call is cut into
+    chunks of chunk_frames samples and agc_apply sees them one at a time, as the post-processor
+    thread hands them over (src/post_processor.c:55-57)."""
+
+    def __init__(self, sample_rate_hz, target=0.0, chunk_frames=16384, clock="samples", **kw):
+        super().__init__(input_rate_hz=sample_rate_hz, no_resample=True, agc=True, agc_target=target,
+                         agc_chunk_frames=chunk_frames, agc_clock=clock, **kw)
+
+    apply = _Cf32Op._run
+
+    @property
+    def state(self):
+        return self.chain.agc_state()

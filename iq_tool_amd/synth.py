@@ -52,3 +52,18 @@ def raw_stream(n, rate_hz, seed, fmt, chunk=1 << 22):
         m = min(chunk, n - s)
         parts.append(quantise(complex_signal(m, rate_hz, seed, s), fmt))
     return np.concatenate(parts) if parts else np.zeros(0, np.int16)
+
+
+def agc_envelope_signal(n, rate_hz, seed):
+    """Complex noise whose envelope walks the digital AGC (src/agc.c:105-222) through every branch:
+    an early burst while scanning, a burst after the 2 s lock that clips (ratchet), a fade longer
+    than the 4 s hang time (creep), then a recovery."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.05)
+    t = np.arange(n) / float(rate_hz)
+    env = np.ones(n, np.float32)
+    env[(t > 0.5) & (t < 0.8)] = 3.0
+    env[(t > 3.0) & (t < 3.2)] = 6.0
+    env[t > 4.0] = 0.2
+    env[t > 11.0] = 1.5
+    return x * env

@@ -854,7 +854,97 @@ unsigned orc_filter_apply(orc_filter *q, const orc_cf32 *in, unsigned n, orc_cf3
  * ---------------------------------------------------------------------------------------- */
 #define ORC_CHUNK 16384 /* ref: include/constants.h:123 */
 
+/* ------------------------------------------------------------------------------------------
+ * Output AGC, "digital" profile.  ref: src/agc.c (this part of the file is the reference's own
+ * arithmetic, not liquid's; the dx / local profiles are liquid agc_crcf and are not restated).
+ * Constants: include/constants.h:184-192.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_AGC_PEAK_TARGET      0.9f
+#define ORC_AGC_LOCK_TIME        2.0f
+#define ORC_AGC_HANG_TIME        4.0f
+#define ORC_AGC_RECOVERY_RATE    1.0005f
+#define ORC_AGC_LOWER_THRESHOLD  0.75f
+
+struct orc_agc {
+    float  target;
+    double rate;
+    int    clock_mode;
+    double wall;
+    /* AppResources state, include/app_context.h:227-231 */
+    int      locked;
+    float    gain, peak_memory;
+    uint64_t seen;
+    double   last_strong;
+};
+
+static double agc_now(const orc_agc *q)
+{
+    return q->clock_mode == ORC_AGC_CLOCK_WALL ? q->wall : (double)q->seen / q->rate;
+}
+
+orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode)
+{
+    orc_agc *q = (orc_agc *)calloc(1, sizeof(*q));
+    q->target = (target_level_arg > 0) ? target_level_arg : ORC_AGC_PEAK_TARGET; /* ref: agc.c:111-113 */
+    q->rate = sample_rate;      /* config->target_rate, agc.c:146 */
+    q->clock_mode = clock_mode;
+    orc_agc_reset(q);
+    return q;
+}
+void orc_agc_destroy(orc_agc *q) { free(q); }
+void orc_agc_set_wall_time(orc_agc *q, double now_sec) { q->wall = now_sec; }
+
+void orc_agc_reset(orc_agc *q) /* ref: agc.c:27-33, 75, 231-237 */
+{
+    q->locked = 0; q->seen = 0; q->peak_memory = 0.05f; q->gain = 1.0f;
+    q->last_strong = agc_now(q);
+}
+
+void orc_agc_apply(orc_agc *q, orc_cf32 *x, unsigned n)
+{
+    unsigned i;
+    float peak = 0.0f;
+    if (n == 0) return;                                   /* ref: agc.c:86 */
+    for (i = 0; i < n; i++) {                             /* ref: agc.c:120-124, 166-170 */
+        float mag = hypotf(x[i].re, x[i].im);             /* cabsf */
+        if (mag > peak) peak = mag;
+    }
+    if (!q->locked) {                                     /* scanning, ref: agc.c:117-160 */
+        float safe, g;
+        double elapsed;
+        if (peak > q->peak_memory) q->peak_memory = peak;
+        safe = (q->peak_memory < 1e-4f) ? 1e-4f : q->peak_memory;
+        g = q->target / safe;
+        for (i = 0; i < n; i++) { x[i].re *= g; x[i].im *= g; }
+        elapsed = (double)q->seen / q->rate;
+        if (elapsed > ORC_AGC_LOCK_TIME) {
+            q->locked = 1; q->gain = g;
+            q->last_strong = agc_now(q);
+        }
+    } else {                                              /* locked, ref: agc.c:165-215 */
+        float g = q->gain;
+        float out_peak = peak * g;
+        double now = agc_now(q);
+        if (out_peak > 1.0f) {                            /* safety ratchet */
+            g = 0.99f / peak;
+            q->last_strong = now;
+        } else if (out_peak > (q->target * ORC_AGC_LOWER_THRESHOLD)) {
+            q->last_strong = now;
+        } else if (now - q->last_strong > ORC_AGC_HANG_TIME) {
+            g *= ORC_AGC_RECOVERY_RATE;
+        }
+        q->gain = g;
+        for (i = 0; i < n; i++) { x[i].re *= g; x[i].im *= g; }
+    }
+    q->seen += n;                                         /* ref: agc.c:218 */
+}
+int      orc_agc_is_locked(const orc_agc *q) { return q->locked; }
+float    orc_agc_gain(const orc_agc *q) { return q->gain; }
+float    orc_agc_peak_memory(const orc_agc *q) { return q->peak_memory; }
+uint64_t orc_agc_samples_seen(const orc_agc *q) { return q->seen; }
+
 struct orc_chain {
+    orc_agc *agc;
     orc_chain_desc d;
     float ratio;
     orc_dcblock *dc;
@@ -895,6 +985,7 @@ orc_chain *orc_chain_create(const orc_chain_desc *d, int *err)
         c->filt = orc_filter_create(&d->filter, d->input_rate_hz, target, d->no_resample, err);
         if (!c->filt) { orc_chain_destroy(c); return NULL; }
     }
+    if (d->agc_enable) c->agc = orc_agc_create(d->agc_target, target, d->agc_clock); /* ref: pipeline.c:145 */
     c->cap = orc_chain_max_out_frames(c, ORC_CHUNK);
     c->A = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));
     c->B = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));
@@ -905,7 +996,7 @@ void orc_chain_destroy(orc_chain *c)
 {
     if (!c) return;
     orc_dcblock_destroy(c->dc); orc_nco_destroy(c->pre_nco); orc_nco_destroy(c->post_nco);
-    orc_msresamp_destroy(c->rs); orc_filter_destroy(c->filt);
+    orc_msresamp_destroy(c->rs); orc_filter_destroy(c->filt); orc_agc_destroy(c->agc);
     free(c->A); free(c->B); free(c);
 }
 
@@ -916,10 +1007,12 @@ void orc_chain_reset(orc_chain *c) /* ref: pre_processor.c:57-61, resampler.c:43
     if (c->post_nco) orc_nco_set_phase(c->post_nco, 0.0f);
     if (c->rs) orc_msresamp_reset(c->rs);
     orc_filter_reset(c->filt);
+    if (c->agc) orc_agc_reset(c->agc); /* ref: post_processor.c:75 */
 }
 
 void orc_chain_set_iq_factors(orc_chain *c, float mag, float phase) { c->iq_mag = mag; c->iq_phase = phase; }
 float orc_chain_ratio(const orc_chain *c) { return c->ratio; }
+orc_agc *orc_chain_agc(orc_chain *c) { return c->agc; }
 
 size_t orc_chain_max_out_frames(const orc_chain *c, size_t frames_in)
 {
@@ -961,6 +1054,7 @@ size_t orc_chain_process(orc_chain *c, const void *raw_in, size_t frames_in, voi
             else nw = orc_filter_apply(c->filt, cur, nw, cur);
         }
         if (c->post_nco && nw) { orc_nco_mix_block(c->post_nco, d->shift_hz >= 0, cur, other, nw); { orc_cf32 *t = cur; cur = other; other = t; } }
+        if (nw && c->agc) orc_agc_apply(c->agc, cur, nw); /* ref: post_processor.c:55-57 */
         if (nw) {
             orc_convert_cf32_to_block(cur, (char *)out + total_out * obps, nw, d->out_format);
             if (tap) memcpy(tap + total_out, cur, (size_t)nw * sizeof(orc_cf32));

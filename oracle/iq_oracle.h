@@ -133,13 +133,34 @@ typedef struct {
     int    no_resample;
     orc_filter_cfg filter;
     int    dc_f32_literal;    /* 1: float recurrence exactly as liquid runs it */
+    int    agc_enable;        /* config->output_agc.enable with profile "digital" (agc.c:105-222) */
+    float  agc_target;        /* config->output_agc.target_level_arg; <= 0 -> AGC_DIGITAL_PEAK_TARGET */
+    int    agc_clock;         /* ORC_AGC_CLOCK_* */
 } orc_chain_desc;
+/* ---- output AGC, "digital" profile (ref: src/agc.c:21-83 create, 85-222 apply, 224-238 reset) ----
+ * The reference reads get_monotonic_time_sec() for the hang / creep logic of its locked phase
+ * (agc.c:176, 202); the clock is a parameter here: SAMPLES = time of the output stream
+ * (samples_seen / sample_rate, deterministic, equal to the wall clock when the reference runs
+ * in real time), WALL = the value handed to orc_agc_set_wall_time(). */
+enum { ORC_AGC_CLOCK_SAMPLES = 0, ORC_AGC_CLOCK_WALL = 1 };
+typedef struct orc_agc orc_agc;
+orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode);
+void     orc_agc_destroy(orc_agc *q);
+void     orc_agc_reset(orc_agc *q);
+void     orc_agc_set_wall_time(orc_agc *q, double now_sec);
+void     orc_agc_apply(orc_agc *q, orc_cf32 *x, unsigned n);   /* one reference chunk, in place */
+int      orc_agc_is_locked(const orc_agc *q);
+float    orc_agc_gain(const orc_agc *q);
+float    orc_agc_peak_memory(const orc_agc *q);
+uint64_t orc_agc_samples_seen(const orc_agc *q);
+
 typedef struct orc_chain orc_chain;
 orc_chain *orc_chain_create(const orc_chain_desc *d, int *err);
 void   orc_chain_destroy(orc_chain *c);
 void   orc_chain_reset(orc_chain *c);
 void   orc_chain_set_iq_factors(orc_chain *c, float mag, float phase);
 float  orc_chain_ratio(const orc_chain *c);
+orc_agc *orc_chain_agc(orc_chain *c);        /* NULL when the AGC is off */
 size_t orc_chain_max_out_frames(const orc_chain *c, size_t frames_in);
 /* Processes frames_in frames in reference-sized chunks (16384).  Returns frames written.
  * If cf32_tap != NULL the cf32 samples entering convert_cf32_to_block are also stored there. */

@@ -39,7 +39,8 @@ class ChainDesc(C.Structure):
                 ("iq_correct_enable", C.c_int), ("iq_mag", C.c_float), ("iq_phase", C.c_float),
                 ("no_resample", C.c_int),
                 ("filter", FilterCfg),
-                ("dc_f32_literal", C.c_int)]
+                ("dc_f32_literal", C.c_int),
+                ("agc_enable", C.c_int), ("agc_target", C.c_float), ("agc_clock", C.c_int)]
 
 
 def build(force=False):
@@ -102,6 +103,16 @@ def _proto(lib):
     P("orc_filter_ntaps", C.c_uint, [vp])
     P("orc_filter_taps", C.POINTER(C.c_float), [vp])
     P("orc_filter_apply", C.c_uint, [vp, vp, C.c_uint, vp])
+    P("orc_agc_create", vp, [C.c_float, C.c_double, C.c_int])
+    P("orc_agc_destroy", None, [vp])
+    P("orc_agc_reset", None, [vp])
+    P("orc_agc_set_wall_time", None, [vp, C.c_double])
+    P("orc_agc_apply", None, [vp, vp, C.c_uint])
+    P("orc_agc_is_locked", C.c_int, [vp])
+    P("orc_agc_gain", C.c_float, [vp])
+    P("orc_agc_peak_memory", C.c_float, [vp])
+    P("orc_agc_samples_seen", C.c_uint64, [vp])
+    P("orc_chain_agc", vp, [vp])
     P("orc_chain_create", vp, [C.POINTER(ChainDesc), C.POINTER(C.c_int)])
     P("orc_chain_destroy", None, [vp])
     P("orc_chain_reset", None, [vp])
@@ -345,12 +356,49 @@ class Filter:
         return y[:n].copy()
 
 
+class Agc:
+    """agc_create / agc_apply / agc_reset, "digital" profile (src/agc.c); apply() takes ONE chunk"""
+
+    def __init__(self, sample_rate, target=0.0, clock="samples", L=None, handle=None):
+        self.L = L or lib()
+        self.own = handle is None
+        self.q = handle or self.L.orc_agc_create(target, sample_rate, {"samples": 0, "wall": 1}[clock])
+
+    def __del__(self):
+        if getattr(self, "q", None) and self.own:
+            self.L.orc_agc_destroy(self.q)
+
+    def reset(self):
+        self.L.orc_agc_reset(self.q)
+
+    def set_wall_time(self, t):
+        self.L.orc_agc_set_wall_time(self.q, t)
+
+    def apply(self, x):
+        y = np.array(x, np.complex64, copy=True)
+        self.L.orc_agc_apply(self.q, _ptr(y), y.size)
+        return y
+
+    def apply_chunked(self, x, chunk=16384):
+        return np.concatenate([self.apply(x[i:i + chunk]) for i in range(0, len(x), chunk)]) if len(x) else np.zeros(0, np.complex64)
+
+    locked = property(lambda s: bool(s.L.orc_agc_is_locked(s.q)))
+    gain = property(lambda s: s.L.orc_agc_gain(s.q))
+    peak_memory = property(lambda s: s.L.orc_agc_peak_memory(s.q))
+    samples_seen = property(lambda s: s.L.orc_agc_samples_seen(s.q))
+
+
 def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5,
               gain=1.0, shift_hz=0.0, shift_after_resample=False, dc_block=False,
               iq_correct=False, iq_mag=0.0, iq_phase=0.0, no_resample=False,
               filters=(), transition_width_hz=0.0, attenuation_db=0.0, filter_taps=0,
-              filter_impl="auto", fft_size=0, dc_f32_literal=False):
+              filter_impl="auto", fft_size=0, dc_f32_literal=False,
+              agc=False, agc_target=0.0, agc_clock="samples", agc_chunk_frames=0):
+    assert agc_chunk_frames in (0, 16384), "the oracle chunks like the reference: 16384 frames"
     d = ChainDesc()
+    d.agc_enable = int(bool(agc))
+    d.agc_target = agc_target
+    d.agc_clock = {"samples": 0, "wall": 1}[agc_clock] if isinstance(agc_clock, str) else agc_clock
     d.in_format = fmt_id(in_format)
     d.out_format = fmt_id(out_format)
     d.input_rate_hz = input_rate_hz
@@ -391,6 +439,11 @@ class Chain:
 
     def set_iq_factors(self, mag, phase):
         self.L.orc_chain_set_iq_factors(self.c, mag, phase)
+
+    @property
+    def agc(self):
+        h = self.L.orc_chain_agc(self.c)
+        return Agc(0, L=self.L, handle=h) if h else None
 
     @property
     def ratio(self):

@@ -376,6 +376,93 @@ def test_fft_overlap_save_kernel_agrees_with_direct_form(gpu, oracle, monkeypatc
     assert np.abs(got - want).max() <= TOL and np.abs(direct - want).max() <= TOL
 
 
+# --------------------------------------------------------------------------------------------
+# output AGC, "digital" profile
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("chunk,splits", [(1000, None), (1000, [7000, 1000, 50000, 62000]), (16384, None), (250, [250 * 100, 250 * 380])])
+def test_agc_operator_scan_lock_ratchet_creep(gpu, oracle, chunk, splits):
+    from iq_tool_amd import ops
+    rate = 8000.0
+    x = synth.agc_envelope_signal(120000, rate, 31)
+    a = oracle.Agc(rate)
+    want = a.apply_chunked(x, chunk)
+    op = ops.Agc(rate, chunk_frames=chunk)
+    if splits is None:
+        got = op.apply(x)
+    else:
+        pos, outs = 0, []
+        for n in splits:
+            outs.append(op.apply(x[pos:pos + n])); pos += n
+        assert pos == x.size
+        got = np.concatenate(outs)
+    assert got.size == want.size
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    st = op.state
+    assert st["locked"] and a.locked and st["samples_seen"] == x.size
+    assert abs(st["gain"] - a.gain) <= 1e-6 * a.gain and st["peak_memory"] == a.peak_memory
+    op.reset()
+    st = op.state
+    assert not st["locked"] and st["gain"] == 1.0 and st["samples_seen"] == 0 and st["peak_memory"] == np.float32(0.05)
+    assert np.abs(op.apply(x[:5000]) - oracle.Agc(rate).apply_chunked(x[:5000], chunk)).max() <= 2e-6
+
+
+def test_agc_many_chunks_per_call(gpu, oracle):
+    """more than one 64-chunk batch in the gain scan, lock in the middle of a batch"""
+    from iq_tool_amd import ops
+    rate = 8000.0
+    x = synth.agc_envelope_signal(120000, rate, 33)
+    want = oracle.Agc(rate).apply_chunked(x, 100)
+    got = ops.Agc(rate, chunk_frames=100).apply(x)
+    assert np.abs(got - want).max() <= 2e-6 * float(np.abs(want).max())
+
+
+@pytest.mark.parametrize("out_format", ["cf32", "cs16"])
+def test_agc_in_nrsc5_preset_chain(gpu, oracle, out_format):
+    """every shipped NRSC-5 preset enables the digital AGC (iq_tool_presets.conf:190-248)"""
+    n = 6 * 1000 * 1000            # 2.5 s of input: crosses the 2 s lock
+    raw = synth.raw_stream(n, 2.4e6, 34, "cs16")
+    kw = dict(NRSC5, out_format=out_format, agc=True)
+    want = run_oracle(oracle, raw, **kw)
+    ch = gpu.Chain(**kw)
+    got = np.concatenate([ch.process(raw[:2 * 16384 * 100]), ch.process(raw[2 * 16384 * 100:])])
+    assert got.size == want.size
+    if out_format == "cf32":
+        assert np.abs(cf(got) - cf(want)).max() <= TOL * 20          # gain ~ 3: tolerance scales with it
+    else:
+        int_close(got, want, min_same=0.95)
+    assert ch.agc_state()["locked"]
+
+
+def test_agc_with_fft_filter_and_interpolation_chunks(gpu, oracle):
+    """chunk boundaries in the output follow the block-quantised filter and the r > 1 resampler"""
+    n = 16384 * 12 + 5000
+    raw = synth.raw_stream(n, 8e3, 35, "cs16")
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=8e3, target_rate_hz=20e3, agc=True,
+              filters=(("passband", 1.0e3, 1.5e3),), filter_impl="fft")
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, splits=[16384 * 5, 16384 * 7 + 5000], **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL * 10
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=48e3, target_rate_hz=12e3, agc=True, agc_target=0.5,
+              filters=(("passband", 1.0e3, 1.5e3),), filter_impl="fft")
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL * 10
+
+
+def test_agc_unbuilt_profiles_and_bad_target(gpu):
+    from iq_tool_amd import IqgpuError
+    for prof in ("dx", "local"):
+        with pytest.raises(IqgpuError) as e:
+            gpu.Chain(agc=True, agc_profile=prof)
+        assert e.value.code == -10
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(agc=True, agc_target=1.5)
+    assert e.value.code == -1
+    # the scanning phase never reads the clock: both clock modes agree there
+    raw = synth.raw_stream(100000, 2.4e6, 36, "cs16")
+    assert np.array_equal(gpu.Chain(agc=True, agc_clock="wall", **NRSC5).process(raw), gpu.Chain(agc=True, **NRSC5).process(raw))
+
+
 def test_create_errors(gpu):
     from iq_tool_amd import IqgpuError
     with pytest.raises(IqgpuError) as e:

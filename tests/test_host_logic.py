@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert not missing, missing
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert set(names) == bound, (set(names) ^ bound)
-    assert lib.iqgpu_abi_version() == 1
+    assert lib.iqgpu_abi_version() == 2
 
 
 def test_struct_layouts_match_ctypes(tmp_path):
@@ -49,9 +49,10 @@ def test_struct_layouts_match_ctypes(tmp_path):
         #include <stddef.h>
         #include "iqgpu.h"
         int main(void) {
-            printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(iqgpu_chain_desc), offsetof(iqgpu_chain_desc, shift_hz),
+            printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(iqgpu_chain_desc), offsetof(iqgpu_chain_desc, shift_hz),
                    offsetof(iqgpu_chain_desc, filters), offsetof(iqgpu_chain_desc, block_samples),
-                   sizeof(iqgpu_chain_info), offsetof(iqgpu_chain_info, arb_step), sizeof(iqgpu_profile));
+                   sizeof(iqgpu_chain_info), offsetof(iqgpu_chain_info, arb_step), sizeof(iqgpu_profile),
+                   offsetof(iqgpu_chain_desc, agc_chunk_frames), sizeof(iqgpu_agc_state), offsetof(iqgpu_agc_state, samples_seen));
             return 0;
         }""")
     src = tmp_path / "layout.c"
@@ -59,8 +60,9 @@ def test_struct_layouts_match_ctypes(tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    D, I, P = _lib.ChainDesc, _lib.ChainInfo, _lib.Profile
-    want = [C.sizeof(D), D.shift_hz.offset, D.filters.offset, D.block_samples.offset, C.sizeof(I), I.arb_step.offset, C.sizeof(P)]
+    D, I, P, A = _lib.ChainDesc, _lib.ChainInfo, _lib.Profile, _lib.AgcState
+    want = [C.sizeof(D), D.shift_hz.offset, D.filters.offset, D.block_samples.offset, C.sizeof(I), I.arb_step.offset, C.sizeof(P),
+            D.agc_chunk_frames.offset, C.sizeof(A), A.samples_seen.offset]
     assert got == want
 
 

@@ -370,3 +370,74 @@ def test_chain_create_errors(oracle):
                dict(NRSC5, shift_hz=2.4e6 * 6), dict(NRSC5, filters=(("lowpass", 600e3, 0.0),))):
         with pytest.raises(ValueError):
             oracle.Chain(**kw)
+
+
+# --------------------------------------------------------------------------------------------
+# output AGC, "digital" profile (src/agc.c) against an independent numpy restatement
+# --------------------------------------------------------------------------------------------
+def _agc_numpy(x, rate, target=0.9, chunk=16384):
+    """agc.c:105-222 with the sample-count clock, written chunk by chunk in float32 numpy"""
+    f = np.float32
+    locked, peak_mem, g, seen, last_strong = False, f(0.05), f(1.0), 0, 0.0
+    y = np.empty_like(x)
+    gains = []
+    for b in range(0, len(x), chunk):
+        blk = x[b:b + chunk]
+        peak = f(np.hypot(blk.real.astype(np.float64), blk.imag.astype(np.float64)).max())
+        now = seen / rate
+        if not locked:
+            if peak > peak_mem:
+                peak_mem = peak
+            safe = f(1e-4) if peak_mem < f(1e-4) else peak_mem
+            cur = f(target) / safe
+            if seen / rate > 2.0:
+                locked, g, last_strong = True, cur, now
+        else:
+            outp = f(peak * g)
+            if outp > f(1.0):
+                g = f(0.99) / peak
+                last_strong = now
+            elif outp > f(f(target) * f(0.75)):
+                last_strong = now
+            elif now - last_strong > 4.0:
+                g = f(g * f(1.0005))
+            cur = g
+        y[b:b + chunk] = (blk.real * cur + 1j * (blk.imag * cur)).astype(np.complex64)
+        gains.append(float(cur))
+        seen += len(blk)
+    return y, np.array(gains), locked, float(g), float(peak_mem)
+
+
+def test_agc_digital_matches_numpy_restatement(oracle):
+    rate, chunk = 8000.0, 1000
+    x = synth.agc_envelope_signal(120000, rate, 31)
+    want, gains, locked, g, pm = _agc_numpy(x, rate, chunk=chunk)
+    a = oracle.Agc(rate)
+    got = a.apply_chunked(x, chunk)
+    assert np.array_equal(got.view(np.float32), want.view(np.float32))
+    assert a.locked and locked and a.gain == np.float32(g) and a.peak_memory == np.float32(pm)
+    assert a.samples_seen == x.size
+    # the envelope really drove every branch
+    assert np.any(np.diff(gains[:20]) < 0) and np.any(np.diff(gains[20:]) < 0) and np.any(np.diff(gains[40:]) > 0)
+    a.reset()
+    assert not a.locked and a.gain == 1.0 and a.peak_memory == np.float32(0.05) and a.samples_seen == 0
+
+
+def test_agc_in_chain_runs_between_post_nco_and_pack(oracle):
+    """chain with the AGC == chain without it, cf32 out, then agc_apply per 16384-frame input chunk"""
+    n = 200000
+    raw = synth.raw_stream(n, 48e3, 32, "cs16")
+    kw = dict(in_format="cs16", input_rate_hz=48e3, target_rate_hz=12e3, shift_hz=1e3)
+    plain = oracle.Chain(out_format="cf32", **kw)
+    a = oracle.Agc(12e3)
+    outs = []
+    rb = np.ascontiguousarray(raw).view(np.uint8)
+    for b in range(0, n, 16384):
+        y = plain.process(rb[b * 4:(b + 16384) * 4]).view(np.complex64)
+        if y.size:
+            outs.append(a.apply(y))
+    want = np.concatenate(outs)
+    got = oracle.Chain(out_format="cf32", agc=True, **kw).process(raw).view(np.complex64)
+    assert np.array_equal(got.view(np.float32), want.view(np.float32))
+    packed = oracle.Chain(out_format="cs16", agc=True, **kw).process(raw)
+    assert np.array_equal(packed, oracle.from_cf32(want, "cs16"))
