@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -222,6 +223,10 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--filter-taps")) { int t = atoi(NEXT); if (t && t % 2 == 0) t++; o.desc.filter_taps = t; }   /* src/config.c:233-236 */
         else if (!strcmp(a, "--filter-type")) { const char *v = NEXT; o.desc.filter_impl = !strcmp(v, "fft") ? IQGPU_FILTER_IMPL_FFT : IQGPU_FILTER_IMPL_FIR; }
         else if (!strcmp(a, "--filter-fft-size")) o.desc.fft_size = atoi(NEXT);
+        else if (!strcmp(a, "--output-agc")) { o.desc.agc_enable = 1; if (!o.desc.agc_profile) o.desc.agc_profile = IQGPU_AGC_LOCAL; }   /* src/config.c:306-310 */
+        else if (!strcmp(a, "--agc-profile")) { const char *v = NEXT; o.desc.agc_enable = 1;
+            o.desc.agc_profile = !strcasecmp(v, "dx") ? IQGPU_AGC_DX : !strcasecmp(v, "local") ? IQGPU_AGC_LOCAL : !strcasecmp(v, "digital") ? IQGPU_AGC_DIGITAL : -1; }
+        else if (!strcmp(a, "--agc-target")) o.desc.agc_target = (float)atof(NEXT);
         else if (!strcmp(a, "--chunk-frames")) o.chunk_frames = (size_t)atoll(NEXT);
         else if (!strcmp(a, "--shards")) o.shards = atoi(NEXT);
         else if (!strcmp(a, "--devices")) o.devices = atoi(NEXT);
