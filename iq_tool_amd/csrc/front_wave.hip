@@ -23,6 +23,7 @@
 // are handled by a scalar-load instantiation of the same tile routine; the host gives those tiles
 // to a few extra waves (a handful of tiles each) so that the streaming waves run a loop with no
 // special cases in it.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -209,13 +210,18 @@ struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned 
 // delta0: which of them carry an output (hit), and the gather of that output's 14 taps (7 x
 // ds_read_b64 from the arm's 56-byte row; asm, so that they are not fused into half-rate
 // ds_read2_b64).  Returns with every tap landed.
-__device__ __forceinline__ void issue_taps(const WaveLds &w, int lane, uint32_t delta0, uint32_t step, float inv_step,
-                                           uint32_t &n0, bool hit[4], v2f tp[4][7])
+// first output at or after the lane's first half-band sample (4*lane), for a tile whose first
+// output has phase delta0 (< step): n0 = its index within the tile, Pl = its phase relative to 4*lane
+__device__ __forceinline__ void tap_phase(int lane, uint32_t delta0, uint32_t step, float inv_step, uint32_t &n0, uint32_t &Pl)
 {
     const uint32_t tgt = (uint32_t)(4 * lane) << 24;
     n0 = 0;
     if (tgt > delta0) n0 = ceil_div_small(tgt - delta0, step, inv_step);
-    uint32_t Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);   // phase relative to 4*lane
+    Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);
+}
+
+__device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32_t step, bool hit[4], v2f tp[4][7])
+{
     unsigned row[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -254,7 +260,7 @@ __device__ __forceinline__ void issue_taps(const WaveLds &w, int lane, uint32_t 
 // EDGE = false: every tile (and the one after the last, for the prefetch) lies inside the call's
 //               new, aligned frames and outside the history the call leaves behind.
 // EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
-template <int BPS, bool EDGE>
+template <int BPS, bool EDGE, bool FAST>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1)
 {
@@ -266,8 +272,15 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     const float inv_step = 1.0f / (float)step;
     uint64_t k_tile0 = first_k_at((uint64_t)(t_emit0 * 256) << 24, a.phi0, step);
     uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - ((uint64_t)(t_emit0 * 256) << 24));   // < step
-    const int obps = out_bytes(a.out_fmt);
-    const bool unit_gain = a.gain == 1.0f;
+    const int obps = FAST ? 4 : out_bytes(a.out_fmt);
+    const bool unit_gain = FAST || a.gain == 1.0f;
+    // FAST: the same outputs-per-tile count and lane phases without a division in the loop
+    const uint32_t n_est = (uint32_t)(((uint64_t)1 << 32) / step);
+    const uint64_t c_est = (uint64_t)n_est * step;                       // <= 2^32
+    uint32_t n0_st = 0, Pl_st = 0;
+    bool taps_ready = false;
+    const unsigned nco_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)w.nco;
+    const bool nco_al = (nco_lds & 0x1fffu) == 0;                       // 8 KiB-aligned table (it sits at LDS offset 0)
     const int woff = (5 + (lane >> 1)) * kRowB + (lane & 1) * 16;       // this lane's LDS write slot
 
     // register prefetch of the next tile's frames (compiler-managed loads: hipcc waits for them with
@@ -282,7 +295,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     // cs16 output of the streaming variant: a tile's four packed dwords are held in registers and
     // stored at the top of the NEXT iteration, right after the wait for the prefetched frames, so
     // that this wait (vmcnt(0)) only ever covers loads and stores issued a whole tile earlier
-    const bool defer = !EDGE && a.out_fmt == IQGPU_FMT_CS16;
+    const bool defer = !EDGE && (FAST || a.out_fmt == IQGPU_FMT_CS16);
     uint32_t pend_val[4] = {0, 0, 0, 0}, pend_idx[4] = {~0u, ~0u, ~0u, ~0u};
     char *pend_base = (char *)a.out;
     STAMP_DECL
@@ -297,8 +310,19 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         if (!EDGE) {
             // consume the prefetched frames first: the wait for them lands here, before the next
             // tile's loads are issued, so those stay in flight across the whole tile
-            unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
-            unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
+            if (FAST) {
+                // cs16 left unnormalised: the 2^-15 lives in this kernel's copy of the NCO table (exact)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        x[c][s].x = (float)(short)(nxt[c].w[s] & 0xffffu);
+                        x[c][s].y = (float)(short)(nxt[c].w[s] >> 16);
+                    }
+            } else {
+                unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
+                unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
+            }
             STAMP(0);
             if (defer) {
 #pragma unroll
@@ -310,7 +334,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 load_chunk<VB>(src, nxt[0]);
                 load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
-            if (a.iq_enable) {
+            if (!FAST && a.iq_enable) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -320,7 +344,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                         x[c][s].y = fmaf(a.iq_phase, re, x[c][s].y);
                     }
             }
-            if (a.nco_mode != 0) {
+            if (FAST || a.nco_mode != 0) {
                 // all eight table lookups first, then the eight complex multiplies: one LDS round
                 // trip per tile instead of eight
                 v2f cs[2][4];
@@ -328,7 +352,16 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 for (int c = 0; c < 2; ++c) {
                     uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) { cs[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
+                    for (int s = 0; s < 4; ++s) {
+                        if (FAST && nco_al) {
+                            // table entry address = LDS base | 8 * rounded top 10 bits (one v_and_or_b32)
+                            const unsigned ad = (((th + (1u << 21)) >> 19) & 0x1ff8u) | nco_lds;
+                            cs[c][s] = *(const __attribute__((address_space(3))) v2f *)(size_t)ad;
+                        } else {
+                            cs[c][s] = nco_phasor2(w.nco, th);
+                        }
+                        th += a.nco_dtheta;
+                    }
                 }
                 // (an empty asm that consumes all eight values: keeps hipcc's scheduler from sinking each
                 // lookup next to its multiply, which costs a full LDS round trip per sample)
@@ -356,13 +389,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                         const int64_t h = (int64_t)a.hist_cap + js;
                         if (h >= 0) v = a.hist_in[h];                 // already fully processed
                     } else if (js < a.frames_in) {
-                        v = unpack_one(a.raw, js, a.in_fmt, a.gain);
-                        if (a.iq_enable) {
+                        if (FAST) { const short *pr = (const short *)a.raw + 2 * js; v = cf2{(float)pr[0], (float)pr[1]}; }
+                        else v = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                        if (!FAST && a.iq_enable) {
                             const float re = v.x;
                             v.x = re * a.iq_magp1;
                             v.y = fmaf(a.iq_phase, re, v.y);
                         }
-                        if (a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
+                        if (FAST || a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
                         const int64_t back = a.frames_in - js;          // 1 .. hist_cap for kept frames
                         if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
                     }
@@ -427,10 +461,16 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 }
                 // (gathered right before use: values written by asm loads must not sit in registers
                 // that the register allocator may copy before the wait below)
-                uint32_t n0 = 0;
+                uint32_t n0, Pl;
+                if (FAST && !EDGE) {
+                    if (!taps_ready) { tap_phase(lane, delta0, step, inv_step, n0_st, Pl_st); taps_ready = true; }
+                    n0 = n0_st; Pl = Pl_st;
+                } else {
+                    tap_phase(lane, delta0, step, inv_step, n0, Pl);
+                }
                 bool hit[4];
                 v2f tp[4][7];
-                issue_taps(w, lane, delta0, step, inv_step, n0, hit, tp);
+                issue_taps(w, Pl, step, hit, tp);
                 STAMP(3);
                 v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
@@ -451,22 +491,37 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 for (int r = 0; r < 4; ++r) {
                     if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
-                        if (a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
+                        if (!FAST && a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
                         if (defer) { pend_val[r] = pack_cs16(cf2{yy.x, yy.y}); pend_idx[r] = kk; }
-                        else pack_store_at(obase, kk, a.out_fmt, cf2{yy.x, yy.y});
+                        else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
                 }
                 pend_base = obase;
             }
             // outputs of this tile, ceil((2^32 - delta0) / step) = floor((2^32 - 1 - delta0) / step) + 1
-            const uint32_t xm = 0xffffffffu - delta0;
-            uint32_t nfl = (uint32_t)((float)xm * inv_step);
-            nfl -= ((uint64_t)nfl * step > (uint64_t)xm) ? 1u : 0u;
-            nfl += ((uint64_t)(nfl + 1) * step <= (uint64_t)xm) ? 1u : 0u;
-            const uint32_t nt = nfl + 1u;
+            uint32_t nt;
+            if (FAST) {
+                // outputs k with delta0 + k step < 2^32: n_est of them, one more iff the (n_est)-th still fits
+                nt = n_est + (((uint64_t)delta0 + c_est) < ((uint64_t)1 << 32) ? 1u : 0u);
+            } else {
+                const uint32_t xm = 0xffffffffu - delta0;
+                uint32_t nfl = (uint32_t)((float)xm * inv_step);
+                nfl -= ((uint64_t)nfl * step > (uint64_t)xm) ? 1u : 0u;
+                nfl += ((uint64_t)(nfl + 1) * step <= (uint64_t)xm) ? 1u : 0u;
+                nt = nfl + 1u;
+            }
             k_tile0 += nt;
-            delta0 = (uint32_t)((uint64_t)delta0 + (uint64_t)nt * step - ((uint64_t)1 << 32));
+            // e = shift of every phase from this tile to the next, |e| < step
+            const int32_t e = (int32_t)((int64_t)((uint64_t)nt * step) - ((int64_t)1 << 32));
+            delta0 = (uint32_t)((int32_t)delta0 + e);
+            if (FAST && !EDGE && taps_ready) {
+                // the lane's first output keeps its index unless its phase leaves [0, step)
+                int32_t pl = (int32_t)Pl_st + e;
+                if (pl < 0) { pl += (int32_t)step; n0_st += 1u; }
+                else if (pl >= (int32_t)step) { pl -= (int32_t)step; n0_st -= 1u; }
+                Pl_st = (uint32_t)pl;
+            }
         }
 
         STAMP(5);
@@ -493,7 +548,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 }
 
 // BPS: bytes per input frame on the vector-load path (2, 4, 8); 0 = no vector path for this format
-template <int BPS>
+//      FAST: cs16 in, unit gain, no iq correction, pre NCO on, no post NCO, cs16 out (the NRSC-5 preset
+//      shape) -- the same arithmetic with every run-time switch resolved at compile time
+template <int BPS, bool FAST>
 __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -510,7 +567,10 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
 
     if (a.nco_mode != 0 || a.pnco_mode != 0) {
         const float sgn = (a.nco_mode < 0 || a.pnco_mode < 0) ? -1.0f : 1.0f;   // mix down: conj(phasor)
-        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x, sgn * v.y}; }
+        // FAST: the cs16 normaliser 2^-15 is folded into the table -- power-of-two scaling commutes with
+        // every rounding of x * (c + j s), so the mixed samples are bit-identical
+        const float scl = FAST ? 1.0f / 32768.0f : 1.0f;
+        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
     }
     // polyphase taps: arm a lives in row a ^ (a >> 5).  The arms that the lanes of one gather touch
     // form an arithmetic progression (mod 256); with plain 56-byte rows that lands 3.3x the cycles of
@@ -539,12 +599,12 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
-        run_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        run_tiles<BPS, true, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
     } else {
         const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
         if (g >= a.w_fast_g1) return;
         const int64_t t0 = g * a.w_tiles_per_wave;
-        if (BPS != 0) run_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
+        if (BPS != 0) run_tiles<BPS, false, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
     }
 }
 
@@ -561,17 +621,20 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_S1(BPS)                                                                                          \
+#define IQGPU_LAUNCH_S1(BPS, FAST)                                                                                    \
     do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                           (int)lds);                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST>,                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL(k_front_s1<BPS>, dim3(grid), dim3(kWThreads), lds, s, a);                                  \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST>), dim3(grid), dim3(kWThreads), lds, s, a);                          \
     } while (0)
-    if (cls == 2) IQGPU_LAUNCH_S1(2);
-    else if (cls == 4) IQGPU_LAUNCH_S1(4);
-    else if (cls == 8) IQGPU_LAUNCH_S1(8);
-    else IQGPU_LAUNCH_S1(0);
+    const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
+                      a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
+    if (cls == 2) IQGPU_LAUNCH_S1(2, false);
+    else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true);
+    else if (cls == 4) IQGPU_LAUNCH_S1(4, false);
+    else if (cls == 8) IQGPU_LAUNCH_S1(8, false);
+    else IQGPU_LAUNCH_S1(0, false);
 #undef IQGPU_LAUNCH_S1
     return hipGetLastError();
 }
