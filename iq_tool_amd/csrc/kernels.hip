@@ -20,6 +20,43 @@ namespace iqgpu {
 
 __device__ __forceinline__ int lvl_hist(const FrontArgs &a, int i) { return (i < a.S) ? 4 * a.m[i] : kArbHist; }
 
+// one half-band decimator stage over a level buffer: dst[j] = 0.5 x[2j+1-2m] + sum_q h[2q+1] x[2j-2q]
+// (taps pre-scaled by 0.5).  M > 0: compile-time semi-length, two accumulator chains.
+template <int M>
+__device__ __forceinline__ void hb_stage(const cf2 *src, cf2 *dst, const float *taps, int n_out, int tid, int m_rt = 0)
+{
+    const int m = M > 0 ? M : m_rt;
+    float h[M > 0 ? 2 * M : 1];
+    if (M > 0) {
+#pragma unroll
+        for (int q = 0; q < 2 * M; ++q) h[q] = taps[q];
+    }
+    for (int jl = tid; jl < n_out; jl += kThreads) {
+        const cf2 d = src[2 * jl + 1 - 2 * m];           // centre tap (delay branch), gain 0.5
+        const cf2 *p = src + 2 * jl;
+        float ar = 0.5f * d.x, ai = 0.5f * d.y;
+        if (M > 0) {
+            cf2 sv[M > 0 ? 2 * M : 1];
+#pragma unroll
+            for (int q = 0; q < 2 * M; ++q) sv[q] = p[-2 * q];
+            float br = 0.0f, bi = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 2 * M; q += 2) {             // same order within each chain as the rolled loop
+                ar = fmaf(h[q], sv[q].x, ar); ai = fmaf(h[q], sv[q].y, ai);
+                br = fmaf(h[q + 1], sv[q + 1].x, br); bi = fmaf(h[q + 1], sv[q + 1].y, bi);
+            }
+            ar += br; ai += bi;
+        } else {
+            for (int q = 0; q < 2 * m; ++q) {                // odd taps h[2q+1] on x[2jl - 2q]
+                const cf2 sv = p[-2 * q];
+                const float h = taps[q];
+                ar = fmaf(h, sv.x, ar); ai = fmaf(h, sv.y, ai);
+            }
+        }
+        dst[jl] = cf2{ar, ai};
+    }
+}
+
 // ============================================================================================
 // k_front
 //   Block b owns tiles [b*tpb, (b+1)*tpb) of kTile input samples (tile boundaries are aligned to
@@ -98,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_front(const FrontArgs a)
         }
 
         // ------------------------------------------------------------ phase 1: pointwise
+#pragma unroll
         for (int c = 0; c < kTile / 1024; ++c) {
             const int l = c * 1024 + 4 * tid;
             const int64_t j = j0 + l;
@@ -217,16 +255,13 @@ __global__ __launch_bounds__(kThreads) void k_front(const FrontArgs a)
             const cf2 *src = s_lvl + a.lvl_off[i] + 4 * m;
             cf2 *dst = s_lvl + a.lvl_off[i + 1] + lvl_hist(a, i + 1);
             const float *taps = s_hb + a.tap_off[i];
-            for (int jl = tid; jl < n_out; jl += kThreads) {
-                const cf2 d = src[2 * jl + 1 - 2 * m];       // centre tap (delay branch), gain 0.5
-                float ar = 0.5f * d.x, ai = 0.5f * d.y;
-                const cf2 *p = src + 2 * jl;
-                for (int q = 0; q < 2 * m; ++q) {            // odd taps h[2q+1] on x[2jl - 2q]
-                    const cf2 sv = p[-2 * q];
-                    const float h = taps[q];
-                    ar = fmaf(h, sv.x, ar); ai = fmaf(h, sv.y, ai);
-                }
-                dst[jl] = cf2{ar, ai};
+            // liquid's designs at 60 dB use m = 10, 5, 3, 3, ...: those get fully unrolled bodies (all window
+            // reads in flight at once); any other semi-length runs the rolled loop
+            switch (m) {
+            case 3:  hb_stage<3>(src, dst, a.hb_taps + a.tap_off[i], n_out, tid); break;    // uniform global reads:
+            case 5:  hb_stage<5>(src, dst, a.hb_taps + a.tap_off[i], n_out, tid); break;    // s_load, taps in SGPRs
+            case 10: hb_stage<10>(src, dst, a.hb_taps + a.tap_off[i], n_out, tid); break;
+            default: hb_stage<0>(src, dst, taps, n_out, tid, m); break;
             }
             __syncthreads();
         }
