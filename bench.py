@@ -185,7 +185,7 @@ def main():
                        "sharding": "independent stream per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic_bytes if args.log2_frames == 28 else None,
-                         "kernel": "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
+                         "kernel": "k_front_s1<4, true>" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
         }

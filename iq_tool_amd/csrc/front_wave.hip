@@ -279,17 +279,28 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     const uint64_t c_est = (uint64_t)n_est * step;                       // <= 2^32
     uint32_t n0_st = 0, Pl_st = 0;
     bool taps_ready = false;
-    const unsigned nco_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)w.nco;
-    const bool nco_al = (nco_lds & 0x1fffu) == 0;                       // 8 KiB-aligned table (it sits at LDS offset 0)
     const int woff = (5 + (lane >> 1)) * kRowB + (lane & 1) * 16;       // this lane's LDS write slot
 
     // register prefetch of the next tile's frames (compiler-managed loads: hipcc waits for them with
     // vmcnt(0) at the top of the next iteration, a whole tile after they were issued)
     RawChunk nxt[2];
+    // ... and of its eight NCO phasors: the table lookups depend on the stream position only, so they are
+    // issued a tile ahead too and their LDS round trip never sits on the tile's critical path
+    const bool nco_on = !EDGE && (FAST || a.nco_mode != 0);
+    v2f cs_n[2][4];
+    auto nco_lookup = [&](int64_t tile_first) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t th = a.nco_theta0 + ((uint32_t)tile_first + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cs_n[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
+        }
+    };
     if (!EDGE) {
         const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * VB + 4 * VB * lane;
         load_chunk<VB>(src, nxt[0]);
         load_chunk<VB>(src + 256 * VB, nxt[1]);
+        if (nco_on) nco_lookup(t_begin * kWTile);
     }
 
     // cs16 output of the streaming variant: a tile's four packed dwords are held in registers and
@@ -344,34 +355,13 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                         x[c][s].y = fmaf(a.iq_phase, re, x[c][s].y);
                     }
             }
-            if (FAST || a.nco_mode != 0) {
-                // all eight table lookups first, then the eight complex multiplies: one LDS round
-                // trip per tile instead of eight
-                v2f cs[2][4];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        if (FAST && nco_al) {
-                            // table entry address = LDS base | 8 * rounded top 10 bits (one v_and_or_b32)
-                            const unsigned ad = (((th + (1u << 21)) >> 19) & 0x1ff8u) | nco_lds;
-                            cs[c][s] = *(const __attribute__((address_space(3))) v2f *)(size_t)ad;
-                        } else {
-                            cs[c][s] = nco_phasor2(w.nco, th);
-                        }
-                        th += a.nco_dtheta;
-                    }
-                }
-                // (an empty asm that consumes all eight values: keeps hipcc's scheduler from sinking each
-                // lookup next to its multiply, which costs a full LDS round trip per sample)
-                asm volatile("" : "+v"(cs[0][0]), "+v"(cs[0][1]), "+v"(cs[0][2]), "+v"(cs[0][3]),
-                                  "+v"(cs[1][0]), "+v"(cs[1][1]), "+v"(cs[1][2]), "+v"(cs[1][3]));
+            if (nco_on) {
+                // the eight phasors were looked up while the previous tile was in flight (below)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, cs[c][s]);
+                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, cs_n[c][s]);
                         x[c][s] = cf2{y.x, y.y};
                     }
             }
@@ -412,6 +402,13 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             *(float4 *)(XO + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
         }
         __builtin_amdgcn_wave_barrier();
+        // the rows that become the next tile's history are read back NOW (queued right behind the writes)
+        // and stored at the end of the tile: by then the data is long there, so the slide costs no LDS
+        // round trip of its own
+        float sl_e = 0.f, sl_o = 0.f, sl_h = 0.f;
+        if (lane < 60) { sl_e = *(const float *)(XE + 64 * kRowB + lane * 4); sl_o = *(const float *)(XO + 64 * kRowB + lane * 4); }
+        if (nco_on) nco_lookup(i0 + kWTile);
+        __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
 
         // ------------------------------------------------------------ half-band: 4 outputs per lane
@@ -442,6 +439,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             *(float4 *)(ph + 16) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
         }
         __builtin_amdgcn_wave_barrier();
+        if (lane < 48) sl_h = *(const float *)(HB + 64 * kRowB + lane * 4);
+        __builtin_amdgcn_sched_barrier(0);
 
         // ------------------------------------------------------------ polyphase + pack
         if (emit) {
@@ -529,12 +528,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         {
             // the last 5 (XE, XO) / 4 (HB) rows become the history rows of the next tile.  One dword per
             // lane: a ds_write_b32 costs 4 LDS cycles whatever the lane count, a ds_write_b128 13.
-            float ve = 0.f, vo = 0.f, vh = 0.f;
-            if (lane < 60) { ve = *(const float *)(XE + 64 * kRowB + lane * 4); vo = *(const float *)(XO + 64 * kRowB + lane * 4); }
-            if (lane < 48) vh = *(const float *)(HB + 64 * kRowB + lane * 4);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 60) { *(float *)(XE + lane * 4) = ve; *(float *)(XO + lane * 4) = vo; }
-            if (lane < 48) *(float *)(HB + lane * 4) = vh;
+            if (lane < 60) { *(float *)(XE + lane * 4) = sl_e; *(float *)(XO + lane * 4) = sl_o; }
+            if (lane < 48) *(float *)(HB + lane * 4) = sl_h;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
