@@ -132,7 +132,7 @@ typedef struct {
 } iqgpu_chain_info;
 
 /* Per-kernel device time accumulated by HIP events on the chain's stream (profiling mode only). */
-enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_AGC = 5, IQGPU_K_COUNT = 8 };
+enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_AGC = 5, IQGPU_K_CASCADE = 6, IQGPU_K_COUNT = 8 };
 typedef struct {
     uint64_t launches[IQGPU_K_COUNT];
     double   ms[IQGPU_K_COUNT];

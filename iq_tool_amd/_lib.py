@@ -11,7 +11,7 @@ FMT_NAME = {v: k for k, v in FMT.items()}
 BYTES_PER_FRAME = {8: 2, 9: 2, 10: 4, 11: 4, 16: 4, 12: 6, 13: 8, 14: 8, 15: 8}
 FILTER = dict(none=0, lowpass=1, highpass=2, passband=3, stopband=4)
 FILTER_IMPL = dict(auto=0, fir=1, fft=2)
-K_NAMES = ("dc_prefix", "dc_scan", "front", "filter", "move")
+K_NAMES = ("dc_prefix", "dc_scan", "front", "filter", "move", "agc", "cascade")
 
 ERRORS = {0: "OK", -1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ERATIO", -5: "EFORMAT", -6: "ESHIFT",
           -7: "EFILTER", -8: "ECAPACITY", -9: "EHIP", -10: "EUNSUPPORTED"}

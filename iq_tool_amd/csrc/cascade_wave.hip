@@ -1,0 +1,310 @@
+// cascade_wave.hip -- k_cascade: the leading half-band stages of a multi-stage decimation
+// (msresamp2, SPEC B.6) as a wave-autonomous kernel, for chains with S >= 2 stages:
+//
+//   raw -> unpack/gain -> [iq correct] -> [pre NCO] -> half-band stages 0 .. K-1  -> cf32 (HBM)
+//
+// K = S - 1.  The stream it writes (rate / 2^K) is then consumed by k_front_s1 (front_wave.hip) as a
+// one-stage chain: last half-band (m = 10) -> 256-arm polyphase -> [post NCO] -> pack.  The extra
+// round trip through HBM is 16 bytes per 2^K input frames; what it buys is that every stage runs in
+// the structure of the headline kernel instead of the workgroup-tiled k_front.
+//
+// Mapping (as in front_wave.hip): one wavefront owns a run of 512-frame tiles, frames arrive by
+// register-prefetched 16-byte loads, every stage keeps its input split into even / odd streams in
+// rows of 4 cf32 (48-byte pitch) in the wave's private LDS slice, a lane owns 4 consecutive
+// outputs of a stage.  Stage k sees 512 >> k samples per tile, so 64 >> k lanes work on it; the
+// narrow late stages cost little next to stage 0 and in exchange there is no multi-rate cadence
+// and no alignment rule beyond the 2^K input group.  Semi-lengths 3 and 5 (what liquid designs
+// for every stage but the last at 60 dB) are compiled in; anything else stays on k_front.
+#include <hip/hip_runtime.h>
+
+#include "../../include/iqgpu.h"
+#include "dsp_device.hpp"
+#include "kernels.hpp"
+#include "wave_common.hpp"
+
+namespace iqgpu {
+
+__host__ __device__ constexpr int casc_hist_rows(int m) { return (2 * m - 1 + 3) / 4; }   // older rows a lane reads
+
+// One stage: 4 outputs per lane for lanes < n_act.
+//   out j = 0.5 O[j - M] + sum_q h[q] E[j - q], q < 2M   (E[i] = x[2i], O[i] = x[2i+1]; h pre-scaled by 0.5)
+// XE / XO: the stage's input rows; row (H + l) holds samples 4l .. 4l+3 of the tile, rows 0 .. H-1 the history.
+template <int M>
+__device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int lane, const float *taps_sgpr, v2f y[4])
+{
+    constexpr int H = casc_hist_rows(M);
+    v2f E[4 * (H + 1)];
+    const char *we = XE + lane * kRowB;
+#pragma unroll
+    for (int r = 0; r <= H; ++r) {
+        const float4 v0 = ld4(we + r * kRowB), v1 = ld4(we + r * kRowB + 16);
+        E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
+        E[4 * r + 2] = v2f{v1.x, v1.y}; E[4 * r + 3] = v2f{v1.z, v1.w};
+    }
+    // centre taps: O[4l + i - M] = window index 4H + i - M  ->  rows r0, r0 + 1
+    constexpr int c0 = 4 * H - M;                     // window index of i = 0
+    constexpr int r0 = c0 / 4;
+    v2f O[8];
+    {
+        const char *wo = XO + (lane + r0) * kRowB;
+        const float4 v0 = ld4(wo), v1 = ld4(wo + 16);
+        O[0] = v2f{v0.x, v0.y}; O[1] = v2f{v0.z, v0.w}; O[2] = v2f{v1.x, v1.y}; O[3] = v2f{v1.z, v1.w};
+        if ((c0 & 3) != 0) {
+            const float4 u0 = ld4(wo + kRowB), u1 = ld4(wo + kRowB + 16);
+            O[4] = v2f{u0.x, u0.y}; O[5] = v2f{u0.z, u0.w}; O[6] = v2f{u1.x, u1.y}; O[7] = v2f{u1.z, u1.w};
+        }
+    }
+    const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v2f o = O[(c0 & 3) + i];
+        y[i] = v2f{0.5f * o.x, 0.5f * o.y};
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < M; ++q2) {
+        const v2f tp = hbp[q2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, E[4 * H + i - 2 * q2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[4 * H + i - 2 * q2 - 1]);
+    }
+}
+
+struct CascLds { char *XE[kCascMaxK], *XO[kCascMaxK]; const cf2 *nco; };
+
+template <int BPS, bool EDGE>
+__device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w, const int lane,
+                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1)
+{
+    constexpr int VB = BPS ? BPS : 4;
+    const int K = a.casc_K;
+    const bool unit_gain = a.gain == 1.0f;
+    char *XE0 = w.XE[0], *XO0 = w.XO[0];
+    const int H0 = casc_hist_rows(a.m[0]);
+    const int woff = (H0 + (lane >> 1)) * kRowB + (lane & 1) * 16;     // this lane's write slot in stage 0
+
+    RawChunk nxt[2];
+    const bool nco_on = !EDGE && a.nco_mode != 0;
+    v2f cs_n[2][4];
+    auto nco_lookup = [&](int64_t tile_first) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t th = a.nco_theta0 + ((uint32_t)tile_first + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cs_n[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
+        }
+    };
+    if (!EDGE) {
+        const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * VB + 4 * VB * lane;
+        load_chunk<VB>(src, nxt[0]);
+        load_chunk<VB>(src + 256 * VB, nxt[1]);
+        if (nco_on) nco_lookup(t_begin * kWTile);
+    }
+
+    for (int64_t t = t_begin; t < t_emit1; ++t) {
+        const int64_t i0 = t * kWTile;
+        const int64_t j0 = i0 - a.rem0;
+        const bool emit = t >= t_emit0;
+
+        // ------------------------------------------------------------ pointwise -> stage 0 rows
+        cf2 x[2][4];
+        if (!EDGE) {
+            unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
+            unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
+            {
+                const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
+                load_chunk<VB>(src, nxt[0]);
+                load_chunk<VB>(src + 256 * VB, nxt[1]);
+            }
+            if (a.iq_enable) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float re = x[c][s].x;
+                        x[c][s].x = re * a.iq_magp1;
+                        x[c][s].y = fmaf(a.iq_phase, re, x[c][s].y);
+                    }
+            }
+            if (nco_on) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, cs_n[c][s]);
+                        x[c][s] = cf2{y.x, y.y};
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int l4 = 256 * c + 4 * lane;
+                const int64_t j = j0 + l4;
+                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t js = j + s;
+                    cf2 v{0.0f, 0.0f};
+                    if (js < 0) {
+                        const int64_t h = (int64_t)a.hist_cap + js;
+                        if (h >= 0) v = a.hist_in[h];                 // already fully processed
+                    } else if (js < a.frames_in) {
+                        v = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                        if (a.iq_enable) {
+                            const float re = v.x;
+                            v.x = re * a.iq_magp1;
+                            v.y = fmaf(a.iq_phase, re, v.y);
+                        }
+                        if (a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
+                        const int64_t back = a.frames_in - js;          // 1 .. hist_cap for kept frames
+                        if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
+                    }
+                    x[c][s] = v;
+                    th += a.nco_dtheta;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int off = woff + 32 * c * kRowB;
+            *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
+            *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nco_on) nco_lookup(i0 + kWTile);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ------------------------------------------------------------ the stages
+#pragma unroll
+        for (int k = 0; k < kCascMaxK; ++k) {
+            if (k < K) {
+                const int n_act = 64 >> k;                        // lanes with outputs in this stage
+                const int m = a.m[k];
+                v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+                if (lane < n_act) {
+                    if (m == 3) casc_stage<3>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y);
+                    else        casc_stage<5>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y);
+                }
+                // slide this stage's history: its last H rows become rows 0 .. H-1 (one dword per lane)
+                const int Hk = casc_hist_rows(m), rows = 64 >> k;
+                float se = 0.f, so = 0.f;
+                if (lane < 12 * Hk) { se = *(const float *)(w.XE[k] + rows * kRowB + lane * 4); so = *(const float *)(w.XO[k] + rows * kRowB + lane * 4); }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 12 * Hk) { *(float *)(w.XE[k] + lane * 4) = se; *(float *)(w.XO[k] + lane * 4) = so; }
+                if (k + 1 < K) {
+                    // outputs 4l .. 4l+3 -> even / odd rows of the next stage
+                    if (lane < n_act) {
+                        const int Hn = casc_hist_rows(a.m[k + 1]);
+                        const int off = (Hn + (lane >> 1)) * kRowB + (lane & 1) * 16;
+                        *(float4 *)(w.XE[k + 1] + off) = make_float4(y[0].x, y[0].y, y[2].x, y[2].y);
+                        *(float4 *)(w.XO[k + 1] + off) = make_float4(y[1].x, y[1].y, y[3].x, y[3].y);
+                    }
+                } else if (emit && lane < n_act) {
+                    // the last stage's outputs go to memory: 32 contiguous bytes per lane
+                    const int64_t o = ((i0 >> K) + 4 * lane);
+                    if (!EDGE || o + 4 <= a.casc_n_out) {
+                        float4 *dst = (float4 *)(a.casc_out + o);
+                        dst[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+                        dst[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (o + i < a.casc_n_out) a.casc_out[o + i] = cf2{y[i].x, y[i].y};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+size_t cascade_wave_lds(const FrontArgs &a)
+{
+    size_t b = 0;
+    for (int k = 0; k < a.casc_K; ++k) b += 2u * (size_t)(casc_hist_rows(a.m[k]) + (64 >> k) + 1) * kRowB;
+    return b;
+}
+
+template <int BPS>
+__global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cf2 *s_nco = (cf2 *)smem;
+    CascLds w;
+    w.nco = s_nco;
+    {
+        char *p = (char *)smem + 1024 * 8 + wave * a.casc_wave_lds;
+        char *p0 = p;
+#pragma unroll
+        for (int k = 0; k < kCascMaxK; ++k) {
+            w.XE[k] = p; w.XO[k] = p;
+            if (k < a.casc_K) {
+                const int rows = casc_hist_rows(a.m[k]) + (64 >> k) + 1;
+                w.XE[k] = p; w.XO[k] = p + rows * kRowB;
+                p += 2 * rows * kRowB;
+            }
+        }
+        for (int i = lane; i < a.casc_wave_lds / 16; i += 64) ((float4 *)p0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (a.nco_mode != 0) {
+        const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;          // mix down: conj(phasor)
+        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x, sgn * v.y}; }
+    }
+    __syncthreads();
+
+    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+    if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
+        const int keep = a.hist_cap - (int)a.frames_in;
+        for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
+    }
+    if (gw < a.w_n_edge) {
+        int64_t t0, t1;
+        if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
+        else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        casc_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+    } else {
+        const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
+        if (g >= a.w_fast_g1) return;
+        const int64_t t0 = g * a.w_tiles_per_wave;
+        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
+    }
+}
+
+// true when the chain's leading stages can run here (the caller still checks S >= 2 and no dc blocker)
+bool cascade_supported(const int *m_run_order, int S)
+{
+    if (S < 2 || S - 1 > kCascMaxK) return false;
+    for (int k = 0; k < S - 1; ++k) if (m_run_order[k] != 3 && m_run_order[k] != 5) return false;
+    return m_run_order[S - 1] == 10;
+}
+
+hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
+{
+    const size_t lds = 1024 * 8 + (size_t)kWaves * a.casc_wave_lds;
+    const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
+    const unsigned grid = (unsigned)((n_items + kWaves - 1) / kWaves);
+    if (grid == 0) return hipSuccess;
+    int cls;
+    switch (a.in_fmt) {
+    case IQGPU_FMT_CS8: case IQGPU_FMT_CU8: cls = 2; break;
+    case IQGPU_FMT_CS16: case IQGPU_FMT_CU16: case IQGPU_FMT_SC16Q11: cls = 4; break;
+    case IQGPU_FMT_CF32: cls = 8; break;
+    default: cls = 0; break;
+    }
+#define IQGPU_LAUNCH_CASC(BPS)                                                                                         \
+    do {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute((const void *)k_cascade<BPS>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                           (int)lds);                                                                 \
+        if (e != hipSuccess) return e;                                                                                \
+        hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(kWThreads), lds, s, a);                                   \
+    } while (0)
+    if (cls == 2) IQGPU_LAUNCH_CASC(2);
+    else if (cls == 4) IQGPU_LAUNCH_CASC(4);
+    else if (cls == 8) IQGPU_LAUNCH_CASC(8);
+    else IQGPU_LAUNCH_CASC(0);
+#undef IQGPU_LAUNCH_CASC
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

@@ -123,6 +123,10 @@ struct iqgpu_chain {
     cf2 *d_nco_tab = nullptr; float *d_arb = nullptr; float *d_hb = nullptr; cf2 *d_ftaps = nullptr;
     cf2 *d_hfreq = nullptr, *d_twiddle = nullptr; int fft_log2n = 0, fft_threads = 0;   // overlap-save path of FFT-kind filters
     cf2 *d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
+    // S >= 2 without a dc blocker: k_cascade (stages 0 .. S-2) -> mid -> k_front_s1 (last stage + polyphase)
+    bool cascade = false; int hist2_cap = 0, casc_warm = 1;
+    cf2 *d_hist2[2] = {nullptr, nullptr}; int hist2_cur = 0;
+    DevBuf mid;
     cd2 *d_dc_state = nullptr;
     void *d_sink = nullptr;      // store sink of k_front_s1
     DevBuf dc_agg, dc_carry;
@@ -194,6 +198,8 @@ static void free_device_state(iqgpu_chain *c)
     c->abuf.release(); c->agc_peak.release(); c->agc_gain.release();
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
+    for (int i = 0; i < 2; ++i) if (c->d_hist2[i]) (void)hipFree(c->d_hist2[i]);
+    c->mid.release();
     if (c->d_dc_state) (void)hipFree(c->d_dc_state);
     if (c->d_sink) (void)hipFree(c->d_sink);
     c->dc_agg.release(); c->dc_carry.release();
@@ -279,6 +285,17 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     c->S = c->decim ? c->rp.S : 0;
     c->D = 1 << c->S;
     c->TG = kTile >> c->S;
+    if (c->decim && c->S >= 2 && !c->dc && !getenv("IQGPU_FORCE_GENERIC")) {
+        int mm[kMaxS];
+        for (int i = 0; i < c->S; ++i) mm[i] = c->rp.stages[(size_t)i].m;
+        c->cascade = cascade_supported(mm, c->S);
+        if (c->cascade) {
+            uint64_t h = 0;                                   // input history the first S-1 stages need
+            for (int k = c->S - 2; k >= 0; --k) h = 2 * h + 4u * (unsigned)mm[k];
+            c->casc_warm = (int)((h + kWTile - 1) / kWTile); if (c->casc_warm < 1) c->casc_warm = 1;
+            c->hist2_cap = kTile + 2;                         // last stage: 66 samples of history, one warm-up tile
+        }
+    }
     // ---- output AGC (src/agc.c:21-83, src/config.c:306-330) ----
     if (d->agc_enable) {
         if (d->agc_profile != IQGPU_AGC_DIGITAL)
@@ -379,6 +396,10 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             for (int i = 0; i < 2; ++i) {
                 CREATE_TRY(hipMalloc((void **)&c->d_hist[i], (size_t)c->hist_cap * sizeof(cf2)));
                 CREATE_TRY(hipMemset(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2)));
+                if (c->cascade) {
+                    CREATE_TRY(hipMalloc((void **)&c->d_hist2[i], (size_t)c->hist2_cap * sizeof(cf2)));
+                    CREATE_TRY(hipMemset(c->d_hist2[i], 0, (size_t)c->hist2_cap * sizeof(cf2)));
+                }
             }
         }
         if (c->agc) {
@@ -761,9 +782,65 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
             a.sink = c->d_sink;
         }
-        KernelTimer kt(c, IQGPU_K_FRONT);
-        if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
-        else HIP_TRY(launch_front(a, n_blocks, c->stream));
+        // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
+        auto tiles_per_wave = [&](int64_t w_tiles) {
+            int64_t tpw64;
+            if (c->auto_block) {
+                const int64_t slots = (int64_t)c->n_cu * kWaves;
+                tpw64 = (w_tiles + slots - 1) / slots;
+                if (tpw64 < 16) tpw64 = 16;
+            } else {
+                tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
+            }
+            if (tpw64 < 1) tpw64 = 1;
+            if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
+            return (int)tpw64;
+        };
+        const bool casc = c->cascade && !c->force_generic;
+        if (casc) {
+            // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
+            const int K = c->S - 1;
+            const int rem_k = c->rem & ((1 << K) - 1), rem_1 = c->rem >> K;
+            const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> K;
+            int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
+            FrontArgs a1 = a;
+            a1.rem0 = rem_k;
+            a1.nco_theta0 = c->nco_theta - (uint32_t)rem_k * c->nco_dtheta;
+            a1.casc_K = K;
+            for (int k = 0; k < K; ++k) {
+                const std::vector<float> &br = c->rp.stages[(size_t)k].branch;
+                for (size_t q = 0; q < 12; ++q) a1.casc_taps[k][q] = q < br.size() ? 0.5f * br[q] : 0.0f;
+            }
+            a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
+            a1.casc_wave_lds = (int)cascade_wave_lds(a1);
+            a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
+            a1.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + kWTile - 1) / kWTile;
+            plan_front_s1(a1, tiles_per_wave(a1.w_total_tiles), c->casc_warm, 4);
+            { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
+            // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
+            if (n_mid > 0) {
+                FrontArgs a2{};
+                a2.raw = c->mid.p; a2.hist_in = c->d_hist2[c->hist2_cur]; a2.hist_out = c->d_hist2[c->hist2_cur ^ 1];
+                a2.frames_in = n_mid; a2.hist_cap = c->hist2_cap; a2.rem0 = rem_1;
+                a2.in_fmt = IQGPU_FMT_CF32; a2.gain = 1.0f; a2.raw_aligned = 1;
+                a2.nco_tab = c->d_nco_tab;
+                a2.mode = 1; a2.S = 1; a2.m[0] = c->rp.stages[(size_t)K].m;
+                a2.arb_table = c->d_arb; a2.step = c->rp.step; a2.phi0 = c->phi;
+                a2.n_groups = p.n_groups; a2.n_out = p.n_res;
+                a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
+                a2.out_fmt = a.out_fmt; a2.out = a.out;
+                a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
+                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles), 1, 4);
+                for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
+                a2.sink = c->d_sink;
+                { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
+                c->hist2_cur ^= 1;
+            }
+        } else {
+            KernelTimer kt(c, IQGPU_K_FRONT);
+            if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
+            else HIP_TRY(launch_front(a, n_blocks, c->stream));
+        }
     }
     if (c->decim) c->hist_cur ^= 1;
 
@@ -885,7 +962,10 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     }
     if (c->late) HIP_TRY(hipMemsetAsync(c->ibuf[c->icur].p, 0, (size_t)c->ihist * sizeof(cf2), c->stream));
     if (c->decim)
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2), c->stream));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(cf2), c->stream));
+            if (c->cascade) HIP_TRY(hipMemsetAsync(c->d_hist2[i], 0, (size_t)c->hist2_cap * sizeof(cf2), c->stream));
+        }
     if (c->fp.enabled) {
         // the filter object's history is cleared; the FFT remainder is NOT (src/filter.c:417-436):
         // pending samples stay queued in front of the new stream

@@ -77,6 +77,12 @@ struct FrontArgs {
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
     void       *sink;         // 64 KiB scratch that absorbs the stores of lanes without an output
+    // k_cascade (cascade_wave.hip): the first casc_K stages of an S >= 2 chain, cf32 out
+    int32_t     casc_K;
+    int32_t     casc_wave_lds;          // bytes of LDS per wavefront
+    float       casc_taps[4][12];       // branch taps of stages 0 .. K-1 (pre-scaled by 0.5), 2m <= 10 each
+    cf2        *casc_out;               // intermediate stream, index 0 = first sample this call completes
+    int64_t     casc_n_out;             // (rem0 + frames_in) >> K
     // post-resample NCO
     int32_t     pnco_mode;
     uint32_t    pnco_theta0, pnco_dtheta;
@@ -87,6 +93,11 @@ struct FrontArgs {
 
 size_t front_lds_bytes(const FrontArgs &a);
 hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
+// leading stages of a multi-stage decimation as a wave-autonomous kernel (cascade_wave.hip)
+constexpr int kCascMaxK = 4;
+bool cascade_supported(const int *m_run_order, int S);
+size_t cascade_wave_lds(const FrontArgs &a);
+hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);

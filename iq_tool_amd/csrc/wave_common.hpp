@@ -1,0 +1,126 @@
+// wave_common.hpp -- device helpers shared by the wave-autonomous kernels (front_wave.hip, cascade_wave.hip):
+// register-prefetched raw loads, the unpack of prefetched words, packed-f32 primitives, NCO lookups.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/iqgpu.h"
+#include "dsp_device.hpp"
+#include "kernels.hpp"
+
+namespace iqgpu {
+
+constexpr int kRowB = 48;                                   // LDS row: 4 cf32 + 16 B pad (odd number of 16-byte slots)
+
+struct RawChunk { uint32_t w[8]; };
+
+template <int BPS>
+__device__ __forceinline__ void load_chunk(const char *p, RawChunk &r)
+{
+    if (BPS == 4) {
+        const uint4 v = *(const uint4 *)p;
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if (BPS == 2) {
+        const uint2 v = *(const uint2 *)p;
+        r.w[0] = v.x; r.w[1] = v.y;
+    } else {
+        const uint4 v0 = *(const uint4 *)p, v1 = *(const uint4 *)(p + 16);
+        r.w[0] = v0.x; r.w[1] = v0.y; r.w[2] = v0.z; r.w[3] = v0.w;
+        r.w[4] = v1.x; r.w[5] = v1.y; r.w[6] = v1.z; r.w[7] = v1.w;
+    }
+}
+
+// four frames from prefetched words; arithmetic identical to unpack_one (src/sample_convert.c:75-96).
+// unit_gain skips the multiply by 1.0f (exact).
+template <int BPS>
+__device__ __forceinline__ void unpack_chunk(const RawChunk &r, int fmt, float gain, bool unit_gain, cf2 x[4])
+{
+    if (BPS == 4) {
+        if (fmt == IQGPU_FMT_CU16) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                x[s].x = ((float)(r.w[s] & 0xffffu) - 32767.5f) * (1.0f / 32768.0f);
+                x[s].y = ((float)(r.w[s] >> 16) - 32767.5f) * (1.0f / 32768.0f);
+            }
+        } else {
+            const float norm = (fmt == IQGPU_FMT_CS16) ? 1.0f / 32768.0f : 1.0f / 2048.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                x[s].x = (float)(short)(r.w[s] & 0xffffu) * norm;
+                x[s].y = (float)(short)(r.w[s] >> 16) * norm;
+            }
+        }
+    } else if (BPS == 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned h = r.w[s >> 1] >> ((s & 1) * 16);
+            if (fmt == IQGPU_FMT_CU8) {
+                x[s].x = ((float)(h & 0xffu) - 127.5f) * (1.0f / 128.0f);
+                x[s].y = ((float)((h >> 8) & 0xffu) - 127.5f) * (1.0f / 128.0f);
+            } else {
+                x[s].x = (float)(signed char)(h & 0xffu) * (1.0f / 128.0f);
+                x[s].y = (float)(signed char)((h >> 8) & 0xffu) * (1.0f / 128.0f);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            x[s].x = __uint_as_float(r.w[2 * s]);
+            x[s].y = __uint_as_float(r.w[2 * s + 1]);
+        }
+    }
+    if (!unit_gain) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { x[s].x *= gain; x[s].y *= gain; }
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const char *p) { return *(const float4 *)p; }
+
+// ---- packed-f32 primitives (VOP3P).  hipcc's SLP vectoriser does find v_pk_fma_f32 on its own but
+// pays for every scalar broadcast with v_mov pairs and serialises the polyphase chains; the three
+// hot inner products are therefore written with explicit op_sel forms (this file is compiled with
+// -fno-slp-vectorize).  A v2f is one {re, im} sample in an aligned VGPR pair.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc += t.lo * x   /   acc += t.hi * x      (t: a pair of real taps, x: {re, im})
+__device__ __forceinline__ void pk_fma_lo(v2f &acc, v2f t, v2f x)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_hi(v2f &acc, v2f t, v2f x)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(t), "v"(x));
+}
+// the same with the tap pair in SGPRs (wave-uniform half-band taps)
+__device__ __forceinline__ void pk_fma_lo_s(v2f &acc, v2f t, v2f x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_hi_s(v2f &acc, v2f t, v2f x)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+// x * (c + j s) with cs = {c, s}:  t = {-xi s, xi c};  y = {xr c, xr s} + t
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f cs)
+{
+    v2f t, y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(x), "v"(cs));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y) : "v"(x), "v"(cs), "v"(t));
+    return y;
+}
+__device__ __forceinline__ v2f nco_phasor2(const cf2 *tab, uint32_t theta)
+{
+    return *(const v2f *)(tab + ((theta + (1u << 21)) >> 22));
+}
+
+// y = x * (c + j s); the sign of s for mix-down is folded into the LDS copy of the table
+__device__ __forceinline__ cf2 cmul_tab(cf2 x, cf2 cs)
+{
+    cf2 y;
+    y.x = fmaf(x.x, cs.x, -(x.y * cs.y));
+    y.y = fmaf(x.x, cs.y, x.y * cs.x);
+    return y;
+}
+
+} // namespace iqgpu

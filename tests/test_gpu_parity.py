@@ -377,6 +377,46 @@ def test_fft_overlap_save_kernel_agrees_with_direct_form(gpu, oracle, monkeypatc
 
 
 # --------------------------------------------------------------------------------------------
+# S >= 2 chains without a dc blocker: k_cascade (stages 0 .. S-2) + k_front_s1 (last stage)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt_in,rate_in,rate_out,S", [
+    ("cs16", 10e6, 2.4e6, 2), ("cu8", 2.4e6, 250e3, 3), ("cs8", 8e6, 390e3, 4),
+    ("cu8", 61.44e6, 1488375.0, 5), ("cf32", 2.0e6, 300e3, 2), ("cu16", 20e6, 1.3e6, 3)])
+def test_cascade_chain_matches_oracle_and_generic(gpu, oracle, monkeypatch, fmt_in, rate_in, rate_out, S):
+    n = 700001
+    raw = synth.raw_stream(n, rate_in, 41, fmt_in)
+    kw = dict(in_format=fmt_in, out_format="cf32", input_rate_hz=rate_in, target_rate_hz=rate_out,
+              shift_hz=-0.07 * rate_in, iq_correct=True, iq_mag=0.02, iq_phase=0.01, gain=0.8)
+    ch = gpu.Chain(**kw)
+    assert ch.info().num_halfband_stages == S
+    want = cf(run_oracle(oracle, raw, **kw))
+    bpf = ch.in_bytes
+    rb = np.ascontiguousarray(raw).view(np.uint8)
+    outs, pos = [], 0
+    for k in (1, 3, 300000, 7, 131072, n - 431083):
+        outs.append(ch.process(rb[pos * bpf:(pos + k) * bpf])); pos += k
+    assert pos == n
+    got = cf(np.concatenate(outs))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = cf(run_gpu(gpu, raw, **kw))
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert slow.size == got.size and np.abs(slow - got).max() <= 4e-6
+    ch.reset()
+    assert np.abs(cf(ch.process(raw)) - want).max() <= TOL
+
+
+def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
+    n = 1 << 20
+    raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0,
+              shift_hz=150e3, shift_after_resample=True)
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, splits=[n // 2 + 3, n - n // 2 - 3], **kw)
+    int_close(got, want)
+
+
+# --------------------------------------------------------------------------------------------
 # output AGC, "digital" profile
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("chunk,splits", [(1000, None), (1000, [7000, 1000, 50000, 62000]), (16384, None), (250, [250 * 100, 250 * 380])])
