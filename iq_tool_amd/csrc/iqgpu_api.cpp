@@ -687,16 +687,18 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     if (c->dc) {
         int rc = c->dc_agg.ensure((size_t)n_blocks * sizeof(cf2)); if (rc) return rc;
         rc = c->dc_carry.ensure((size_t)n_blocks * sizeof(cd2)); if (rc) return rc;
+        DcGeom dg{};
+        dg.mode = 0; dg.n_seg = n_blocks; dg.frames_in = (int64_t)frames_in;
+        dg.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
+        dg.seg_len = (int64_t)c->tiles_per_block * kTile;
         DcPrefixArgs pa{};
-        pa.raw = d_raw_in; pa.frames_in = (int64_t)frames_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
-        pa.c = c->dc_c; pa.logc = c->dc_logc;
-        pa.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
-        pa.seg_len = (int64_t)c->tiles_per_block * kTile;
-        pa.n_seg = n_blocks; pa.agg = (cf2 *)c->dc_agg.p;
+        pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
+        pa.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        pa.c = c->dc_c; pa.logc = c->dc_logc; pa.geom = dg; pa.agg = (cf2 *)c->dc_agg.p;
         { KernelTimer kt(c, IQGPU_K_DC_PREFIX); HIP_TRY(launch_dc_prefix(pa, c->stream)); }
         DcScanArgs sa{};
         sa.agg = (const cf2 *)c->dc_agg.p; sa.carry = (cd2 *)c->dc_carry.p; sa.state = c->d_dc_state;
-        sa.frames_in = (int64_t)frames_in; sa.seg_first = pa.seg_first; sa.seg_len = pa.seg_len; sa.n_seg = n_blocks; sa.logc = c->dc_logc;
+        sa.geom = dg; sa.logc = c->dc_logc;
         { KernelTimer kt(c, IQGPU_K_DC_SCAN); HIP_TRY(launch_dc_scan(sa, c->stream)); }
     }
 

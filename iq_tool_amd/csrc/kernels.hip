@@ -335,27 +335,19 @@ hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s)
 // ============================================================================================
 // DC-blocker carries
 // ============================================================================================
-// Segment s covers the new samples [start(s), start(s+1)); start(0) = 0 and start(s) for s >= 1 is
-// the first new sample that block s of k_front processes (its warm-up start), clamped to the call.
-__host__ __device__ __forceinline__ int64_t dc_seg_start(int s, int64_t seg_first, int64_t seg_len, int64_t frames_in)
-{
-    if (s == 0) return 0;
-    int64_t v = seg_first + (int64_t)(s - 1) * seg_len;
-    if (v < 0) v = 0;
-    if (v > frames_in) v = frames_in;
-    return v;
-}
-
 // One workgroup per segment: A = sum_k c^(end-1-k) x[k] over the segment's new samples.
 __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
 {
     __shared__ float red[2 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sgm = blockIdx.x;
-    const int64_t beg = dc_seg_start(sgm, a.seg_first, a.seg_len, a.frames_in);
-    const int64_t end = (sgm == a.n_seg - 1) ? a.frames_in : dc_seg_start(sgm + 1, a.seg_first, a.seg_len, a.frames_in);
+    const int64_t beg = dc_seg_start(a.geom, sgm);
+    const int64_t end = (sgm == a.geom.n_seg - 1) ? a.geom.frames_in : dc_seg_start(a.geom, sgm + 1);
     const int64_t len = end - beg;
     float accr = 0.0f, acci = 0.0f;
+    const int vb = (a.in_fmt == IQGPU_FMT_CS8 || a.in_fmt == IQGPU_FMT_CU8) ? 2
+                 : (a.in_fmt == IQGPU_FMT_CS16 || a.in_fmt == IQGPU_FMT_CU16 || a.in_fmt == IQGPU_FMT_SC16Q11) ? 4
+                 : (a.in_fmt == IQGPU_FMT_CF32) ? 8 : 0;
     if (len > 0) {
         // left-pad the segment to whole chunks of 1024 so that the last chunk ends at `end`
         const int64_t n_chunks = (len + 1023) >> 10;
@@ -365,11 +357,15 @@ __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
         for (int64_t ch = 0; ch < n_chunks; ++ch) {
             const int64_t u = (ch << 10) + 4 * tid;       // padded position of this thread's 4 samples
             float lr = 0.0f, li = 0.0f;
+            const int64_t k0 = beg + u - pad;
+            cf2 xv[4];
+            // one coalesced vector load when the four frames are real and 16-byte aligned
+            const bool vec = vb != 0 && a.raw_aligned && u >= pad && ((k0 * vb) & 15) == 0 && unpack_four_fast(a.raw, k0, a.in_fmt, a.gain, xv);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int64_t k = beg + u + s - pad;
                 cf2 x{0.0f, 0.0f};
-                if (u + s >= pad) x = unpack_one(a.raw, k, a.in_fmt, a.gain);
+                if (vec) x = xv[s];
+                else if (u + s >= pad) x = unpack_one(a.raw, k0 + s, a.in_fmt, a.gain);
                 lr = fmaf(lr, c, x.x); li = fmaf(li, c, x.y);
             }
             accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
@@ -390,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
 
 hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_prefix, dim3((unsigned)a.n_seg), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_dc_prefix, dim3((unsigned)a.geom.n_seg), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -401,9 +397,9 @@ __global__ void k_dc_scan(const DcScanArgs a)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double vr = a.state->x, vi = a.state->y;
     int64_t prev_len = -1; double f = 1.0;
-    for (int sgm = 0; sgm < a.n_seg; ++sgm) {
-        const int64_t beg = dc_seg_start(sgm, a.seg_first, a.seg_len, a.frames_in);
-        const int64_t end = (sgm == a.n_seg - 1) ? a.frames_in : dc_seg_start(sgm + 1, a.seg_first, a.seg_len, a.frames_in);
+    for (int sgm = 0; sgm < a.geom.n_seg; ++sgm) {
+        const int64_t beg = dc_seg_start(a.geom, sgm);
+        const int64_t end = (sgm == a.geom.n_seg - 1) ? a.geom.frames_in : dc_seg_start(a.geom, sgm + 1);
         const int64_t len = end > beg ? end - beg : 0;
         a.carry[sgm] = cd2{vr, vi};
         if (len != prev_len) { f = exp((double)len * a.logc); prev_len = len; }

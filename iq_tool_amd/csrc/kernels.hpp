@@ -107,16 +107,50 @@ void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_ti
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
 // ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+#define IQGPU_HD __host__ __device__
+#else
+#define IQGPU_HD
+#endif
+// Where the front kernel's independent pieces start in the call's new samples.  Segment s covers
+// [start(s), start(s+1)); start(0) = 0; starts clamp to [0, frames_in].
+struct DcGeom {
+    int32_t mode;          // 0: blocks of k_front (regular spacing); 1: wave runs of k_cascade
+    int32_t n_seg;
+    int64_t frames_in;
+    // mode 0: start(s) = seg_first + (s - 1) seg_len for s >= 1
+    int64_t seg_first, seg_len;
+    // mode 1: runs in stream order -- n_edge1 edge runs of edge_tpw tiles from tile 0, n_stream streaming runs
+    // of tpw tiles from tile g0 * tpw, then edge runs from tile tb; a run starts warm tiles early
+    int64_t n_edge1, n_stream, edge_tpw, tpw, g0, tb;
+    int32_t warm, rem0;
+};
+IQGPU_HD inline int64_t dc_seg_start(const DcGeom &g, int s)
+{
+    if (s <= 0) return 0;
+    int64_t v;
+    if (g.mode == 0) {
+        v = g.seg_first + (int64_t)(s - 1) * g.seg_len;
+    } else {
+        int64_t t0;
+        if (s < g.n_edge1) t0 = (int64_t)s * g.edge_tpw;
+        else if (s < g.n_edge1 + g.n_stream) t0 = (g.g0 + (s - g.n_edge1)) * g.tpw;
+        else t0 = g.tb + (s - g.n_edge1 - g.n_stream) * g.edge_tpw;
+        v = (t0 - g.warm) * 512 - g.rem0;
+    }
+    if (v < 0) v = 0;
+    if (v > g.frames_in) v = g.frames_in;
+    return v;
+}
+
 struct DcPrefixArgs {
     const void *raw;
-    int64_t     frames_in;
     int32_t     in_fmt;
     float       gain;
+    int32_t     raw_aligned;
     float       c;            // 1 - alpha
     double      logc;
-    int64_t     seg_first;    // start (new-sample index, may be <= 0) of segment 1; segment 0 starts at 0
-    int64_t     seg_len;      // spacing of the starts of segments 1..n-1; starts clamp to [0, frames_in]
-    int32_t     n_seg;
+    DcGeom      geom;
     cf2        *agg;          // [n_seg]
 };
 hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s);
@@ -125,9 +159,7 @@ struct DcScanArgs {
     const cf2 *agg;
     cd2       *carry;         // [n_seg]
     cd2       *state;         // in: state before sample 0; out: state after the last sample
-    int64_t    frames_in;
-    int64_t    seg_first, seg_len;
-    int32_t    n_seg;
+    DcGeom     geom;
     double     logc;
 };
 hipError_t launch_dc_scan(const DcScanArgs &a, hipStream_t s);
@@ -208,11 +240,6 @@ hipError_t launch_interp(const InterpArgs &a, int n_cu, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // Output AGC, "digital" profile (agc.hip): per-chunk peak -> gain scan over chunks -> scale + pack
 // ---------------------------------------------------------------------------------------------
-#if defined(__HIPCC__)
-#define IQGPU_HD __host__ __device__
-#else
-#define IQGPU_HD
-#endif
 // How one process() call maps its input chunks (chunk_frames input frames each, counted from the
 // start of the call) to ranges of its output: closed form, so kernels and host agree without a table.
 struct AgcGeom {
