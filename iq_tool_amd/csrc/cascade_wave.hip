@@ -1,7 +1,7 @@
 // cascade_wave.hip -- k_cascade: the leading half-band stages of a multi-stage decimation
 // (msresamp2, SPEC B.6) as a wave-autonomous kernel, for chains with S >= 2 stages:
 //
-//   raw -> unpack/gain -> [iq correct] -> [pre NCO] -> half-band stages 0 .. K-1  -> cf32 (HBM)
+//   raw -> unpack/gain -> [dc block] -> [iq correct] -> [pre NCO] -> half-band stages 0 .. K-1  -> cf32 (HBM)
 //
 // K = S - 1.  The stream it writes (rate / 2^K) is then consumed by k_front_s1 (front_wave.hip) as a
 // one-stage chain: last half-band (m = 10) -> 256-arm polyphase -> [post NCO] -> pack.  The extra
@@ -70,14 +70,53 @@ __device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int l
     }
 }
 
+// DC blocker over one 256-frame chunk (lane: frames 4 lane .. 4 lane + 3).  hist: bit s set = frame s is an
+// already-processed history frame (enters the recurrence as zero and is left untouched).
+// (vr, vi) = v[n-1] at the chunk's first frame on entry, at the next chunk's first frame on exit.
+__device__ __forceinline__ void dc_chunk(const FrontArgs &a, int lane, float lane_pow, cf2 x[4], unsigned hist, float &vr, float &vi)
+{
+    const float cc = a.dc_c, aa = a.dc_a;
+    cf2 xd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xd[s] = (hist & (1u << s)) ? cf2{0.0f, 0.0f} : x[s];
+    float br = xd[0].x, bi = xd[0].y;
+#pragma unroll
+    for (int s = 1; s < 4; ++s) { br = fmaf(br, cc, xd[s].x); bi = fmaf(bi, cc, xd[s].y); }
+    // inclusive scan over the 64 lanes: B_l += c^(4*2^k) B_(l-2^k)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float ur = __shfl_up(br, 1 << k), ui = __shfl_up(bi, 1 << k);
+        if (lane >= (1 << k)) { br = fmaf(a.dc_cpow[k], ur, br); bi = fmaf(a.dc_cpow[k], ui, bi); }
+    }
+    float er = __shfl_up(br, 1), ei = __shfl_up(bi, 1);           // exclusive
+    if (lane == 0) { er = 0.0f; ei = 0.0f; }
+    const float tr = __shfl(br, 63), ti = __shfl(bi, 63);         // the chunk's aggregate
+    float sr = fmaf(lane_pow, vr, er), si = fmaf(lane_pow, vi, ei);   // v[n-1] of the lane's first frame
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float yr = fmaf(-aa, sr, xd[s].x), yi = fmaf(-aa, si, xd[s].y);
+        sr = fmaf(cc, sr, xd[s].x); si = fmaf(cc, si, xd[s].y);
+        if (!(hist & (1u << s))) { x[s].x = yr; x[s].y = yi; }
+    }
+    const float c256 = a.dc_cpow[6];
+    vr = fmaf(c256, vr, tr); vi = fmaf(c256, vi, ti);
+}
+
 struct CascLds { char *XE[kCascMaxK], *XO[kCascMaxK]; const cf2 *nco; };
 
 template <int BPS, bool EDGE>
 __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w, const int lane,
-                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1)
+                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
     constexpr int VB = BPS ? BPS : 4;
     const int K = a.casc_K;
+    // dc blocker (SPEC B.5): v[n] = x[n] + c v[n-1], y[n] = x[n] - (1 - c) v[n-1]; v carried as a wave-uniform pair
+    float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
+    bool dc_started = false;
+    if (a.dc_enable) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
+    }
     const bool unit_gain = a.gain == 1.0f;
     char *XE0 = w.XE[0], *XO0 = w.XO[0];
     const int H0 = casc_hist_rows(a.m[0]);
@@ -116,6 +155,11 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 load_chunk<VB>(src, nxt[0]);
                 load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
+            if (a.dc_enable) {
+                if (!dc_started) { const cd2 cv = a.dc_carry[seg]; dc_vr = (float)cv.x; dc_vi = (float)cv.y; dc_started = true; }
+                dc_chunk(a, lane, lane_pow, x[0], 0u, dc_vr, dc_vi);
+                dc_chunk(a, lane, lane_pow, x[1], 0u, dc_vr, dc_vi);
+            }
             if (a.iq_enable) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -136,30 +180,58 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                     }
             }
         } else {
+            // edge tiles: per-frame loads; history frames (js < 0) are already fully processed and skip
+            // every operator, frames past the end of the call are zeros
+            unsigned hist_mask[2] = {0u, 0u}, new_mask[2] = {0u, 0u};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int l4 = 256 * c + 4 * lane;
-                const int64_t j = j0 + l4;
-                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
+                const int64_t j = j0 + 256 * c + 4 * lane;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int64_t js = j + s;
                     cf2 v{0.0f, 0.0f};
                     if (js < 0) {
                         const int64_t h = (int64_t)a.hist_cap + js;
-                        if (h >= 0) v = a.hist_in[h];                 // already fully processed
+                        if (h >= 0) v = a.hist_in[h];
+                        hist_mask[c] |= 1u << s;
                     } else if (js < a.frames_in) {
                         v = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                        new_mask[c] |= 1u << s;
+                    }
+                    x[c][s] = v;
+                }
+            }
+            if (a.dc_enable && (dc_started || j0 + kWTile > 0)) {
+                if (!dc_started) {
+                    // state before the run's first new sample, moved back over the history positions of this
+                    // tile that precede it (they feed zeros into the recurrence)
+                    const cd2 cv = a.dc_carry[seg];
+                    const int64_t n_h = (j0 < 0) ? -j0 : 0;
+                    const double back = exp(-(double)n_h * a.dc_logc);
+                    dc_vr = (float)(cv.x * back); dc_vi = (float)(cv.y * back);
+                    dc_started = true;
+                }
+                dc_chunk(a, lane, lane_pow, x[0], hist_mask[0], dc_vr, dc_vi);
+                dc_chunk(a, lane, lane_pow, x[1], hist_mask[1], dc_vr, dc_vi);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int l4 = 256 * c + 4 * lane;
+                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (new_mask[c] & (1u << s)) {
+                        cf2 v = x[c][s];
                         if (a.iq_enable) {
                             const float re = v.x;
                             v.x = re * a.iq_magp1;
                             v.y = fmaf(a.iq_phase, re, v.y);
                         }
                         if (a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
-                        const int64_t back = a.frames_in - js;          // 1 .. hist_cap for kept frames
+                        const int64_t back = a.frames_in - (j0 + l4 + s);   // 1 .. hist_cap for kept frames
                         if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
+                        x[c][s] = v;
                     }
-                    x[c][s] = v;
                     th += a.nco_dtheta;
                 }
             }
@@ -262,12 +334,16 @@ __global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
-        casc_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        // position of this run among the dc-carry segments: edge runs of the first region, streaming runs,
+        // edge runs of the second region (kernels.hpp, DcGeom mode 1)
+        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + (a.w_fast_g1 - a.w_fast_g0));
+        casc_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
         if (g >= a.w_fast_g1) return;
         const int64_t t0 = g * a.w_tiles_per_wave;
-        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
+        const int seg = (int)(a.w_n_edge1 + (gw - a.w_n_edge));
+        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
     }
 }
 

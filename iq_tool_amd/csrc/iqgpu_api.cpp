@@ -285,7 +285,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     c->S = c->decim ? c->rp.S : 0;
     c->D = 1 << c->S;
     c->TG = kTile >> c->S;
-    if (c->decim && c->S >= 2 && !c->dc && !getenv("IQGPU_FORCE_GENERIC")) {
+    if (c->decim && c->S >= 2 && !getenv("IQGPU_FORCE_GENERIC")) {
         int mm[kMaxS];
         for (int i = 0; i < c->S; ++i) mm[i] = c->rp.stages[(size_t)i].m;
         c->cascade = cascade_supported(mm, c->S);
@@ -683,14 +683,51 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     int n_blocks = (int)((total_tiles + c->tiles_per_block - 1) / c->tiles_per_block);
     if (n_blocks < 1) n_blocks = 1;
 
+    // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
+    auto tiles_per_wave = [&](int64_t w_tiles) {
+        int64_t tpw64;
+        if (c->auto_block) {
+            const int64_t slots = (int64_t)c->n_cu * kWaves;
+            tpw64 = (w_tiles + slots - 1) / slots;
+            if (tpw64 < 16) tpw64 = 16;
+        } else {
+            tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
+        }
+        if (tpw64 < 1) tpw64 = 1;
+        if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
+        return (int)tpw64;
+    };
+    // ---- S >= 2: run geometry of k_cascade (needed by the dc carries as well) ----
+    const bool casc = c->cascade && !c->force_generic;
+    const int casc_K = c->S - 1;
+    const int rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : 0;
+    FrontArgs cplan{};
+    if (casc) {
+        cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
+        cplan.in_fmt = c->desc.in_format; cplan.out_fmt = IQGPU_FMT_CF32;
+        cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + kWTile - 1) / kWTile;
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles), c->casc_warm, 4);
+    }
+
     // ---- dc-blocker carries ----
     if (c->dc) {
-        int rc = c->dc_agg.ensure((size_t)n_blocks * sizeof(cf2)); if (rc) return rc;
-        rc = c->dc_carry.ensure((size_t)n_blocks * sizeof(cd2)); if (rc) return rc;
         DcGeom dg{};
-        dg.mode = 0; dg.n_seg = n_blocks; dg.frames_in = (int64_t)frames_in;
-        dg.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
-        dg.seg_len = (int64_t)c->tiles_per_block * kTile;
+        dg.frames_in = (int64_t)frames_in;
+        if (casc) {
+            dg.mode = 1;
+            dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
+            dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
+            dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k;
+            dg.n_seg = (int)(cplan.w_n_edge + dg.n_stream);
+            if (dg.n_seg < 1) dg.n_seg = 1;
+        } else {
+            dg.mode = 0; dg.n_seg = n_blocks;
+            dg.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
+            dg.seg_len = (int64_t)c->tiles_per_block * kTile;
+        }
+        int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
+        rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
         DcPrefixArgs pa{};
         pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
         pa.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
@@ -769,40 +806,15 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             // per-wave run length: with block_samples = 0 every resident wave (12 per CU, one
             // workgroup per CU) gets ONE run, so the launch is a single balanced round with one
             // warm-up tile per wave; an explicit block_samples gives runs of block_samples / 16
-            int64_t tpw64;
-            if (c->auto_block) {
-                const int64_t slots = (int64_t)c->n_cu * kWaves;
-                tpw64 = (a.w_total_tiles + slots - 1) / slots;
-                if (tpw64 < 16) tpw64 = 16;
-            } else {
-                tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
-            }
-            if (tpw64 < 1) tpw64 = 1;
-            if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
-            const int tpw = (int)tpw64;
+            const int tpw = tiles_per_wave(a.w_total_tiles);
             plan_front_s1(a, tpw, (int)((c->rp.history_in + kWTile - 1) / kWTile), 4);
             for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
             a.sink = c->d_sink;
         }
-        // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
-        auto tiles_per_wave = [&](int64_t w_tiles) {
-            int64_t tpw64;
-            if (c->auto_block) {
-                const int64_t slots = (int64_t)c->n_cu * kWaves;
-                tpw64 = (w_tiles + slots - 1) / slots;
-                if (tpw64 < 16) tpw64 = 16;
-            } else {
-                tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
-            }
-            if (tpw64 < 1) tpw64 = 1;
-            if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
-            return (int)tpw64;
-        };
-        const bool casc = c->cascade && !c->force_generic;
         if (casc) {
             // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
-            const int K = c->S - 1;
-            const int rem_k = c->rem & ((1 << K) - 1), rem_1 = c->rem >> K;
+            const int K = casc_K;
+            const int rem_1 = c->rem >> K;
             const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> K;
             int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
             FrontArgs a1 = a;
@@ -816,8 +828,11 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
             a1.casc_wave_lds = (int)cascade_wave_lds(a1);
             a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
-            a1.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + kWTile - 1) / kWTile;
-            plan_front_s1(a1, tiles_per_wave(a1.w_total_tiles), c->casc_warm, 4);
+            a1.w_total_tiles = cplan.w_total_tiles; a1.w_tiles_per_wave = cplan.w_tiles_per_wave;
+            a1.w_warm_tiles = cplan.w_warm_tiles; a1.w_edge_tpw = cplan.w_edge_tpw;
+            a1.w_fast_g0 = cplan.w_fast_g0; a1.w_fast_g1 = cplan.w_fast_g1;
+            a1.w_edge_ta = cplan.w_edge_ta; a1.w_edge_tb = cplan.w_edge_tb;
+            a1.w_n_edge1 = cplan.w_n_edge1; a1.w_n_edge = cplan.w_n_edge;
             { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
             // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
             if (n_mid > 0) {

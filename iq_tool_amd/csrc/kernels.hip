@@ -390,28 +390,65 @@ hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// carry[b] = state before segment b; state <- state after the last sample.  Sequential over the
-// (few thousand at most) segments, in double.
-__global__ void k_dc_scan(const DcScanArgs a)
+// carry[s] = state before segment s; state <- state after the last sample.  The per-segment maps
+// v -> f_s v + g_s (f_s = c^len_s, g_s = the segment's aggregate) compose associatively: each of the 256
+// threads folds a contiguous slice of segments, the slices are scanned through LDS, then every thread
+// replays its slice from its prefix.  All in double.
+__global__ __launch_bounds__(kThreads) void k_dc_scan(const DcScanArgs a)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double vr = a.state->x, vi = a.state->y;
-    int64_t prev_len = -1; double f = 1.0;
-    for (int sgm = 0; sgm < a.geom.n_seg; ++sgm) {
+    __shared__ double sf[kThreads], sr[kThreads], si[kThreads];
+    const int tid = threadIdx.x;
+    const int n = a.geom.n_seg;
+    const int per = (n + kThreads - 1) / kThreads;
+    const int s0 = tid * per, s1 = (s0 + per < n) ? s0 + per : n;
+    auto seg_len = [&](int sgm) {
         const int64_t beg = dc_seg_start(a.geom, sgm);
-        const int64_t end = (sgm == a.geom.n_seg - 1) ? a.geom.frames_in : dc_seg_start(a.geom, sgm + 1);
-        const int64_t len = end > beg ? end - beg : 0;
-        a.carry[sgm] = cd2{vr, vi};
-        if (len != prev_len) { f = exp((double)len * a.logc); prev_len = len; }
-        const cf2 g = a.agg[sgm];
-        vr = vr * f + (double)g.x; vi = vi * f + (double)g.y;
+        const int64_t end = (sgm == n - 1) ? a.geom.frames_in : dc_seg_start(a.geom, sgm + 1);
+        return end > beg ? end - beg : (int64_t)0;
+    };
+    // fold the slice: v_out = F v_in + (Gr, Gi)
+    double F = 1.0, Gr = 0.0, Gi = 0.0;
+    {
+        int64_t prev_len = -1; double f = 1.0;
+        for (int sgm = s0; sgm < s1; ++sgm) {
+            const int64_t len = seg_len(sgm);
+            if (len != prev_len) { f = exp((double)len * a.logc); prev_len = len; }
+            const cf2 g = a.agg[sgm];
+            F *= f; Gr = Gr * f + (double)g.x; Gi = Gi * f + (double)g.y;
+        }
     }
-    a.state->x = vr; a.state->y = vi;
+    sf[tid] = F; sr[tid] = Gr; si[tid] = Gi;
+    __syncthreads();
+    // inclusive scan of the maps (later map applied after the earlier one)
+    for (int o = 1; o < kThreads; o <<= 1) {
+        double pf = 1.0, pr = 0.0, pi = 0.0;
+        const bool has = tid >= o;
+        if (has) { pf = sf[tid - o]; pr = sr[tid - o]; pi = si[tid - o]; }
+        __syncthreads();
+        if (has) { sr[tid] = sr[tid] + sf[tid] * pr; si[tid] = si[tid] + sf[tid] * pi; sf[tid] = sf[tid] * pf; }
+        __syncthreads();
+    }
+    const double v0r = a.state->x, v0i = a.state->y;
+    // state before this thread's slice = (inclusive scan of the previous thread) applied to v0
+    double vr = v0r, vi = v0i;
+    if (tid > 0) { vr = sf[tid - 1] * v0r + sr[tid - 1]; vi = sf[tid - 1] * v0i + si[tid - 1]; }
+    {
+        int64_t prev_len = -1; double f = 1.0;
+        for (int sgm = s0; sgm < s1; ++sgm) {
+            a.carry[sgm] = cd2{vr, vi};
+            const int64_t len = seg_len(sgm);
+            if (len != prev_len) { f = exp((double)len * a.logc); prev_len = len; }
+            const cf2 g = a.agg[sgm];
+            vr = vr * f + (double)g.x; vi = vi * f + (double)g.y;
+        }
+    }
+    __syncthreads();
+    if (tid == kThreads - 1) { a.state->x = sf[tid] * v0r + sr[tid]; a.state->y = sf[tid] * v0i + si[tid]; }
 }
 
 hipError_t launch_dc_scan(const DcScanArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -406,6 +406,23 @@ def test_cascade_chain_matches_oracle_and_generic(gpu, oracle, monkeypatch, fmt_
     assert np.abs(cf(ch.process(raw)) - want).max() <= TOL
 
 
+@pytest.mark.parametrize("fmt_in,rate_in,rate_out", [("cs16", 10e6, 2.4e6), ("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 250e3)])
+def test_cascade_chain_with_dc_blocker(gpu, oracle, monkeypatch, fmt_in, rate_in, rate_out):
+    """dc blocker inside k_cascade: carries per wave run from k_dc_prefix / k_dc_scan (DcGeom mode 1)"""
+    n = 900001
+    raw = synth.raw_stream(n, rate_in, 43, fmt_in)
+    kw = dict(in_format=fmt_in, out_format="cf32", input_rate_hz=rate_in, target_rate_hz=rate_out,
+              dc_block=True, shift_hz=0.05 * rate_in)
+    want = cf(run_oracle(oracle, raw, **kw))
+    got = cf(run_gpu(gpu, raw, splits=[2, 511, 400000, 1, 499487], **kw))
+    assert got.size == want.size and np.abs(got - want).max() <= TOL
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = cf(run_gpu(gpu, raw, **kw))
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert np.abs(slow - got).max() <= 4e-6
+    assert np.abs(cf(run_gpu(gpu, raw, **kw)) - want).max() <= TOL
+
+
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
     n = 1 << 20
     raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
