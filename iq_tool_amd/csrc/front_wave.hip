@@ -151,8 +151,15 @@ __device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32
 // EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
 template <int BPS, bool EDGE, bool FAST>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
-                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1)
+                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
+    // dc blocker (never in the FAST instantiation): wave-uniform state, carries per run as in k_cascade
+    float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
+    bool dc_started = false;
+    if (!FAST && a.dc_enable) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
+    }
     constexpr int VB = BPS ? BPS : 4;
     char *XE = w.XE, *XO = w.XO, *HB = w.HB;
 
@@ -234,6 +241,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 load_chunk<VB>(src, nxt[0]);
                 load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
+            if (!FAST && a.dc_enable) {
+                if (!dc_started) { const cd2 cv = a.dc_carry[seg]; dc_vr = (float)cv.x; dc_vi = (float)cv.y; dc_started = true; }
+                dc_chunk(a, lane, lane_pow, x[0], 0u, dc_vr, dc_vi);
+                dc_chunk(a, lane, lane_pow, x[1], 0u, dc_vr, dc_vi);
+            }
             if (!FAST && a.iq_enable) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -255,31 +267,59 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     }
             }
         } else {
+            // edge tiles: per-frame loads; history frames (js < 0) are already fully processed and skip
+            // every operator, frames past the end of the call are zeros
+            unsigned hist_mask[2] = {0u, 0u}, new_mask[2] = {0u, 0u};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int l4 = 256 * c + 4 * lane;
-                const int64_t j = j0 + l4;
-                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
+                const int64_t j = j0 + 256 * c + 4 * lane;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int64_t js = j + s;
                     cf2 v{0.0f, 0.0f};
                     if (js < 0) {
                         const int64_t h = (int64_t)a.hist_cap + js;
-                        if (h >= 0) v = a.hist_in[h];                 // already fully processed
+                        if (h >= 0) v = a.hist_in[h];
+                        hist_mask[c] |= 1u << s;
                     } else if (js < a.frames_in) {
                         if (FAST) { const short *pr = (const short *)a.raw + 2 * js; v = cf2{(float)pr[0], (float)pr[1]}; }
                         else v = unpack_one(a.raw, js, a.in_fmt, a.gain);
+                        new_mask[c] |= 1u << s;
+                    }
+                    x[c][s] = v;
+                }
+            }
+            if (!FAST && a.dc_enable && (dc_started || j0 + kWTile > 0)) {
+                if (!dc_started) {
+                    // state before the run's first new sample, moved back over the history positions of this
+                    // tile that precede it (they feed zeros into the recurrence)
+                    const cd2 cv = a.dc_carry[seg];
+                    const int64_t n_h = (j0 < 0) ? -j0 : 0;
+                    const double back = exp(-(double)n_h * a.dc_logc);
+                    dc_vr = (float)(cv.x * back); dc_vi = (float)(cv.y * back);
+                    dc_started = true;
+                }
+                dc_chunk(a, lane, lane_pow, x[0], hist_mask[0], dc_vr, dc_vi);
+                dc_chunk(a, lane, lane_pow, x[1], hist_mask[1], dc_vr, dc_vi);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int l4 = 256 * c + 4 * lane;
+                uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (new_mask[c] & (1u << s)) {
+                        cf2 v = x[c][s];
                         if (!FAST && a.iq_enable) {
                             const float re = v.x;
                             v.x = re * a.iq_magp1;
                             v.y = fmaf(a.iq_phase, re, v.y);
                         }
                         if (FAST || a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
-                        const int64_t back = a.frames_in - js;          // 1 .. hist_cap for kept frames
+                        const int64_t back = a.frames_in - (j0 + l4 + s);   // 1 .. hist_cap for kept frames
                         if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
+                        x[c][s] = v;
                     }
-                    x[c][s] = v;
                     th += a.nco_dtheta;
                 }
             }
@@ -483,12 +523,14 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
-        run_tiles<BPS, true, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + (a.w_fast_g1 - a.w_fast_g0));   // DcGeom mode 1 order
+        run_tiles<BPS, true, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
         if (g >= a.w_fast_g1) return;
         const int64_t t0 = g * a.w_tiles_per_wave;
-        if (BPS != 0) run_tiles<BPS, false, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave);
+        const int seg = (int)(a.w_n_edge1 + (gw - a.w_n_edge));
+        if (BPS != 0) run_tiles<BPS, false, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
     }
 }
 
@@ -512,7 +554,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL((k_front_s1<BPS, FAST>), dim3(grid), dim3(kWThreads), lds, s, a);                          \
     } while (0)
-    const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
+    const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
                       a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
     if (cls == 2) IQGPU_LAUNCH_S1(2, false);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true);

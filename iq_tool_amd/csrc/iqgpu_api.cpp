@@ -697,24 +697,34 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
         return (int)tpw64;
     };
-    // ---- S >= 2: run geometry of k_cascade (needed by the dc carries as well) ----
+    // ---- run geometry of the wave-autonomous kernels (needed by the dc carries as well) ----
+    //   S >= 2: k_cascade (stages 0 .. S-2) + k_front_s1 (last stage);  S == 1: k_front_s1
     const bool casc = c->cascade && !c->force_generic;
+    const bool fast_s1 = c->decim && c->S == 1 && c->rp.stages[0].m == 10 && !c->force_generic;
     const int casc_K = c->S - 1;
-    const int rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : 0;
+    const int rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : c->rem;
     FrontArgs cplan{};
-    if (casc) {
+    if (casc || fast_s1) {
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
-        cplan.in_fmt = c->desc.in_format; cplan.out_fmt = IQGPU_FMT_CF32;
+        cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
         cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + kWTile - 1) / kWTile;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles), c->casc_warm, 4);
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles),
+                      casc ? c->casc_warm : (int)((c->rp.history_in + kWTile - 1) / kWTile), 4);
     }
+    auto copy_plan = [&](FrontArgs &dst) {
+        dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
+        dst.w_warm_tiles = cplan.w_warm_tiles; dst.w_edge_tpw = cplan.w_edge_tpw;
+        dst.w_fast_g0 = cplan.w_fast_g0; dst.w_fast_g1 = cplan.w_fast_g1;
+        dst.w_edge_ta = cplan.w_edge_ta; dst.w_edge_tb = cplan.w_edge_tb;
+        dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
+    };
 
     // ---- dc-blocker carries ----
     if (c->dc) {
         DcGeom dg{};
         dg.frames_in = (int64_t)frames_in;
-        if (casc) {
+        if (casc || fast_s1) {
             dg.mode = 1;
             dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
             dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
@@ -799,15 +809,9 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (filt)         { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
         else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
         else              { a.out_fmt = fin_fmt; a.out = fin_out; }
-        // wave-autonomous fast path: one half-band stage (m = 10), no dc blocker
-        const bool fast_s1 = c->decim && c->S == 1 && a.m[0] == 10 && !c->dc && !c->force_generic;
+        // wave-autonomous fast path: one half-band stage (m = 10)
         if (fast_s1) {
-            a.w_total_tiles = (span_samples + kWTile - 1) / kWTile;
-            // per-wave run length: with block_samples = 0 every resident wave (12 per CU, one
-            // workgroup per CU) gets ONE run, so the launch is a single balanced round with one
-            // warm-up tile per wave; an explicit block_samples gives runs of block_samples / 16
-            const int tpw = tiles_per_wave(a.w_total_tiles);
-            plan_front_s1(a, tpw, (int)((c->rp.history_in + kWTile - 1) / kWTile), 4);
+            copy_plan(a);
             for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
             a.sink = c->d_sink;
         }
@@ -828,11 +832,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
             a1.casc_wave_lds = (int)cascade_wave_lds(a1);
             a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
-            a1.w_total_tiles = cplan.w_total_tiles; a1.w_tiles_per_wave = cplan.w_tiles_per_wave;
-            a1.w_warm_tiles = cplan.w_warm_tiles; a1.w_edge_tpw = cplan.w_edge_tpw;
-            a1.w_fast_g0 = cplan.w_fast_g0; a1.w_fast_g1 = cplan.w_fast_g1;
-            a1.w_edge_ta = cplan.w_edge_ta; a1.w_edge_tb = cplan.w_edge_tb;
-            a1.w_n_edge1 = cplan.w_n_edge1; a1.w_n_edge = cplan.w_n_edge;
+            copy_plan(a1);
             { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
             // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
             if (n_mid > 0) {

@@ -123,4 +123,36 @@ __device__ __forceinline__ cf2 cmul_tab(cf2 x, cf2 cs)
     return y;
 }
 
+// DC blocker over one 256-frame chunk (lane: frames 4 lane .. 4 lane + 3).  hist: bit s set = frame s is an
+// already-processed history frame (enters the recurrence as zero and is left untouched).
+// (vr, vi) = v[n-1] at the chunk's first frame on entry, at the next chunk's first frame on exit.
+__device__ __forceinline__ void dc_chunk(const FrontArgs &a, int lane, float lane_pow, cf2 x[4], unsigned hist, float &vr, float &vi)
+{
+    const float cc = a.dc_c, aa = a.dc_a;
+    cf2 xd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xd[s] = (hist & (1u << s)) ? cf2{0.0f, 0.0f} : x[s];
+    float br = xd[0].x, bi = xd[0].y;
+#pragma unroll
+    for (int s = 1; s < 4; ++s) { br = fmaf(br, cc, xd[s].x); bi = fmaf(bi, cc, xd[s].y); }
+    // inclusive scan over the 64 lanes: B_l += c^(4*2^k) B_(l-2^k)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float ur = __shfl_up(br, 1 << k), ui = __shfl_up(bi, 1 << k);
+        if (lane >= (1 << k)) { br = fmaf(a.dc_cpow[k], ur, br); bi = fmaf(a.dc_cpow[k], ui, bi); }
+    }
+    float er = __shfl_up(br, 1), ei = __shfl_up(bi, 1);           // exclusive
+    if (lane == 0) { er = 0.0f; ei = 0.0f; }
+    const float tr = __shfl(br, 63), ti = __shfl(bi, 63);         // the chunk's aggregate
+    float sr = fmaf(lane_pow, vr, er), si = fmaf(lane_pow, vi, ei);   // v[n-1] of the lane's first frame
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float yr = fmaf(-aa, sr, xd[s].x), yi = fmaf(-aa, si, xd[s].y);
+        sr = fmaf(cc, sr, xd[s].x); si = fmaf(cc, si, xd[s].y);
+        if (!(hist & (1u << s))) { x[s].x = yr; x[s].y = yi; }
+    }
+    const float c256 = a.dc_cpow[6];
+    vr = fmaf(c256, vr, tr); vi = fmaf(c256, vi, ti);
+}
+
 } // namespace iqgpu

@@ -423,6 +423,25 @@ def test_cascade_chain_with_dc_blocker(gpu, oracle, monkeypatch, fmt_in, rate_in
     assert np.abs(cf(run_gpu(gpu, raw, **kw)) - want).max() <= TOL
 
 
+@pytest.mark.parametrize("fmt_out", ["cf32", "cs16"])
+def test_nrsc5_chain_with_dc_blocker_wave_kernel(gpu, oracle, monkeypatch, fmt_out):
+    """S = 1 with the dc blocker runs in k_front_s1 too (carries per wave run)"""
+    n = 1200003
+    raw = synth.raw_stream(n, 2.4e6, 44, "cs16")
+    kw = dict(NRSC5, out_format=fmt_out, dc_block=True)
+    want = run_oracle(oracle, raw, **kw)
+    got = run_gpu(gpu, raw, splits=[100, 600000, 3, 599900], **kw)
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = run_gpu(gpu, raw, **kw)
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert got.size == want.size == slow.size
+    if fmt_out == "cf32":
+        assert np.abs(cf(got) - cf(want)).max() <= TOL and np.abs(cf(slow) - cf(got)).max() <= 4e-6
+    else:
+        int_close(got, want)
+        int_close(slow, got, min_same=0.999)
+
+
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
     n = 1 << 20
     raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
