@@ -21,39 +21,59 @@
 
 namespace iqgpu {
 
+// LDS index swizzle: one pad element per 32.  The autosort writes of the early passes are strided
+// (stride 4 Ns elements); without the pad 65 % of the kernel's LDS cycles were bank conflicts
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE on config 3).
+__device__ __forceinline__ int sw(int i) { return i + (i >> 5); }
+
 __device__ __forceinline__ cf2 cmulf(cf2 a, cf2 b)
 {
     return cf2{fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
 }
 
-// one Stockham pass of radix R (4 or 2) over N points: src -> dst, sub-transform size Ns -> Ns*R.
-// tw[k] = exp(-2 pi i k / N)
-template <int R>
-__device__ __forceinline__ void stockham_pass(const cf2 *src, cf2 *dst, const cf2 *tw, int N, int Ns, int tid, int nthr)
+// Stockham autosort passes over N points in LDS, sub-transform size Ns -> Ns*R per pass.
+// tw[k] = exp(-2 pi i k / N).  A thread owns at most kFftMaxB butterflies per pass (the launcher
+// sizes the workgroup accordingly); the twiddles of pass p+1 are fetched from the (L2-resident)
+// table while pass p computes, so that their latency is off the pass-to-pass critical path.
+constexpr int kFftMaxB = 2;
+
+struct TwSet { cf2 w[kFftMaxB][3]; };
+
+__device__ __forceinline__ void load_twiddles(TwSet &t, const cf2 *tw, int N, int Ns, int tid, int nthr)
 {
-    const int nb = N / R;
-    const int tstride = N / (Ns * R);                 // table step of this pass
-    for (int j = tid; j < nb; j += nthr) {
-        const int k = j & (Ns - 1);
-        cf2 v[R];
+    const int nb = N >> 2, tstride = N / (Ns * 4);
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = src[j + r * nb];
-        if (Ns > 1) {
+    for (int i = 0; i < kFftMaxB; ++i) {
+        const int j = tid + i * nthr;
+        const int k = (j < nb) ? (j & (Ns - 1)) : 0;
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmulf(v[r], tw[k * r * tstride]);
-        }
-        const int j0 = (j - k) * R + k;
-        if (R == 4) {
+        for (int r = 1; r < 4; ++r) t.w[i][r - 1] = tw[k * r * tstride];
+    }
+}
+
+__device__ __forceinline__ void radix4_pass(const cf2 *src, cf2 *dst, const TwSet &t, int N, int Ns, int tid, int nthr)
+{
+    const int nb = N >> 2;
+#pragma unroll
+    for (int i = 0; i < kFftMaxB; ++i) {
+        const int j = tid + i * nthr;
+        if (j < nb) {
+            const int k = j & (Ns - 1);
+            cf2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = src[sw(j + r * nb)];
+            if (Ns > 1) {
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v[r] = cmulf(v[r], t.w[i][r - 1]);
+            }
+            const int j0 = (j - k) * 4 + k;
             const cf2 a{v[0].x + v[2].x, v[0].y + v[2].y}, b{v[0].x - v[2].x, v[0].y - v[2].y};
             const cf2 c{v[1].x + v[3].x, v[1].y + v[3].y};
             const cf2 d{v[1].y - v[3].y, v[3].x - v[1].x};             // (v1 - v3) * (-i)
-            dst[j0] = cf2{a.x + c.x, a.y + c.y};
-            dst[j0 + Ns] = cf2{b.x + d.x, b.y + d.y};
-            dst[j0 + 2 * Ns] = cf2{a.x - c.x, a.y - c.y};
-            dst[j0 + 3 * Ns] = cf2{b.x - d.x, b.y - d.y};
-        } else {
-            dst[j0] = cf2{v[0].x + v[1].x, v[0].y + v[1].y};
-            dst[j0 + Ns] = cf2{v[0].x - v[1].x, v[0].y - v[1].y};
+            dst[sw(j0)] = cf2{a.x + c.x, a.y + c.y};
+            dst[sw(j0 + Ns)] = cf2{b.x + d.x, b.y + d.y};
+            dst[sw(j0 + 2 * Ns)] = cf2{a.x - c.x, a.y - c.y};
+            dst[sw(j0 + 3 * Ns)] = cf2{b.x - d.x, b.y - d.y};
         }
     }
 }
@@ -63,16 +83,28 @@ __device__ __forceinline__ cf2 *fft_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int
 {
     cf2 *src = buf0, *dst = buf1;
     int Ns = 1;
+    TwSet cur, nxt;
     if (log2n & 1) {
-        stockham_pass<2>(src, dst, tw, N, Ns, tid, nthr);
+        // one radix-2 pass first (no twiddles at Ns = 1); meanwhile fetch the twiddles of the Ns = 2 pass
+        load_twiddles(cur, tw, N, 2, tid, nthr);
+        const int nb = N >> 1;
+        for (int j = tid; j < nb; j += nthr) {
+            const cf2 v0 = src[sw(j)], v1 = src[sw(j + nb)];
+            dst[sw(2 * j)] = cf2{v0.x + v1.x, v0.y + v1.y};
+            dst[sw(2 * j + 1)] = cf2{v0.x - v1.x, v0.y - v1.y};
+        }
         __syncthreads();
         Ns = 2;
         cf2 *t = src; src = dst; dst = t;
+    } else {
+        load_twiddles(cur, tw, N, 1, tid, nthr);
     }
     while (Ns < N) {
-        stockham_pass<4>(src, dst, tw, N, Ns, tid, nthr);
+        if (Ns * 4 < N) load_twiddles(nxt, tw, N, Ns * 4, tid, nthr);
+        radix4_pass(src, dst, cur, N, Ns, tid, nthr);
         __syncthreads();
         Ns *= 4;
+        cur = nxt;
         cf2 *t = src; src = dst; dst = t;
     }
     return src;
@@ -83,30 +115,31 @@ __global__ __launch_bounds__(kFftMaxThreads) void k_fftconv(const FftConvArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N = 1 << a.log2n, L1 = a.ntaps - 1, V = N - L1;
-    cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + N;
-    cf2 *s_nco = buf1 + N;                                  // only when the post NCO is on
+    const int NP = N + (N >> 5) + 2;                        // padded length (sw)
+    cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + NP;
+    cf2 *s_nco = buf1 + NP;                                  // only when the post NCO is on
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += nthr) s_nco[i] = a.nco_tab[i];
 
     // window sample p <-> filter-input stream index s = blk*V - L1 + p <-> fbuf[L1 + s]
     const int64_t o0 = (int64_t)blockIdx.x * V;
     for (int p = tid; p < N; p += nthr) {
         const int64_t fi = o0 + p;
-        buf0[p] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+        buf0[sw(p)] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
     }
     __syncthreads();
     cf2 *X = fft_lds(buf0, buf1, a.twiddle, N, a.log2n, tid, nthr);
     cf2 *other = (X == buf0) ? buf1 : buf0;
     // Y = conj(FFT(conj(X . H))), H already carries the 1/N
     for (int p = tid; p < N; p += nthr) {
-        const cf2 z = cmulf(X[p], a.hfreq[p]);
-        X[p] = cf2{z.x, -z.y};
+        const cf2 z = cmulf(X[sw(p)], a.hfreq[p]);
+        X[sw(p)] = cf2{z.x, -z.y};
     }
     __syncthreads();
     cf2 *Y = fft_lds(X, other, a.twiddle, N, a.log2n, tid, nthr);
     const int64_t left = a.n_emit - o0;
     const int nv = left < (int64_t)V ? (int)left : V;
     for (int i = tid; i < nv; i += nthr) {
-        cf2 y = Y[L1 + i];
+        cf2 y = Y[sw(L1 + i)];
         y.y = -y.y;
         const int64_t k = o0 + i;
         if (a.pnco_mode != 0)
@@ -121,13 +154,14 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
     const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
     if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
-    const size_t lds = (size_t)2 * N * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
+    const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fftconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     int nthr = a.threads > 0 ? a.threads : (N >= 8192 ? 1024 : (N >= 4096 ? 512 : 256));
     if (nthr > kFftMaxThreads) nthr = kFftMaxThreads;
+    while (nthr * kFftMaxB < (N >> 2)) nthr *= 2;                   // at most kFftMaxB radix-4 butterflies per thread
     hipLaunchKernelGGL(k_fftconv, dim3(nb), dim3(nthr), lds, s, a);
     return hipGetLastError();
 }
