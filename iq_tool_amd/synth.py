@@ -42,6 +42,17 @@ def quantise(x, fmt):
         return np.trunc(w + half).astype(dt)
     if fmt == "cf32":
         return v.copy()
+    if fmt == "cs32":
+        w = np.clip(np.round(v.astype(np.float64) * 2147483647.0), -2147483648.0, 2147483647.0)
+        return w.astype(np.int32)
+    if fmt == "cu32":
+        w = np.clip(np.round(v.astype(np.float64) * 2147483647.0 + 2147483647.5), 0.0, 4294967295.0)
+        return w.astype(np.uint32)
+    if fmt == "cs24":
+        w = np.clip(np.round(v.astype(np.float64) * 8388607.0), -8388608.0, 8388607.0).astype(np.int32)
+        b = np.empty((w.size, 3), np.uint8)            # 3 little-endian bytes per component
+        b[:, 0] = w & 0xff; b[:, 1] = (w >> 8) & 0xff; b[:, 2] = (w >> 16) & 0xff
+        return b.reshape(-1)
     raise ValueError("synth.quantise: format %r not supported" % fmt)
 
 

@@ -668,3 +668,82 @@ def test_full_size_count_law_split_invariance_and_spot_parity(gpu, oracle):
     want = oracle.Chain(**NRSC5).process(np.tile(seg, 8))
     int_close(out1.view(np.int16)[:want.size], want)
     d_in.free(); d_out.free()
+
+
+# --------------------------------------------------------------------------------------------
+# randomised chains: every dispatch path (k_front / k_front_s1 / k_cascade / k_interp / k_fir /
+# k_fftconv / agc) against the oracle, with random call splits
+# --------------------------------------------------------------------------------------------
+def _random_chain(rng):
+    fmt_in = str(rng.choice(["cs16", "cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"]))
+    fmt_out = str(rng.choice(["cf32", "cf32", "cs16", "cu8", "cs8", "cu16"]))
+    rate_in = float(rng.choice([250e3, 1.0e6, 2.4e6, 8e6, 20e6]))
+    kind = rng.integers(0, 10)
+    if kind == 0:
+        kw = dict(no_resample=True, target_rate_hz=rate_in)
+    elif kind <= 2:
+        kw = dict(target_rate_hz=rate_in * float(rng.uniform(1.0, 6.0)))           # interpolating
+    else:
+        kw = dict(target_rate_hz=rate_in * float(2.0 ** -rng.uniform(0.05, 5.5)))  # S = 0 .. 5
+    kw.update(in_format=fmt_in, out_format=fmt_out, input_rate_hz=rate_in, gain=float(rng.choice([1.0, 1.0, 0.5, 1.7])))
+    if rng.random() < 0.5:
+        kw["shift_hz"] = float(rng.uniform(-0.3, 0.3) * rate_in)
+        if rng.random() < 0.3 and not kw.get("no_resample"):
+            kw["shift_after_resample"] = True
+            kw["shift_hz"] = float(rng.uniform(-0.3, 0.3) * kw["target_rate_hz"])
+    if rng.random() < 0.4:
+        kw["dc_block"] = True
+    if rng.random() < 0.3:
+        kw.update(iq_correct=True, iq_mag=float(rng.uniform(-0.05, 0.05)), iq_phase=float(rng.uniform(-0.05, 0.05)))
+    out_rate = kw["target_rate_hz"]
+    if rng.random() < 0.45:
+        lim = 0.5 * min(out_rate, rate_in)
+        typ = str(rng.choice(["lowpass", "passband", "highpass", "stopband"]))
+        if typ in ("lowpass", "highpass"):
+            req = (typ, float(rng.uniform(0.1, 0.6) * lim), 0.0)
+        else:
+            bw = float(rng.uniform(0.1, 0.3) * lim)
+            req = (typ, float(rng.uniform(-0.5, 0.5) * lim), bw)
+        kw["filters"] = (req,)
+        kw["filter_impl"] = str(rng.choice(["auto", "fir", "fft"]))
+        if rng.random() < 0.5:
+            kw["filter_taps"] = int(rng.choice([31, 101, 257, 1025]))
+    if rng.random() < 0.25:
+        kw["agc"] = True
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_chain_matches_oracle(gpu, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    kw = _random_chain(rng)
+    from iq_tool_amd import IqgpuError
+    n = int(rng.integers(60000, 260000))
+    r = kw["target_rate_hz"] / kw["input_rate_hz"]
+    if r > 1.5:
+        n = int(n / r) + 20000
+    raw = synth.raw_stream(n, kw["input_rate_hz"], 500 + seed, kw["in_format"])
+    try:
+        ch = gpu.Chain(**kw)
+    except IqgpuError as e:
+        # whatever the product rejects the oracle must reject too (filter beyond Nyquist, ...)
+        with pytest.raises(ValueError):
+            oracle.Chain(**{k: v for k, v in kw.items() if k not in ("block_samples", "device")})
+        assert e.code in (-4, -6, -7)
+        return
+    want = run_oracle(oracle, raw, **kw)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n, 3)) | {0, n})
+    if kw.get("agc"):
+        cuts = sorted(set((v // 16384) * 16384 for v in cuts) | {0, n})       # AGC chunks follow the call boundaries
+    bpf = ch.in_bytes
+    rb = np.ascontiguousarray(raw).view(np.uint8)
+    outs = [ch.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    got = np.concatenate(outs) if outs else np.zeros(0, want.dtype)
+    assert got.size == want.size, (kw, got.size, want.size)
+    if want.size == 0:
+        return
+    if kw["out_format"] == "cf32":
+        scale = max(1.0, float(np.abs(cf(want)).max()))
+        assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL * scale, kw
+    else:
+        int_close(got, want, min_same=0.9)
