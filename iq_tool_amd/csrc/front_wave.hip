@@ -203,8 +203,22 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     // stored at the top of the NEXT iteration, right after the wait for the prefetched frames, so
     // that this wait (vmcnt(0)) only ever covers loads and stores issued a whole tile earlier
     const bool defer = !EDGE && (FAST || a.out_fmt == IQGPU_FMT_CS16);
-    uint32_t pend_val[4] = {0, 0, 0, 0}, pend_idx[4] = {~0u, ~0u, ~0u, ~0u};
+    // A lane's outputs of a tile are consecutive (2 to 4 of them: one per 1 .. 2 half-band samples), so
+    // they are compacted and leave as one 8-byte store plus at most one more, instead of four predicated
+    // dword stores -- the CU's vector-memory issue path is one of the three pipes this kernel loads.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+    uint32_t pend_c[4] = {0, 0, 0, 0}, pend_n0 = 0, pend_cnt = 0;
     char *pend_base = (char *)a.out;
+    auto flush_pending = [&]() {
+        if (pend_cnt != 0) {
+            char *b = pend_base + 4u * pend_n0;
+            if (pend_cnt == 1) *(uint32_t *)b = pend_c[0];
+            else *(u32x2 *)b = u32x2{pend_c[0], pend_c[1]};
+            if (pend_cnt == 3) *(uint32_t *)(b + 8) = pend_c[2];
+            if (pend_cnt == 4) *(u32x2 *)(b + 8) = u32x2{pend_c[2], pend_c[3]};
+            pend_cnt = 0;
+        }
+    };
     STAMP_DECL
     STAMP_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
@@ -231,11 +245,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             }
             STAMP(0);
-            if (defer) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (pend_idx[r] != ~0u) { *(uint32_t *)(pend_base + 4u * pend_idx[r]) = pend_val[r]; pend_idx[r] = ~0u; }
-            }
+            if (defer) flush_pending();
             {
                 const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
                 load_chunk<VB>(src, nxt[0]);
@@ -415,15 +425,26 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 char *obase = (char *)a.out + (int64_t)k_tile0 * obps;
                 const uint32_t pth0 = a.pnco_theta0 + (uint32_t)k_tile0 * a.pnco_dtheta;
                 uint32_t kk = n0;
+                uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
                         if (!FAST && a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
-                        if (defer) { pend_val[r] = pack_cs16(cf2{yy.x, yy.y}); pend_idx[r] = kk; }
+                        if (defer) pk[r] = pack_cs16(cf2{yy.x, yy.y});
                         else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
+                }
+                if (defer) {
+                    // compact the hit slots (gaps between hits are 1 or 2 samples, so a streaming lane has >= 2)
+                    const bool h01 = hit[0] && hit[1];
+                    pend_c[0] = hit[0] ? pk[0] : pk[1];
+                    pend_c[1] = h01 ? pk[1] : (hit[2] ? pk[2] : pk[3]);
+                    pend_c[2] = (h01 && hit[2]) ? pk[2] : pk[3];
+                    pend_c[3] = pk[3];
+                    pend_n0 = n0;
+                    pend_cnt = kk - n0;
                 }
                 pend_base = obase;
             }
@@ -463,11 +484,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
     }
-    if (defer) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (pend_idx[r] != ~0u) *(uint32_t *)(pend_base + 4u * pend_idx[r]) = pend_val[r];
-    }
+    if (defer) flush_pending();
     STAMP_FLUSH(a.sink);
 }
 
