@@ -13,6 +13,7 @@
 //                                       then [post NCO] and pack.
 // Twiddles come from an N-entry table in global memory (L2-resident; double-precision values
 // rounded to float -- v_sin/v_cos are not accurate enough for the 1e-5 budget).
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -148,8 +149,153 @@ __global__ __launch_bounds__(kFftMaxThreads) void k_fftconv(const FftConvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fftconv16: the same overlap-save block for N >= 1024 with radix-16 passes held in registers:
+// N / 16 threads, one 16-point butterfly per thread per pass, so a 4096-point transform is 3 LDS
+// round trips (+ barriers) instead of 6, and the 15 twiddles of a butterfly are fetched together
+// with its 16 points.  N = 2^a 16^b: the leading factor (2, 4 or 8) runs first as radix-2 / radix-4.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft4(cf2 &a0, cf2 &a1, cf2 &a2, cf2 &a3)
+{
+    const cf2 s02{a0.x + a2.x, a0.y + a2.y}, d02{a0.x - a2.x, a0.y - a2.y};
+    const cf2 s13{a1.x + a3.x, a1.y + a3.y};
+    const cf2 d13{a1.y - a3.y, a3.x - a1.x};                       // (a1 - a3) * (-i)
+    a0 = cf2{s02.x + s13.x, s02.y + s13.y};
+    a1 = cf2{d02.x + d13.x, d02.y + d13.y};
+    a2 = cf2{s02.x - s13.x, s02.y - s13.y};
+    a3 = cf2{d02.x - d13.x, d02.y - d13.y};
+}
+
+// in place; X[m + 4n] ends up in v[n + 4m]
+__device__ __forceinline__ void dft16(cf2 v[16])
+{
+    // W16^e = exp(-2 pi i e / 16)
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[c], v[c + 4], v[c + 8], v[c + 12]);     // u[c][m] -> v[c + 4m]
+    // u[c][m] *= W16^(c m)
+    v[1 + 4] = cmulf(v[1 + 4], cf2{c1, -s1});          // e = 1
+    v[2 + 4] = cmulf(v[2 + 4], cf2{h, -h});            // e = 2
+    v[3 + 4] = cmulf(v[3 + 4], cf2{s1, -c1});          // e = 3
+    v[1 + 8] = cmulf(v[1 + 8], cf2{h, -h});            // e = 2
+    v[2 + 8] = cf2{v[2 + 8].y, -v[2 + 8].x};           // e = 4: * (-i)
+    v[3 + 8] = cmulf(v[3 + 8], cf2{-h, -h});           // e = 6
+    v[1 + 12] = cmulf(v[1 + 12], cf2{s1, -c1});        // e = 3
+    v[2 + 12] = cmulf(v[2 + 12], cf2{-h, -h});         // e = 6
+    v[3 + 12] = cmulf(v[3 + 12], cf2{-c1, s1});        // e = 9
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dft4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
+}
+
+__device__ __forceinline__ cf2 *fft16_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int N, int log2n, int tid, int T)
+{
+    cf2 *src = buf0, *dst = buf1;
+    int Ns = 1;
+    if (log2n & 1) {                                                  // radix-2, Ns = 1: no twiddles
+        const int nb = N >> 1;
+        for (int j = tid; j < nb; j += T) {
+            const cf2 v0 = src[sw(j)], v1 = src[sw(j + nb)];
+            dst[sw(2 * j)] = cf2{v0.x + v1.x, v0.y + v1.y};
+            dst[sw(2 * j + 1)] = cf2{v0.x - v1.x, v0.y - v1.y};
+        }
+        __syncthreads();
+        Ns = 2;
+        cf2 *t = src; src = dst; dst = t;
+    }
+    if (log2n & 2) {                                                  // radix-4
+        const int nb = N >> 2, tstride = N / (Ns * 4);
+        for (int j = tid; j < nb; j += T) {
+            const int k = j & (Ns - 1);
+            cf2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = src[sw(j + r * nb)];
+            if (Ns > 1) {
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v[r] = cmulf(v[r], tw[k * r * tstride]);
+            }
+            dft4(v[0], v[1], v[2], v[3]);
+            const int j0 = (j - k) * 4 + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[sw(j0 + r * Ns)] = v[r];
+        }
+        __syncthreads();
+        Ns *= 4;
+        cf2 *t = src; src = dst; dst = t;
+    }
+    while (Ns < N) {                                                  // radix-16, one butterfly per thread
+        const int j = tid, k = j & (Ns - 1), tstride = N / (Ns * 16);
+        cf2 v[16], w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = src[sw(j + r * T)];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < 16; ++r) w[r] = tw[k * r * tstride];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v[r] = cmulf(v[r], w[r]);
+        }
+        dft16(v);
+        const int j0 = (j - k) * 16 + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[sw(j0 + r * Ns)] = v[(r >> 2) + 4 * (r & 3)];
+        __syncthreads();
+        Ns *= 16;
+        cf2 *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+__global__ __launch_bounds__(512) void k_fftconv16(const FftConvArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, T = blockDim.x;                     // T = N / 16
+    const int N = 1 << a.log2n, L1 = a.ntaps - 1, V = N - L1;
+    const int NP = N + (N >> 5) + 2;
+    cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + NP;
+    cf2 *s_nco = buf1 + NP;
+    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];
+
+    const int64_t o0 = (int64_t)blockIdx.x * V;
+#pragma unroll 4
+    for (int p = tid; p < N; p += T) {
+        const int64_t fi = o0 + p;
+        buf0[sw(p)] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+    }
+    __syncthreads();
+    cf2 *X = fft16_lds(buf0, buf1, a.twiddle, N, a.log2n, tid, T);
+    cf2 *other = (X == buf0) ? buf1 : buf0;
+#pragma unroll 4
+    for (int p = tid; p < N; p += T) {
+        const cf2 z = cmulf(X[sw(p)], a.hfreq[p]);
+        X[sw(p)] = cf2{z.x, -z.y};
+    }
+    __syncthreads();
+    cf2 *Y = fft16_lds(X, other, a.twiddle, N, a.log2n, tid, T);
+    const int64_t left = a.n_emit - o0;
+    const int nv = left < (int64_t)V ? (int)left : V;
+    for (int i = tid; i < nv; i += T) {
+        cf2 y = Y[sw(L1 + i)];
+        y.y = -y.y;
+        const int64_t k = o0 + i;
+        if (a.pnco_mode != 0)
+            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
+        pack_store(a.out, k, a.out_fmt, y);
+    }
+}
+
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
 {
+    if (a.n_emit > 0 && a.log2n >= 10 && !getenv("IQGPU_FFT_NO_R16")) {
+        const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
+        if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
+        const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
+        const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_fftconv16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_fftconv16, dim3(nb), dim3(N / 16), lds, s, a);
+        return hipGetLastError();
+    }
     if (a.n_emit <= 0) return hipSuccess;
     const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
     if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
