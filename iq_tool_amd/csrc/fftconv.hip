@@ -187,46 +187,56 @@ __device__ __forceinline__ void dft16(cf2 v[16])
     for (int m = 0; m < 4; ++m) dft4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
 }
 
-__device__ __forceinline__ cf2 *fft16_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, int N, int log2n, int tid, int T)
+// in place in ONE buffer: every pass pulls its points into registers, all threads meet, then the
+// autosorted results go back to the same buffer (half the LDS of a ping-pong pair -> twice the
+// workgroups per CU; one more barrier per pass)
+__device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int N, int log2n, int tid, int T)
 {
-    cf2 *src = buf0, *dst = buf1;
     int Ns = 1;
     if (log2n & 1) {                                                  // radix-2, Ns = 1: no twiddles
-        const int nb = N >> 1;
-        for (int j = tid; j < nb; j += T) {
-            const cf2 v0 = src[sw(j)], v1 = src[sw(j + nb)];
-            dst[sw(2 * j)] = cf2{v0.x + v1.x, v0.y + v1.y};
-            dst[sw(2 * j + 1)] = cf2{v0.x - v1.x, v0.y - v1.y};
+        const int nb = N >> 1;                                        // 8 butterflies per thread
+        cf2 v0[8], v1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = tid + i * T; v0[i] = buf[sw(j)]; v1[i] = buf[sw(j + nb)]; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = tid + i * T;
+            buf[sw(2 * j)] = cf2{v0[i].x + v1[i].x, v0[i].y + v1[i].y};
+            buf[sw(2 * j + 1)] = cf2{v0[i].x - v1[i].x, v0[i].y - v1[i].y};
         }
         __syncthreads();
         Ns = 2;
-        cf2 *t = src; src = dst; dst = t;
     }
-    if (log2n & 2) {                                                  // radix-4
+    if (log2n & 2) {                                                  // radix-4: 4 butterflies per thread
         const int nb = N >> 2, tstride = N / (Ns * 4);
-        for (int j = tid; j < nb; j += T) {
-            const int k = j & (Ns - 1);
-            cf2 v[4];
+        cf2 v[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = src[sw(j + r * nb)];
+        for (int i = 0; i < 4; ++i) {
+            const int j = tid + i * T, k = j & (Ns - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][r] = buf[sw(j + r * nb)];
             if (Ns > 1) {
 #pragma unroll
-                for (int r = 1; r < 4; ++r) v[r] = cmulf(v[r], tw[k * r * tstride]);
+                for (int r = 1; r < 4; ++r) v[i][r] = cmulf(v[i][r], tw[k * r * tstride]);
             }
-            dft4(v[0], v[1], v[2], v[3]);
-            const int j0 = (j - k) * 4 + k;
+            dft4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[sw(j0 + r * Ns)] = v[r];
+        for (int i = 0; i < 4; ++i) {
+            const int j = tid + i * T, k = j & (Ns - 1), j0 = (j - k) * 4 + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[sw(j0 + r * Ns)] = v[i][r];
         }
         __syncthreads();
         Ns *= 4;
-        cf2 *t = src; src = dst; dst = t;
     }
     while (Ns < N) {                                                  // radix-16, one butterfly per thread
         const int j = tid, k = j & (Ns - 1), tstride = N / (Ns * 16);
         cf2 v[16], w[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = src[sw(j + r * T)];
+        for (int r = 0; r < 16; ++r) v[r] = buf[sw(j + r * T)];
         if (Ns > 1) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) w[r] = tw[k * r * tstride];
@@ -235,13 +245,12 @@ __device__ __forceinline__ cf2 *fft16_lds(cf2 *buf0, cf2 *buf1, const cf2 *tw, i
         }
         dft16(v);
         const int j0 = (j - k) * 16 + k;
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[sw(j0 + r * Ns)] = v[(r >> 2) + 4 * (r & 3)];
+        for (int r = 0; r < 16; ++r) buf[sw(j0 + r * Ns)] = v[(r >> 2) + 4 * (r & 3)];
         __syncthreads();
         Ns *= 16;
-        cf2 *t = src; src = dst; dst = t;
     }
-    return src;
 }
 
 __global__ __launch_bounds__(512) void k_fftconv16(const FftConvArgs a)
@@ -250,26 +259,26 @@ __global__ __launch_bounds__(512) void k_fftconv16(const FftConvArgs a)
     const int tid = threadIdx.x, T = blockDim.x;                     // T = N / 16
     const int N = 1 << a.log2n, L1 = a.ntaps - 1, V = N - L1;
     const int NP = N + (N >> 5) + 2;
-    cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + NP;
-    cf2 *s_nco = buf1 + NP;
+    cf2 *X = (cf2 *)smem;
+    cf2 *s_nco = X + NP;
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];
 
     const int64_t o0 = (int64_t)blockIdx.x * V;
 #pragma unroll 4
     for (int p = tid; p < N; p += T) {
         const int64_t fi = o0 + p;
-        buf0[sw(p)] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+        X[sw(p)] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
     }
     __syncthreads();
-    cf2 *X = fft16_lds(buf0, buf1, a.twiddle, N, a.log2n, tid, T);
-    cf2 *other = (X == buf0) ? buf1 : buf0;
+    fft16_lds(X, a.twiddle, N, a.log2n, tid, T);
 #pragma unroll 4
     for (int p = tid; p < N; p += T) {
         const cf2 z = cmulf(X[sw(p)], a.hfreq[p]);
         X[sw(p)] = cf2{z.x, -z.y};
     }
     __syncthreads();
-    cf2 *Y = fft16_lds(X, other, a.twiddle, N, a.log2n, tid, T);
+    fft16_lds(X, a.twiddle, N, a.log2n, tid, T);
+    cf2 *Y = X;
     const int64_t left = a.n_emit - o0;
     const int nv = left < (int64_t)V ? (int)left : V;
     for (int i = tid; i < nv; i += T) {
@@ -288,7 +297,7 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
         const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
         if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
         const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
-        const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
+        const size_t lds = (size_t)(N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)k_fftconv16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
