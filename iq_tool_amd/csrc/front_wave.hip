@@ -149,7 +149,7 @@ __device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32
 // EDGE = false: every tile (and the one after the last, for the prefetch) lies inside the call's
 //               new, aligned frames and outside the history the call leaves behind.
 // EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
-template <int BPS, bool EDGE, bool FAST>
+template <int BPS, bool EDGE, bool FAST, bool S0>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
@@ -161,6 +161,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
     }
     constexpr int VB = BPS ? BPS : 4;
+    constexpr int NC = S0 ? 1 : 2;                  // 256-frame chunks per tile: S0 = no half-band stage, a tile
+    constexpr int TILE = 256 * NC;                  // is 256 input frames = 256 polyphase-input samples
     char *XE = w.XE, *XO = w.XO, *HB = w.HB;
 
     // output bookkeeping (wave-uniform): first output whose half-band sample is >= this run's first
@@ -186,17 +188,17 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     v2f cs_n[2][4];
     auto nco_lookup = [&](int64_t tile_first) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             uint32_t th = a.nco_theta0 + ((uint32_t)tile_first + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
 #pragma unroll
             for (int s = 0; s < 4; ++s) { cs_n[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
         }
     };
     if (!EDGE) {
-        const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * VB + 4 * VB * lane;
+        const char *src = (const char *)a.raw + (t_begin * TILE - a.rem0) * VB + 4 * VB * lane;
         load_chunk<VB>(src, nxt[0]);
-        load_chunk<VB>(src + 256 * VB, nxt[1]);
-        if (nco_on) nco_lookup(t_begin * kWTile);
+        if (NC == 2) load_chunk<VB>(src + 256 * VB, nxt[1]);
+        if (nco_on) nco_lookup(t_begin * TILE);
     }
 
     // cs16 output of the streaming variant: a tile's four packed dwords are held in registers and
@@ -222,7 +224,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     STAMP_DECL
     STAMP_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
-        const int64_t i0 = t * kWTile;
+        const int64_t i0 = t * TILE;
         const int64_t j0 = i0 - a.rem0;
         const bool emit = t >= t_emit0;
 
@@ -234,7 +236,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             if (FAST) {
                 // cs16 left unnormalised: the 2^-15 lives in this kernel's copy of the NCO table (exact)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         x[c][s].x = (float)(short)(nxt[c].w[s] & 0xffffu);
@@ -242,23 +244,23 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     }
             } else {
                 unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
-                unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
+                if (NC == 2) unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             }
             STAMP(0);
             if (defer) flush_pending();
             {
-                const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
+                const char *src = (const char *)a.raw + (j0 + TILE) * VB + 4 * VB * lane;
                 load_chunk<VB>(src, nxt[0]);
-                load_chunk<VB>(src + 256 * VB, nxt[1]);
+                if (NC == 2) load_chunk<VB>(src + 256 * VB, nxt[1]);
             }
             if (!FAST && a.dc_enable) {
                 if (!dc_started) { const cd2 cv = a.dc_carry[seg]; dc_vr = (float)cv.x; dc_vi = (float)cv.y; dc_started = true; }
                 dc_chunk(a, lane, lane_pow, x[0], 0u, dc_vr, dc_vi);
-                dc_chunk(a, lane, lane_pow, x[1], 0u, dc_vr, dc_vi);
+                if (NC == 2) dc_chunk(a, lane, lane_pow, x[1], 0u, dc_vr, dc_vi);
             }
             if (!FAST && a.iq_enable) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const float re = x[c][s].x;
@@ -269,7 +271,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             if (nco_on) {
                 // the eight phasors were looked up while the previous tile was in flight (below)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const v2f y = pk_cmul(v2f{x[c][s].x, x[c][s].y}, cs_n[c][s]);
@@ -281,7 +283,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             // every operator, frames past the end of the call are zeros
             unsigned hist_mask[2] = {0u, 0u}, new_mask[2] = {0u, 0u};
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 const int64_t j = j0 + 256 * c + 4 * lane;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -299,7 +301,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     x[c][s] = v;
                 }
             }
-            if (!FAST && a.dc_enable && (dc_started || j0 + kWTile > 0)) {
+            if (!FAST && a.dc_enable && (dc_started || j0 + TILE > 0)) {
                 if (!dc_started) {
                     // state before the run's first new sample, moved back over the history positions of this
                     // tile that precede it (they feed zeros into the recurrence)
@@ -310,10 +312,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     dc_started = true;
                 }
                 dc_chunk(a, lane, lane_pow, x[0], hist_mask[0], dc_vr, dc_vi);
-                dc_chunk(a, lane, lane_pow, x[1], hist_mask[1], dc_vr, dc_vi);
+                if (NC == 2) dc_chunk(a, lane, lane_pow, x[1], hist_mask[1], dc_vr, dc_vi);
             }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 const int l4 = 256 * c + 4 * lane;
                 uint32_t th = a.nco_theta0 + ((uint32_t)i0 + (uint32_t)l4) * a.nco_dtheta;
 #pragma unroll
@@ -334,24 +336,31 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 }
             }
         }
+        if (S0) {
+            // no half-band stage: the lane's four samples ARE its polyphase-input row
+            char *ph = HB + (lane + 4) * kRowB;
+            *(float4 *)ph = make_float4(x[0][0].x, x[0][0].y, x[0][1].x, x[0][1].y);
+            *(float4 *)(ph + 16) = make_float4(x[0][2].x, x[0][2].y, x[0][3].x, x[0][3].y);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int off = woff + 32 * c * kRowB;
-            *(float4 *)(XE + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
-            *(float4 *)(XO + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+            for (int c = 0; c < NC; ++c) {
+                const int off = woff + 32 * c * kRowB;
+                *(float4 *)(XE + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
+                *(float4 *)(XO + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // the rows that become the next tile's history are read back NOW (queued right behind the writes)
         // and stored at the end of the tile: by then the data is long there, so the slide costs no LDS
         // round trip of its own
         float sl_e = 0.f, sl_o = 0.f, sl_h = 0.f;
-        if (lane < 60) { sl_e = *(const float *)(XE + 64 * kRowB + lane * 4); sl_o = *(const float *)(XO + 64 * kRowB + lane * 4); }
-        if (nco_on) nco_lookup(i0 + kWTile);
+        if (!S0 && lane < 60) { sl_e = *(const float *)(XE + 64 * kRowB + lane * 4); sl_o = *(const float *)(XO + 64 * kRowB + lane * 4); }
+        if (nco_on) nco_lookup(i0 + TILE);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
 
         // ------------------------------------------------------------ half-band: 4 outputs per lane
-        {
+        if (!S0) {
             const char *we = XE + lane * kRowB;
             v2f E[24];
 #pragma unroll
@@ -478,7 +487,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         {
             // the last 5 (XE, XO) / 4 (HB) rows become the history rows of the next tile.  One dword per
             // lane: a ds_write_b32 costs 4 LDS cycles whatever the lane count, a ds_write_b128 13.
-            if (lane < 60) { *(float *)(XE + lane * 4) = sl_e; *(float *)(XO + lane * 4) = sl_o; }
+            if (!S0 && lane < 60) { *(float *)(XE + lane * 4) = sl_e; *(float *)(XO + lane * 4) = sl_o; }
             if (lane < 48) *(float *)(HB + lane * 4) = sl_h;
         }
         __builtin_amdgcn_wave_barrier();
@@ -491,7 +500,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 // BPS: bytes per input frame on the vector-load path (2, 4, 8); 0 = no vector path for this format
 //      FAST: cs16 in, unit gain, no iq correction, pre NCO on, no post NCO, cs16 out (the NRSC-5 preset
 //      shape) -- the same arithmetic with every run-time switch resolved at compile time
-template <int BPS, bool FAST>
+//      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
+//      256-frame tiles, the mixed samples go straight to the polyphase rows
+template <int BPS, bool FAST, bool S0 = false>
 __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -541,13 +552,13 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
         const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + (a.w_fast_g1 - a.w_fast_g0));   // DcGeom mode 1 order
-        run_tiles<BPS, true, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        run_tiles<BPS, true, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
         if (g >= a.w_fast_g1) return;
         const int64_t t0 = g * a.w_tiles_per_wave;
         const int seg = (int)(a.w_n_edge1 + (gw - a.w_n_edge));
-        if (BPS != 0) run_tiles<BPS, false, FAST>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
+        if (BPS != 0) run_tiles<BPS, false, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
     }
 }
 
@@ -573,18 +584,33 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     } while (0)
     const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
                       a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
-    if (cls == 2) IQGPU_LAUNCH_S1(2, false);
+#define IQGPU_LAUNCH_S0(BPS)                                                                                          \
+    do {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, false, true>,                                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        if (e != hipSuccess) return e;                                                                                \
+        hipLaunchKernelGGL((k_front_s1<BPS, false, true>), dim3(grid), dim3(kWThreads), lds, s, a);                   \
+    } while (0)
+    if (a.S == 0) {
+        if (cls == 2) IQGPU_LAUNCH_S0(2);
+        else if (cls == 4) IQGPU_LAUNCH_S0(4);
+        else if (cls == 8) IQGPU_LAUNCH_S0(8);
+        else IQGPU_LAUNCH_S0(0);
+    }
+    else if (cls == 2) IQGPU_LAUNCH_S1(2, false);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false);
     else if (cls == 8) IQGPU_LAUNCH_S1(8, false);
     else IQGPU_LAUNCH_S1(0, false);
+#undef IQGPU_LAUNCH_S0
 #undef IQGPU_LAUNCH_S1
     return hipGetLastError();
 }
 
 // Splits the call's tiles into streaming sub-blocks (all tiles vector-loadable) and edge runs.
-void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tpw)
+void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tpw, int tile_frames)
 {
+    const int kWTile = tile_frames;                 // 512 with a half-band stage in the kernel, 256 without
     const int64_t total = a.w_total_tiles;
     int vb;
     switch (a.in_fmt) {

@@ -700,7 +700,9 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     // ---- run geometry of the wave-autonomous kernels (needed by the dc carries as well) ----
     //   S >= 2: k_cascade (stages 0 .. S-2) + k_front_s1 (last stage);  S == 1: k_front_s1
     const bool casc = c->cascade && !c->force_generic;
-    const bool fast_s1 = c->decim && c->S == 1 && c->rp.stages[0].m == 10 && !c->force_generic;
+    const bool fast_s0 = c->decim && c->S == 0 && !c->force_generic;          // polyphase only, 256-frame tiles
+    const bool fast_s1 = fast_s0 || (c->decim && c->S == 1 && c->rp.stages[0].m == 10 && !c->force_generic);
+    const int wtile = fast_s0 ? 256 : kWTile;
     const int casc_K = c->S - 1;
     const int rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : c->rem;
     FrontArgs cplan{};
@@ -708,9 +710,10 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
         cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
-        cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + kWTile - 1) / kWTile;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles),
-                      casc ? c->casc_warm : (int)((c->rp.history_in + kWTile - 1) / kWTile), 4);
+        cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
+        int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
+        if (warm < 1) warm = 1;
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles), warm, 4, wtile);
     }
     auto copy_plan = [&](FrontArgs &dst) {
         dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
@@ -728,7 +731,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             dg.mode = 1;
             dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
             dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
-            dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k;
+            dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k; dg.tile = wtile;
             dg.n_seg = (int)(cplan.w_n_edge + dg.n_stream);
             if (dg.n_seg < 1) dg.n_seg = 1;
         } else {
@@ -812,7 +815,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         // wave-autonomous fast path: one half-band stage (m = 10)
         if (fast_s1) {
             copy_plan(a);
-            for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
+            if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
             a.sink = c->d_sink;
         }
         if (casc) {

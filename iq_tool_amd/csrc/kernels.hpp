@@ -102,7 +102,7 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set)
-void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tiles_per_wave);
+void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile);
 
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
@@ -123,7 +123,7 @@ struct DcGeom {
     // mode 1: runs in stream order -- n_edge1 edge runs of edge_tpw tiles from tile 0, n_stream streaming runs
     // of tpw tiles from tile g0 * tpw, then edge runs from tile tb; a run starts warm tiles early
     int64_t n_edge1, n_stream, edge_tpw, tpw, g0, tb;
-    int32_t warm, rem0;
+    int32_t warm, rem0, tile;   // tile: input frames per tile of the wave kernel (512, or 256 without a half-band)
 };
 IQGPU_HD inline int64_t dc_seg_start(const DcGeom &g, int s)
 {
@@ -136,7 +136,7 @@ IQGPU_HD inline int64_t dc_seg_start(const DcGeom &g, int s)
         if (s < g.n_edge1) t0 = (int64_t)s * g.edge_tpw;
         else if (s < g.n_edge1 + g.n_stream) t0 = (g.g0 + (s - g.n_edge1)) * g.tpw;
         else t0 = g.tb + (s - g.n_edge1 - g.n_stream) * g.edge_tpw;
-        v = (t0 - g.warm) * 512 - g.rem0;
+        v = (t0 - g.warm) * g.tile - g.rem0;
     }
     if (v < 0) v = 0;
     if (v > g.frames_in) v = g.frames_in;

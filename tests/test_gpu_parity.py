@@ -442,6 +442,35 @@ def test_nrsc5_chain_with_dc_blocker_wave_kernel(gpu, oracle, monkeypatch, fmt_o
         int_close(slow, got, min_same=0.999)
 
 
+@pytest.mark.parametrize("variant", ["plain", "dc", "usb_filter_agc", "cf32_shift"])
+def test_s0_chain_cu8_nrsc5_preset_shape(gpu, oracle, monkeypatch, variant):
+    """0.5 <= r < 1 (no half-band stage): the cu8-nrsc5 presets, 2.4 MS/s -> 1.488375 MS/s
+    (iq_tool_presets.conf:190-214), run in the S0 instantiation of the wave kernel"""
+    n = 900005
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0)
+    if variant == "dc":
+        kw.update(dc_block=True, shift_hz=-100e3)
+    elif variant == "usb_filter_agc":
+        kw.update(filters=(("passband", 158.5e3, 113e3),), agc=True)
+    elif variant == "cf32_shift":
+        kw.update(in_format="cs16", out_format="cf32", shift_hz=250e3, gain=1.3)
+    raw = synth.raw_stream(n, 2.4e6, 45, kw["in_format"])
+    ch = gpu.Chain(**kw)
+    assert ch.info().num_halfband_stages == 0
+    want = run_oracle(oracle, raw, **kw)
+    splits = [16384 * 20, 16384 * 30, n - 16384 * 50] if kw.get("agc") else [5, 400000, 1, n - 400006]
+    got = run_gpu(gpu, raw, splits=splits, **kw)
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = run_gpu(gpu, raw, **kw)
+    monkeypatch.delenv("IQGPU_FORCE_GENERIC")
+    assert got.size == want.size == slow.size
+    if kw["out_format"] == "cf32":
+        assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL and np.abs(cf(slow) - cf(got)).max() <= 6e-6
+    else:
+        int_close(got, want, min_same=0.95)
+        int_close(slow, got, min_same=0.99)
+
+
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
     n = 1 << 20
     raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
