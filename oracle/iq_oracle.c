@@ -1063,3 +1063,125 @@ size_t orc_chain_process(orc_chain *c, const void *raw_in, size_t frames_in, voi
     }
     return total_out;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Three stage threads over chunk trays, ref: src/pipeline.c:96-116 (thread creation), 436-490
+ * (pre-processor loop), 492-537 (resampler loop), 539-595 (post-processor loop); queue.c.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+#define ORC_TRAYS 8
+typedef struct {
+    orc_cf32 *A, *B;
+    const char *raw; size_t n;       /* input frames of this chunk */
+    unsigned nf, nw;                 /* frames after pre / after resampler */
+    int last;
+} orc_tray;
+typedef struct {
+    orc_tray *slot[ORC_TRAYS + 1]; int head, tail;
+    pthread_mutex_t mu; pthread_cond_t cv;
+} orc_queue;
+static void q_init(orc_queue *q) { q->head = q->tail = 0; pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL); }
+static void q_put(orc_queue *q, orc_tray *t)
+{
+    pthread_mutex_lock(&q->mu);
+    q->slot[q->tail] = t; q->tail = (q->tail + 1) % (ORC_TRAYS + 1);
+    pthread_cond_signal(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+}
+static orc_tray *q_get(orc_queue *q)
+{
+    orc_tray *t;
+    pthread_mutex_lock(&q->mu);
+    while (q->head == q->tail) pthread_cond_wait(&q->cv, &q->mu);
+    t = q->slot[q->head]; q->head = (q->head + 1) % (ORC_TRAYS + 1);
+    pthread_mutex_unlock(&q->mu);
+    return t;
+}
+typedef struct {
+    orc_chain *c; const char *raw; size_t frames; char *out; size_t total_out;
+    orc_queue free_q, pre_q, rs_q;
+} orc_pipe;
+
+static void *pre_thread(void *arg)
+{
+    orc_pipe *p = (orc_pipe *)arg; orc_chain *c = p->c; const orc_chain_desc *d = &c->d;
+    size_t ibps = orc_bytes_per_sample(d->in_format), done = 0;
+    for (;;) {
+        orc_tray *t = q_get(&p->free_q);
+        size_t n = p->frames - done; if (n > ORC_CHUNK) n = ORC_CHUNK;
+        t->last = (n == 0); t->n = n; t->nf = 0;
+        if (n) {
+            orc_convert_block_to_cf32(p->raw + done * ibps, t->A, n, d->in_format, d->gain);
+            if (c->dc) orc_dcblock_apply(c->dc, t->A, n);
+            if (d->iq_correct_enable) orc_iq_correct_apply(t->A, n, c->iq_mag, c->iq_phase);
+            if (c->pre_nco) orc_nco_mix_block(c->pre_nco, d->shift_hz >= 0, t->A, t->A, n);
+            t->nf = (unsigned)n;
+            if (c->filt && !c->filt->post) t->nf = orc_filter_apply(c->filt, t->A, t->nf, t->A);
+            done += n;
+        }
+        {   /* the tray may be recycled the moment it is handed on: decide first */
+            const int last = t->last;
+            q_put(&p->pre_q, t);
+            if (last) return NULL;
+        }
+    }
+}
+static void *rs_thread(void *arg)
+{
+    orc_pipe *p = (orc_pipe *)arg; orc_chain *c = p->c;
+    for (;;) {
+        orc_tray *t = q_get(&p->pre_q);
+        t->nw = 0;
+        if (!t->last && t->nf) {
+            if (c->rs) orc_msresamp_execute(c->rs, t->A, t->nf, t->B, &t->nw);
+            else { memcpy(t->B, t->A, (size_t)t->nf * sizeof(orc_cf32)); t->nw = t->nf; }
+        }
+        {
+            const int last = t->last;
+            q_put(&p->rs_q, t);
+            if (last) return NULL;
+        }
+    }
+}
+static void *post_thread(void *arg)
+{
+    orc_pipe *p = (orc_pipe *)arg; orc_chain *c = p->c; const orc_chain_desc *d = &c->d;
+    size_t obps = orc_bytes_per_sample(d->out_format);
+    for (;;) {
+        orc_tray *t = q_get(&p->rs_q);
+        int last = t->last;
+        if (!last && t->nw) {
+            orc_cf32 *cur = t->B, *other = t->A; unsigned nw = t->nw;
+            if (c->filt && c->filt->post) {
+                int fft = (c->filt->impl == ORC_FI_FFT_SYM || c->filt->impl == ORC_FI_FFT_ASYM);
+                if (fft) { nw = orc_filter_apply(c->filt, cur, nw, other); { orc_cf32 *x = cur; cur = other; other = x; } }
+                else nw = orc_filter_apply(c->filt, cur, nw, cur);
+            }
+            if (c->post_nco && nw) { orc_nco_mix_block(c->post_nco, d->shift_hz >= 0, cur, other, nw); { orc_cf32 *x = cur; cur = other; other = x; } }
+            if (nw && c->agc) orc_agc_apply(c->agc, cur, nw);
+            if (nw) { orc_convert_cf32_to_block(cur, p->out + p->total_out * obps, nw, d->out_format); p->total_out += nw; }
+        }
+        q_put(&p->free_q, t);
+        if (last) return NULL;
+    }
+}
+
+size_t orc_chain_process_pipelined(orc_chain *c, const void *raw_in, size_t frames_in, void *out)
+{
+    orc_pipe p; orc_tray trays[ORC_TRAYS]; pthread_t th[3]; int i;
+    memset(&p, 0, sizeof(p));
+    p.c = c; p.raw = (const char *)raw_in; p.frames = frames_in; p.out = (char *)out;
+    q_init(&p.free_q); q_init(&p.pre_q); q_init(&p.rs_q);
+    for (i = 0; i < ORC_TRAYS; i++) {
+        trays[i].A = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));
+        trays[i].B = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));
+        q_put(&p.free_q, &trays[i]);
+    }
+    pthread_create(&th[0], NULL, pre_thread, &p);
+    pthread_create(&th[1], NULL, rs_thread, &p);
+    pthread_create(&th[2], NULL, post_thread, &p);
+    for (i = 0; i < 3; i++) pthread_join(th[i], NULL);
+    for (i = 0; i < ORC_TRAYS; i++) { free(trays[i].A); free(trays[i].B); }
+    return p.total_out;
+}

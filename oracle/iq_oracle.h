@@ -167,6 +167,11 @@ size_t orc_chain_max_out_frames(const orc_chain *c, size_t frames_in);
 size_t orc_chain_process(orc_chain *c, const void *raw_in, size_t frames_in, void *out,
                          orc_cf32 *cf32_tap);
 
+/* The same stream through THREE concurrent stage threads (pre-processor, resampler, post-processor)
+ * handing 16384-frame chunks over bounded queues, as the reference runs it (src/pipeline.c:96-116,
+ * 436-595).  Same results as orc_chain_process; exists for bench.py's cpu_baseline ("cores": 3). */
+size_t orc_chain_process_pipelined(orc_chain *c, const void *raw_in, size_t frames_in, void *out);
+
 #ifdef __cplusplus
 }
 #endif

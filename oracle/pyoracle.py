@@ -120,6 +120,7 @@ def _proto(lib):
     P("orc_chain_ratio", C.c_float, [vp])
     P("orc_chain_max_out_frames", sz, [vp, sz])
     P("orc_chain_process", sz, [vp, vp, sz, vp, vp])
+    P("orc_chain_process_pipelined", sz, [vp, vp, sz, vp])
     return lib
 
 
@@ -451,6 +452,15 @@ class Chain:
 
     def max_out_frames(self, n):
         return self.L.orc_chain_max_out_frames(self.c, n)
+
+    def process_pipelined(self, raw):
+        """three concurrent stage threads, as the reference runs the chain (src/pipeline.c:96-116)"""
+        raw = np.ascontiguousarray(raw)
+        n = raw.nbytes // self.ibps
+        cap = self.max_out_frames(n) + 16384
+        out = np.empty(cap * self.obps, np.uint8)
+        k = self.L.orc_chain_process_pipelined(self.c, _ptr(raw), n, _ptr(out))
+        return out[:k * self.obps].view(NP_DTYPE[self.desc.out_format]).copy()
 
     def process(self, raw, want_cf32=False):
         raw = np.ascontiguousarray(raw)

@@ -441,3 +441,14 @@ def test_agc_in_chain_runs_between_post_nco_and_pack(oracle):
     assert np.array_equal(got.view(np.float32), want.view(np.float32))
     packed = oracle.Chain(out_format="cs16", agc=True, **kw).process(raw)
     assert np.array_equal(packed, oracle.from_cf32(want, "cs16"))
+
+
+def test_pipelined_three_thread_chain_equals_single_thread(oracle):
+    """bench.py's cpu_baseline arrangement (pre / resampler / post threads) changes no output byte"""
+    raw = synth.raw_stream(700001, 10e6, 46, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
+              iq_correct=True, iq_mag=0.01, iq_phase=-0.005, filters=(("passband", 158.5e3, 113e3),), filter_taps=1025, agc=True)
+    assert np.array_equal(oracle.Chain(**kw).process(raw), oracle.Chain(**kw).process_pipelined(raw))
+    kw = dict(in_format="cu8", out_format="cf32", input_rate_hz=1e6, target_rate_hz=3.3e6, shift_hz=1e5, shift_after_resample=True)
+    raw = synth.raw_stream(200000, 1e6, 47, "cu8")
+    assert np.array_equal(oracle.Chain(**kw).process(raw), oracle.Chain(**kw).process_pipelined(raw))
