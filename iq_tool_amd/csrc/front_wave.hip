@@ -34,11 +34,12 @@
 namespace iqgpu {
 
 constexpr int kXRows = 5 + 64;                              // 20 history + 256 samples per parity stream
-constexpr int kHRows = 4 + 64;                              // 16 history + 256 half-band outputs
-constexpr int kWaveLds = (2 * kXRows + kHRows) * kRowB;     // 9888 B per wave
+constexpr int kHRows = 4 + 64;                              // 16 history + 256 half-band outputs, aliased onto
+constexpr int kHBOff = 5;                                   //   XO rows kHBOff .. kHBOff + kHRows - 1
+constexpr int kWaveLds = (kXRows + kHBOff + kHRows) * kRowB; // 6816 B per wave
 constexpr int kTabLds = 1024 * 8 + 256 * 14 * 4;            // NCO {cos,sin} + polyphase taps [256][14]
 
-size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kWaves * kWaveLds; }
+size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveLds; }
 
 // smallest q with q * d >= x, for 0 < x < 2^32, 2^24 <= d <= 2^25 (quotient below 2^8).  The float
 // estimate of x / d is within 1e-4 of the truth, so its truncation is the exact floor or one off in
@@ -95,10 +96,6 @@ __device__ __forceinline__ int out_bytes(int fmt)
 
 struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };
 
-// For the lane's four half-band samples 4*lane .. 4*lane+3 of a tile whose first output has phase
-// delta0: which of them carry an output (hit), and the gather of that output's 14 taps (7 x
-// ds_read_b64 from the arm's 56-byte row; asm, so that they are not fused into half-rate
-// ds_read2_b64).  Returns with every tap landed.
 // first output at or after the lane's first half-band sample (4*lane), for a tile whose first
 // output has phase delta0 (< step): n0 = its index within the tile, Pl = its phase relative to 4*lane
 __device__ __forceinline__ void tap_phase(int lane, uint32_t delta0, uint32_t step, float inv_step, uint32_t &n0, uint32_t &Pl)
@@ -109,9 +106,9 @@ __device__ __forceinline__ void tap_phase(int lane, uint32_t delta0, uint32_t st
     Pl = (uint32_t)((uint64_t)delta0 + (uint64_t)n0 * step - (uint64_t)tgt);
 }
 
-__device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32_t step, bool hit[4], v2f tp[4][7])
+// hit pattern and LDS row address of each of the lane's four slots
+__device__ __forceinline__ void tap_rows(const WaveLds &w, uint32_t Pl, uint32_t step, bool hit[4], unsigned row[4])
 {
-    unsigned row[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         hit[r] = (Pl >> 24) == (uint32_t)r;
@@ -119,18 +116,15 @@ __device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32
         row[r] = w.arb_lds + (arm ^ (arm >> 5)) * 56u;
         if (hit[r]) Pl += step;
     }
-    // Two asm blocks with nothing between them; the second ends with the wait, so no instruction of
-    // the compiler's can touch a tap register while its read is in flight (tools/check_isa.py).
-    asm volatile(
-        "ds_read_b64 %0, %14\n\tds_read_b64 %1, %14 offset:8\n\tds_read_b64 %2, %14 offset:16\n\t"
-        "ds_read_b64 %3, %14 offset:24\n\tds_read_b64 %4, %14 offset:32\n\tds_read_b64 %5, %14 offset:40\n\t"
-        "ds_read_b64 %6, %14 offset:48\n\t"
-        "ds_read_b64 %7, %15\n\tds_read_b64 %8, %15 offset:8\n\tds_read_b64 %9, %15 offset:16\n\t"
-        "ds_read_b64 %10, %15 offset:24\n\tds_read_b64 %11, %15 offset:32\n\tds_read_b64 %12, %15 offset:40\n\t"
-        "ds_read_b64 %13, %15 offset:48"
-        : "=&v"(tp[0][0]), "=&v"(tp[0][1]), "=&v"(tp[0][2]), "=&v"(tp[0][3]), "=&v"(tp[0][4]), "=&v"(tp[0][5]), "=&v"(tp[0][6]),
-          "=&v"(tp[1][0]), "=&v"(tp[1][1]), "=&v"(tp[1][2]), "=&v"(tp[1][3]), "=&v"(tp[1][4]), "=&v"(tp[1][5]), "=&v"(tp[1][6])
-        : "v"(row[0]), "v"(row[1]));
+}
+
+// the taps of TWO slots: 7 x ds_read_b64 from each arm's 56-byte row (asm, so that they are not fused into
+// half-rate ds_read2_b64), ending with the wait -- no instruction of the compiler's can touch a tap
+// register while its read is in flight (tools/check_isa.py).  The four slots are gathered as two such
+// pairs with the first pair's 28 FMAs in between: 28 tap registers live instead of 56, which is what
+// lets the kernel run 4 waves per SIMD (128 VGPRs) without scratch spills.
+__device__ __forceinline__ void gather_taps2(unsigned row_a, unsigned row_b, v2f ta[7], v2f tb[7])
+{
     asm volatile(
         "ds_read_b64 %0, %14\n\tds_read_b64 %1, %14 offset:8\n\tds_read_b64 %2, %14 offset:16\n\t"
         "ds_read_b64 %3, %14 offset:24\n\tds_read_b64 %4, %14 offset:32\n\tds_read_b64 %5, %14 offset:40\n\t"
@@ -139,9 +133,9 @@ __device__ __forceinline__ void issue_taps(const WaveLds &w, uint32_t Pl, uint32
         "ds_read_b64 %10, %15 offset:24\n\tds_read_b64 %11, %15 offset:32\n\tds_read_b64 %12, %15 offset:40\n\t"
         "ds_read_b64 %13, %15 offset:48\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(tp[2][0]), "=&v"(tp[2][1]), "=&v"(tp[2][2]), "=&v"(tp[2][3]), "=&v"(tp[2][4]), "=&v"(tp[2][5]), "=&v"(tp[2][6]),
-          "=&v"(tp[3][0]), "=&v"(tp[3][1]), "=&v"(tp[3][2]), "=&v"(tp[3][3]), "=&v"(tp[3][4]), "=&v"(tp[3][5]), "=&v"(tp[3][6])
-        : "v"(row[2]), "v"(row[3])
+        : "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]),
+          "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6])
+        : "v"(row_a), "v"(row_b)
         : "memory");
 }
 
@@ -221,6 +215,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             pend_cnt = 0;
         }
     };
+    float sl_hist = 0.0f;         // one dword per lane (< 48) of the last 4 rows of the polyphase input
     STAMP_DECL
     STAMP_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
@@ -338,6 +333,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         }
         if (S0) {
             // no half-band stage: the lane's four samples ARE its polyphase-input row
+            if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;         // history rows of the polyphase input
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(x[0][0].x, x[0][0].y, x[0][1].x, x[0][1].y);
             *(float4 *)(ph + 16) = make_float4(x[0][2].x, x[0][2].y, x[0][3].x, x[0][3].y);
@@ -353,7 +349,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         // the rows that become the next tile's history are read back NOW (queued right behind the writes)
         // and stored at the end of the tile: by then the data is long there, so the slide costs no LDS
         // round trip of its own
-        float sl_e = 0.f, sl_o = 0.f, sl_h = 0.f;
+        float sl_e = 0.f, sl_o = 0.f;
         if (!S0 && lane < 60) { sl_e = *(const float *)(XE + 64 * kRowB + lane * 4); sl_o = *(const float *)(XO + 64 * kRowB + lane * 4); }
         if (nco_on) nco_lookup(i0 + TILE);
         __builtin_amdgcn_sched_barrier(0);
@@ -382,12 +378,17 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk_fma_hi_s(acc[r], tp, E[19 + r - 2 * q2]);
             }
+            // The half-band output rows live ON TOP of the odd-stream rows (HB row h = XO row h + 5): every read of
+            // the odd stream for this tile has been issued above, so its data rows are dead.  The 4 history rows of
+            // the half-band output (the previous tile's last rows, kept in sl_hist) are put back first: they share
+            // XO rows 5 .. 8, which this tile's pointwise phase has just used.
+            if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
             *(float4 *)(ph + 16) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < 48) sl_h = *(const float *)(HB + 64 * kRowB + lane * 4);
+        if (lane < 48) sl_hist = *(const float *)(HB + 64 * kRowB + lane * 4);
         __builtin_amdgcn_sched_barrier(0);
 
         // ------------------------------------------------------------ polyphase + pack
@@ -416,16 +417,21 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     tap_phase(lane, delta0, step, inv_step, n0, Pl);
                 }
                 bool hit[4];
-                v2f tp[4][7];
-                issue_taps(w, Pl, step, hit, tp);
-                STAMP(3);
+                unsigned row[4];
+                tap_rows(w, Pl, step, hit, row);
                 v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
-                for (int n2 = 0; n2 < 7; ++n2) {
+                for (int half = 0; half < 2; ++half) {
+                    v2f ta[7], tb[7];
+                    gather_taps2(row[2 * half], row[2 * half + 1], ta, tb);
+                    STAMP(3);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pk_fma_lo(y[r], tp[r][n2], H[14 + r - 2 * n2]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pk_fma_hi(y[r], tp[r][n2], H[13 + r - 2 * n2]);
+                    for (int n2 = 0; n2 < 7; ++n2) {
+                        pk_fma_lo(y[2 * half], ta[n2], H[14 + 2 * half - 2 * n2]);
+                        pk_fma_lo(y[2 * half + 1], tb[n2], H[15 + 2 * half - 2 * n2]);
+                        pk_fma_hi(y[2 * half], ta[n2], H[13 + 2 * half - 2 * n2]);
+                        pk_fma_hi(y[2 * half + 1], tb[n2], H[14 + 2 * half - 2 * n2]);
+                    }
                 }
                 STAMP(4);
                 // half-band samples of this tile that exist in this call
@@ -485,10 +491,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         STAMP(5);
         // ------------------------------------------------------------ slide the windows
         {
-            // the last 5 (XE, XO) / 4 (HB) rows become the history rows of the next tile.  One dword per
+            // the last 5 rows of XE / XO become the history rows of the next tile.  One dword per
             // lane: a ds_write_b32 costs 4 LDS cycles whatever the lane count, a ds_write_b128 13.
             if (!S0 && lane < 60) { *(float *)(XE + lane * 4) = sl_e; *(float *)(XO + lane * 4) = sl_o; }
-            if (lane < 48) *(float *)(HB + lane * 4) = sl_h;
         }
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
@@ -503,7 +508,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 template <int BPS, bool FAST, bool S0 = false>
-__global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
+__global__ __launch_bounds__(kS1Threads) void k_front_s1(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
     WaveLds w;
     w.XE = (char *)smem + kTabLds + wave * kWaveLds;
     w.XO = w.XE + kXRows * kRowB;
-    w.HB = w.XO + kXRows * kRowB;
+    w.HB = w.XO + kHBOff * kRowB;
     w.nco = s_nco; w.arb = s_arb;
     w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;   // LDS byte address
 
@@ -522,20 +527,20 @@ __global__ __launch_bounds__(kWThreads) void k_front_s1(const FrontArgs a)
         // FAST: the cs16 normaliser 2^-15 is folded into the table -- power-of-two scaling commutes with
         // every rounding of x * (c + j s), so the mixed samples are bit-identical
         const float scl = FAST ? 1.0f / 32768.0f : 1.0f;
-        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
+        for (int i = tid; i < 1024; i += kS1Threads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
     }
     // polyphase taps: arm a lives in row a ^ (a >> 5).  The arms that the lanes of one gather touch
     // form an arithmetic progression (mod 256); with plain 56-byte rows that lands 3.3x the cycles of
     // a conflict-free ds_read_b64 on MI355X for the NRSC-5 step, with the XOR-folded rows 1.1x
     // (tools/lds_gather_bench.hip).
-    for (int i = tid; i < 256 * 14; i += kWThreads) {
+    for (int i = tid; i < 256 * 14; i += kS1Threads) {
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
     for (int i = lane; i < kWaveLds / 16; i += 64) ((float4 *)w.XE)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t gw = (int64_t)blockIdx.x * kS1Waves + wave;
 #ifdef IQGPU_STAGGER
     // de-synchronise the 12 waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
     // otherwise march through them in lockstep, so that LDS time and VALU time add up
@@ -566,7 +571,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 {
     const size_t lds = front_s1_lds_bytes();
     const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
-    const unsigned grid = (unsigned)((n_items + kWaves - 1) / kWaves);
+    const unsigned grid = (unsigned)((n_items + kS1Waves - 1) / kS1Waves);
     if (grid == 0) return hipSuccess;
     int cls;
     switch (a.in_fmt) {
@@ -580,7 +585,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST>,                                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_front_s1<BPS, FAST>), dim3(grid), dim3(kWThreads), lds, s, a);                          \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST>), dim3(grid), dim3(kS1Threads), lds, s, a);                          \
     } while (0)
     const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
                       a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
@@ -589,7 +594,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, false, true>,                                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_front_s1<BPS, false, true>), dim3(grid), dim3(kWThreads), lds, s, a);                   \
+        hipLaunchKernelGGL((k_front_s1<BPS, false, true>), dim3(grid), dim3(kS1Threads), lds, s, a);                   \
     } while (0)
     if (a.S == 0) {
         if (cls == 2) IQGPU_LAUNCH_S0(2);

@@ -684,10 +684,10 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     if (n_blocks < 1) n_blocks = 1;
 
     // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
-    auto tiles_per_wave = [&](int64_t w_tiles) {
+    auto tiles_per_wave = [&](int64_t w_tiles, int waves = kWaves) {
         int64_t tpw64;
         if (c->auto_block) {
-            const int64_t slots = (int64_t)c->n_cu * kWaves;
+            const int64_t slots = (int64_t)c->n_cu * waves;
             tpw64 = (w_tiles + slots - 1) / slots;
             if (tpw64 < 16) tpw64 = 16;
         } else {
@@ -713,7 +713,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles), warm, 4, wtile);
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? kWaves : kS1Waves), warm, 4, wtile);
     }
     auto copy_plan = [&](FrontArgs &dst) {
         dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
@@ -850,7 +850,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
                 a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
                 a2.out_fmt = a.out_fmt; a2.out = a.out;
                 a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles), 1, 4);
+                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, kS1Waves), 1, 4);
                 for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
                 a2.sink = c->d_sink;
                 { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }

@@ -11,8 +11,13 @@ constexpr int kThreads = 256;      // 4 wavefronts of 64
 constexpr int kMaxS = 12;
 constexpr int kArbHist = 16;       // 13 needed, padded
 constexpr int kWTile = 512;        // input samples per wavefront tile (k_front_s1)
-constexpr int kWaves = 12;         // wavefronts per workgroup in k_front_s1 (3 per SIMD, 1 workgroup per CU)
+constexpr int kWaves = 12;         // wavefronts per workgroup in k_cascade (3 per SIMD, 1 workgroup per CU)
 constexpr int kWThreads = kWaves * 64;
+#ifndef IQGPU_S1_WAVES
+#define IQGPU_S1_WAVES 16
+#endif
+constexpr int kS1Waves = IQGPU_S1_WAVES;   // wavefronts per workgroup in k_front_s1 (4 per SIMD, 1 workgroup per CU)
+constexpr int kS1Threads = kS1Waves * 64;
 constexpr int kFirOutTile = 1024;  // outputs per workgroup tile in the FIR kernel
 constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
 constexpr int kFftMinTaps = 96;    // FIR-kind filters at least this long run as overlap-save (k_fftconv)

@@ -1,14 +1,12 @@
 #!/usr/bin/env python3
 """Static check of the hand-written asm in k_front_s1 (iq_tool_amd/csrc/front_wave.hip).
 
-The polyphase tap gather issues its 28 ds_read_b64 from two adjacent inline-asm blocks and waits for
-them with an `s_waitcnt lgkmcnt(0)` at the end of the second block.  hipcc does not know that the
-destination registers of asm loads are still in flight, so no instruction of its own that
-sits between the two blocks may touch a tap register before the data has landed.  This
+The polyphase tap gather issues ds_read_b64 from inline asm.  hipcc does not know that the destination
+registers of asm loads are still in flight, so every such block must wait for its own reads: this
 script compiles front_wave.hip to gfx950 ISA and verifies for every instantiation that
-  (1) each gather consists of two asm blocks and no instruction between them reads, copies or
-      overwrites a register that the first block's reads are still filling,
-  (2) the second block ends with s_waitcnt lgkmcnt(0),
+  (1) each asm block that reads LDS holds the 14 reads of one slot pair and ENDS with
+      s_waitcnt lgkmcnt(0) (nothing of the compiler's can then see a register that is still filling),
+  (2) there are two such blocks per polyphase section,
   (3) no asm global_load / buffer_load is left in the file (loads are compiler-managed).
 Exit code 0 = ok.  Run by __graft_entry__.build() and tests/test_host_logic.py."""
 import os
@@ -70,32 +68,17 @@ def check(lines):
                     errors.append("k_front_s1<%s>: asm VMEM load found: %s" % (bps, ins))
         gather = [b for b in blocks if b[2] and all(x.startswith("ds_read_b64") or x.startswith("s_waitcnt") for x in b[2])
                   and any(x.startswith("ds_read_b64") for x in b[2])]
-        if len(gather) % 2 != 0:
-            errors.append("k_front_s1<%s>: odd number of tap-gather asm blocks (%d)" % (bps, len(gather)))
+        if len(gather) % 2 != 0 or not gather:
+            errors.append("k_front_s1<%s>: %d tap-gather asm blocks (expected an even, non-zero number)" % (bps, len(gather)))
             continue
-        for a, b in zip(gather[0::2], gather[1::2]):
+        for g in gather:
             n_gathers += 1
-            # registers that the first block's reads are still filling
-            inflight = set()
-            for ins in a[2]:
-                m = re.match(r"ds_read_b64 v\[(\d+):(\d+)\]", ins)
-                if m:
-                    inflight |= set(range(int(m.group(1)), int(m.group(2)) + 1))
-            between = [x.strip() for x in fl[a[1] + 1:b[0]] if x.strip() and not x.strip().startswith(";")]
-            for ins in between:
-                touched = set()
-                for m in re.finditer(r"v\[(\d+):(\d+)\]", ins):
-                    touched |= set(range(int(m.group(1)), int(m.group(2)) + 1))
-                for m in re.finditer(r"\bv(\d+)\b", ins):
-                    touched.add(int(m.group(1)))
-                if touched & inflight:
-                    errors.append("k_front_s1<%s>: `%s` touches a tap register that is still in flight" % (bps, ins))
-            if sum(1 for x in a[2] if x.startswith("ds_read_b64")) != 14 or sum(1 for x in b[2] if x.startswith("ds_read_b64")) != 14:
-                errors.append("k_front_s1<%s>: gather blocks do not hold 14 + 14 reads" % bps)
-            if not b[2][-1].startswith("s_waitcnt lgkmcnt(0)"):
-                errors.append("k_front_s1<%s>: second gather block does not end with s_waitcnt lgkmcnt(0)" % bps)
-            if any(x.startswith("s_waitcnt") for x in a[2]):
-                errors.append("k_front_s1<%s>: unexpected wait inside the first gather block" % bps)
+            if sum(1 for x in g[2] if x.startswith("ds_read_b64")) != 14:
+                errors.append("k_front_s1<%s>: a gather block does not hold 14 reads" % bps)
+            if not g[2][-1].startswith("s_waitcnt lgkmcnt(0)"):
+                errors.append("k_front_s1<%s>: a gather block does not end with s_waitcnt lgkmcnt(0)" % bps)
+            if any(x.startswith("s_waitcnt") for x in g[2][:-1]):
+                errors.append("k_front_s1<%s>: unexpected wait inside a gather block" % bps)
     return errors, n_gathers
 
 
