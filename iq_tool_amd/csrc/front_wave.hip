@@ -39,7 +39,7 @@ constexpr int kHBOff = 5;                                   //   XO rows kHBOff 
 constexpr int kWaveLds = (kXRows + kHBOff + kHRows) * kRowB; // 6816 B per wave
 constexpr int kTabLds = 1024 * 8 + 256 * 14 * 4;            // NCO {cos,sin} + polyphase taps [256][14]
 
-size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveLds; }
+size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveLds; }   // the larger of the two shapes
 
 // smallest q with q * d >= x, for 0 < x < 2^32, 2^24 <= d <= 2^25 (quotient below 2^8).  The float
 // estimate of x / d is within 1e-4 of the truth, so its truncation is the exact floor or one off in
@@ -507,10 +507,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      shape) -- the same arithmetic with every run-time switch resolved at compile time
 //      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
+//      The FAST instantiation fits 4 waves per SIMD (121 VGPRs): 16 waves per workgroup; the others run 12.
 template <int BPS, bool FAST, bool S0 = false>
-__global__ __launch_bounds__(kS1Threads) void k_front_s1(const FrontArgs a)
+__global__ __launch_bounds__(FAST ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kThr = FAST ? kS1Threads : kWThreads, kWv = FAST ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf2   *s_nco = (cf2 *)smem;
@@ -527,20 +529,20 @@ __global__ __launch_bounds__(kS1Threads) void k_front_s1(const FrontArgs a)
         // FAST: the cs16 normaliser 2^-15 is folded into the table -- power-of-two scaling commutes with
         // every rounding of x * (c + j s), so the mixed samples are bit-identical
         const float scl = FAST ? 1.0f / 32768.0f : 1.0f;
-        for (int i = tid; i < 1024; i += kS1Threads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
+        for (int i = tid; i < 1024; i += kThr) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
     }
     // polyphase taps: arm a lives in row a ^ (a >> 5).  The arms that the lanes of one gather touch
     // form an arithmetic progression (mod 256); with plain 56-byte rows that lands 3.3x the cycles of
     // a conflict-free ds_read_b64 on MI355X for the NRSC-5 step, with the XOR-folded rows 1.1x
     // (tools/lds_gather_bench.hip).
-    for (int i = tid; i < 256 * 14; i += kS1Threads) {
+    for (int i = tid; i < 256 * 14; i += kThr) {
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
     for (int i = lane; i < kWaveLds / 16; i += 64) ((float4 *)w.XE)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    const int64_t gw = (int64_t)blockIdx.x * kS1Waves + wave;
+    const int64_t gw = (int64_t)blockIdx.x * kWv + wave;
 #ifdef IQGPU_STAGGER
     // de-synchronise the 12 waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
     // otherwise march through them in lockstep, so that LDS time and VALU time add up
@@ -567,11 +569,21 @@ __global__ __launch_bounds__(kS1Threads) void k_front_s1(const FrontArgs a)
     }
 }
 
+static bool front_s1_fast_shape(const FrontArgs &a)
+{
+    return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
+           !a.dc_enable && a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
+}
+// wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
+int front_s1_waves(const FrontArgs &a) { return front_s1_fast_shape(a) ? kS1Waves : kWaves; }
+
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 {
-    const size_t lds = front_s1_lds_bytes();
+    const bool fast = front_s1_fast_shape(a);
+    const int waves = fast ? kS1Waves : kWaves;
+    const size_t lds = (size_t)kTabLds + (size_t)waves * kWaveLds;
     const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
-    const unsigned grid = (unsigned)((n_items + kS1Waves - 1) / kS1Waves);
+    const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
     int cls;
     switch (a.in_fmt) {
@@ -580,34 +592,24 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_S1(BPS, FAST)                                                                                    \
+#define IQGPU_LAUNCH_S1(BPS, FAST, S0)                                                                                \
     do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST>,                                       \
+        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST, S0>,                                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_front_s1<BPS, FAST>), dim3(grid), dim3(kS1Threads), lds, s, a);                          \
-    } while (0)
-    const bool fast = a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
-                      a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
-#define IQGPU_LAUNCH_S0(BPS)                                                                                          \
-    do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, false, true>,                                \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_front_s1<BPS, false, true>), dim3(grid), dim3(kS1Threads), lds, s, a);                   \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0>), dim3(grid), dim3(waves * 64), lds, s, a);                     \
     } while (0)
     if (a.S == 0) {
-        if (cls == 2) IQGPU_LAUNCH_S0(2);
-        else if (cls == 4) IQGPU_LAUNCH_S0(4);
-        else if (cls == 8) IQGPU_LAUNCH_S0(8);
-        else IQGPU_LAUNCH_S0(0);
+        if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
+        else if (cls == 4) IQGPU_LAUNCH_S1(4, false, true);
+        else if (cls == 8) IQGPU_LAUNCH_S1(8, false, true);
+        else IQGPU_LAUNCH_S1(0, false, true);
     }
-    else if (cls == 2) IQGPU_LAUNCH_S1(2, false);
-    else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true);
-    else if (cls == 4) IQGPU_LAUNCH_S1(4, false);
-    else if (cls == 8) IQGPU_LAUNCH_S1(8, false);
-    else IQGPU_LAUNCH_S1(0, false);
-#undef IQGPU_LAUNCH_S0
+    else if (cls == 2) IQGPU_LAUNCH_S1(2, false, false);
+    else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
+    else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);
+    else if (cls == 8) IQGPU_LAUNCH_S1(8, false, false);
+    else IQGPU_LAUNCH_S1(0, false, false);
 #undef IQGPU_LAUNCH_S1
     return hipGetLastError();
 }

@@ -710,10 +710,13 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
         cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
+        cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
+        cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? kWaves : kS1Waves), warm, 4, wtile);
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? kWaves : front_s1_waves(cplan)), warm, 4, wtile);
     }
     auto copy_plan = [&](FrontArgs &dst) {
         dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
@@ -850,7 +853,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
                 a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
                 a2.out_fmt = a.out_fmt; a2.out = a.out;
                 a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, kS1Waves), 1, 4);
+                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, front_s1_waves(a2)), 1, 4);
                 for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
                 a2.sink = c->d_sink;
                 { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }

@@ -106,6 +106,7 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
+int front_s1_waves(const FrontArgs &a);   // needs S, formats, gain, iq / dc / nco switches
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set)
 void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile);
 
