@@ -289,11 +289,11 @@ __global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
     }
     if (a.nco_mode != 0) {
         const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;          // mix down: conj(phasor)
-        for (int i = tid; i < 1024; i += kWThreads) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x, sgn * v.y}; }
+        for (int i = tid; i < 1024; i += (int)blockDim.x) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x, sgn * v.y}; }
     }
     __syncthreads();
 
-    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t gw = (int64_t)blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
         const int keep = a.hist_cap - (int)a.frames_in;
         for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
@@ -323,11 +323,21 @@ bool cascade_supported(const int *m_run_order, int S)
     return m_run_order[S - 1] == 10;
 }
 
+// wavefronts per workgroup (one workgroup per CU): as many as the LDS slices allow, in whole waves per SIMD,
+// at most 12 (16 was measured on config 3, K = 1: 0.254 ms against 0.232 ms with 12)
+int cascade_waves(const FrontArgs &a)
+{
+    int w = (int)((160 * 1024 - 1024 * 8) / (a.casc_wave_lds > 0 ? a.casc_wave_lds : 1));
+    w &= ~3;
+    return w > kWaves ? kWaves : (w < 4 ? 4 : w);
+}
+
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
 {
-    const size_t lds = 1024 * 8 + (size_t)kWaves * a.casc_wave_lds;
+    const int waves = cascade_waves(a);
+    const size_t lds = 1024 * 8 + (size_t)waves * a.casc_wave_lds;
     const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
-    const unsigned grid = (unsigned)((n_items + kWaves - 1) / kWaves);
+    const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
     int cls;
     switch (a.in_fmt) {
@@ -341,7 +351,7 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
         hipError_t e = hipFuncSetAttribute((const void *)k_cascade<BPS>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                            (int)lds);                                                                 \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(kWThreads), lds, s, a);                                   \
+        hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(waves * 64), lds, s, a);                                   \
     } while (0)
     if (cls == 2) IQGPU_LAUNCH_CASC(2);
     else if (cls == 4) IQGPU_LAUNCH_CASC(4);

@@ -710,13 +710,18 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
         cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        if (casc) {
+            cplan.casc_K = casc_K;
+            for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
+            cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);
+        }
         cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
         cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
         cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? kWaves : front_s1_waves(cplan)), warm, 4, wtile);
+        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? cascade_waves(cplan) : front_s1_waves(cplan)), warm, 4, wtile);
     }
     auto copy_plan = [&](FrontArgs &dst) {
         dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;

@@ -103,6 +103,7 @@ constexpr int kCascMaxK = 4;
 bool cascade_supported(const int *m_run_order, int S);
 size_t cascade_wave_lds(const FrontArgs &a);
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
+int cascade_waves(const FrontArgs &a);    // needs casc_wave_lds
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
