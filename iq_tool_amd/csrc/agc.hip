@@ -26,6 +26,8 @@ __global__ __launch_bounds__(kThreads) void k_agc_peak(const AgcArgs a)
     const int c = blockIdx.x;
     const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
     const int64_t len = e - b;
+    // the scan walks the chunk lengths from this table instead of redoing the 64-bit divisions of the closed form
+    if (blockIdx.y == 0 && threadIdx.x == 0) a.chunk_len[c] = (int32_t)(len > 0 ? len : 0);
     if (len <= 0) return;
     const int64_t per = (len + a.splits - 1) / a.splits;
     const int64_t lo = b + (int64_t)blockIdx.y * per;
@@ -44,41 +46,79 @@ __global__ __launch_bounds__(kThreads) void k_agc_peak(const AgcArgs a)
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
 
+// ---- wave-level helpers on the data-parallel-primitive path (a dependent chain of ds_bpermute shuffles
+// costs ~250 cycles per step; the walk below is sequential, so that latency is its run time) ----
+// value of lane `src` (wave-uniform index) as a scalar broadcast
+__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double rl_d(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// inclusive scans over the 64 lanes: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast 15 / 31
+#define IQGPU_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xf, true)
+__device__ __forceinline__ int wave_scan_add(int v)
+{
+    v += IQGPU_DPP(v, 0x111, 0xf); v += IQGPU_DPP(v, 0x112, 0xf); v += IQGPU_DPP(v, 0x114, 0xf); v += IQGPU_DPP(v, 0x118, 0xf);
+    v += IQGPU_DPP(v, 0x142, 0xa); v += IQGPU_DPP(v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_max(float x)      // x >= 0
+{
+    int v = __float_as_int(x);                                // non-negative floats order like their bit patterns
+    v = max(v, IQGPU_DPP(v, 0x111, 0xf)); v = max(v, IQGPU_DPP(v, 0x112, 0xf)); v = max(v, IQGPU_DPP(v, 0x114, 0xf));
+    v = max(v, IQGPU_DPP(v, 0x118, 0xf)); v = max(v, IQGPU_DPP(v, 0x142, 0xa)); v = max(v, IQGPU_DPP(v, 0x143, 0xc));
+    return __int_as_float(v);
+}
+#undef IQGPU_DPP
+
 __global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
 {
     const int lane = threadIdx.x;
     AgcState st = *a.state;
     const float target = a.target;
     int64_t end_prev = 0;
+    // the batch's two table reads are issued one batch ahead: the walk is sequential, a global load per step
+    // would put ~1 us of latency on each of its n_chunks / 64 steps
+    int32_t len_nx = (lane < a.geom.n_chunks) ? a.chunk_len[lane] : 0;
+    unsigned long long p2_nx = (lane < a.geom.n_chunks) ? a.peak2[lane] : 0ull;
     for (int c0 = 0; c0 < a.geom.n_chunks; c0 += 64) {
         const int c = c0 + lane;
         const bool valid = c < a.geom.n_chunks;
-        const int64_t e_i = agc_out_end(a.geom, valid ? c : a.geom.n_chunks - 1);
-        int64_t b_i = __shfl_up(e_i, 1);
-        if (lane == 0) b_i = end_prev;
+        const int32_t len_i = len_nx;
+        const unsigned long long p2_i = p2_nx;
+        {
+            const int cn = c + 64;
+            len_nx = (cn < a.geom.n_chunks) ? a.chunk_len[cn] : 0;
+            p2_nx = (cn < a.geom.n_chunks) ? a.peak2[cn] : 0ull;
+        }
+        // chunk ends within the batch: inclusive prefix sum of the lengths k_agc_peak recorded
+        const int len_v = valid ? len_i : 0;
+        const int64_t e_i = end_prev + (int64_t)wave_scan_add(len_v);        // a batch holds < 2^31 samples
+        const int64_t b_i = e_i - (int64_t)len_v;
         const bool active = valid && e_i > b_i;                   // empty chunks never reach agc_apply
         const uint64_t seen_i = st.seen + (uint64_t)(b_i - end_prev);
-        const float pk = active ? (float)sqrt(__longlong_as_double((long long)a.peak2[c])) : 0.0f;
+        const float pk = active ? (float)sqrt(__longlong_as_double((long long)p2_i)) : 0.0f;
         const double t_i = a.clock_wall ? a.t_wall : (double)seen_i / a.rate;
         float gain_i = st.gain;
         int cur = 0;
 
         if (!st.locked) {                                         // agc.c:117-160
-            float run = pk;                                       // inclusive prefix max
-#pragma unroll
-            for (int k = 1; k < 64; k <<= 1) { const float o = __shfl_up(run, k); if (lane >= k) run = fmaxf(run, o); }
-            run = fmaxf(run, st.peak_memory);
+            float run = fmaxf(wave_scan_max(pk), st.peak_memory);    // inclusive prefix max
             const bool lock_here = active && ((double)seen_i / a.rate > (double)kAgcLockTime);
             const unsigned long long lm = __ballot(lock_here);
             const int first = lm ? __ffsll((long long)lm) - 1 : 64;
             const float safe = run < 1e-4f ? 1e-4f : run;
             gain_i = target / safe;
             const int last = first < 64 ? first : 63;
-            st.peak_memory = __shfl(run, last);
+            st.peak_memory = rl_f(run, last);
             if (first < 64) {
                 st.locked = 1;
-                st.gain = __shfl(gain_i, first);
-                st.last_strong = shfl_d(t_i, first);
+                st.gain = rl_f(gain_i, first);
+                st.last_strong = rl_d(t_i, first);
             }
             cur = first + 1;
         }
@@ -89,28 +129,32 @@ __global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
             const bool ratchet = cand && outp > 1.0f;
             const bool healthy = cand && !ratchet && outp > target * kAgcLower;
             const unsigned long long hmask = __ballot(healthy);
-            const unsigned long long before = hmask & ((1ull << lane) - 1ull);
-            double ls = st.last_strong;                           // last "strong" time seen by this chunk
-            const int src = before ? 63 - __clzll((long long)before) : lane;
-            const double t_src = shfl_d(t_i, src);
-            if (before) ls = t_src;
-            const bool creep = cand && !ratchet && !healthy && (t_i - ls > (double)kAgcHangTime);
+            const bool weak = cand && !ratchet && !healthy;
+            bool creep = false;
+            if (__ballot(weak) != 0ull) {                         // (rare) some chunk is below the lower threshold
+                const unsigned long long before = hmask & ((1ull << lane) - 1ull);
+                double ls = st.last_strong;                       // last "strong" time seen by this chunk
+                const int src = before ? 63 - __clzll((long long)before) : lane;
+                const double t_src = shfl_d(t_i, src);
+                if (before) ls = t_src;
+                creep = weak && (t_i - ls > (double)kAgcHangTime);
+            }
             const unsigned long long chg = __ballot(ratchet || creep);
             const int first = chg ? __ffsll((long long)chg) - 1 : 64;
             if (lane >= cur && lane < first) gain_i = g;
             const unsigned long long hm2 = first < 64 ? (hmask & ((1ull << first) - 1ull)) : hmask;
-            if (hm2) st.last_strong = shfl_d(t_i, 63 - __clzll((long long)hm2));
+            if (hm2) st.last_strong = rl_d(t_i, 63 - __clzll((long long)hm2));
             if (first < 64) {
                 const bool is_ratchet = (__ballot(ratchet) >> first) & 1ull;
-                const float pk_f = __shfl(pk, first);
-                if (is_ratchet) { st.gain = 0.99f / pk_f; st.last_strong = shfl_d(t_i, first); }
+                const float pk_f = rl_f(pk, first);
+                if (is_ratchet) { st.gain = 0.99f / pk_f; st.last_strong = rl_d(t_i, first); }
                 else st.gain = g * kAgcRecovery;
                 if (lane == first) gain_i = st.gain;
             }
             cur = first + 1;
         }
         if (valid) a.gain[c] = gain_i;
-        const int64_t e_last = __shfl(e_i, 63);
+        const int64_t e_last = end_prev + (int64_t)rl_i((int)(e_i - end_prev), 63);
         st.seen += (uint64_t)(e_last - end_prev);
         end_prev = e_last;
     }
@@ -139,7 +183,7 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
     hipError_t e = hipMemsetAsync(a.peak2, 0, (size_t)a.geom.n_chunks * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)a.geom.n_chunks, (unsigned)a.splits);
-    if (a.n_out > 0) hipLaunchKernelGGL(k_agc_peak, grid, dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_agc_peak, grid, dim3(kThreads), 0, s, a);                     // also fills chunk_len[]
     hipLaunchKernelGGL(k_agc_scan, dim3(1), dim3(64), 0, s, a);
     if (a.n_out > 0) hipLaunchKernelGGL(k_agc_apply, grid, dim3(kThreads), 0, s, a);
     return hipGetLastError();

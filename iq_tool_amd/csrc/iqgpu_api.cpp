@@ -930,9 +930,9 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
         if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
         int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
-        rc = c->agc_gain.ensure((size_t)g.n_chunks * sizeof(float)); if (rc) return rc;
+        rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
         ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
-        ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p; ga.state = c->d_agc_state;
+        ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p; ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
         ga.target = c->agc_target; ga.rate = c->target_rate;
         ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
         ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;

@@ -292,6 +292,7 @@ struct AgcArgs {
     int64_t    n_out;
     unsigned long long *peak2;// [n_chunks] max |x|^2 per chunk, double bits (zeroed before k_agc_peak)
     float     *gain;          // [n_chunks]
+    int32_t   *chunk_len;     // [n_chunks] outputs per chunk, written by k_agc_peak, read by k_agc_scan
     AgcState  *state;
     float      target;
     double     rate;          // config->target_rate
