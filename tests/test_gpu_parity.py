@@ -776,3 +776,32 @@ def test_random_chain_matches_oracle(gpu, oracle, seed):
         assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL * scale, kw
     else:
         int_close(got, want, min_same=0.9)
+
+
+# --------------------------------------------------------------------------------------------
+# run partitioning is invisible: any block_samples gives the same bytes as the default geometry
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("nrsc5", dict(NRSC5)),
+    ("nrsc5_dc_cf32", dict(NRSC5, out_format="cf32", dc_block=True)),
+    ("cascade_s3", dict(in_format="cu8", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=250e3, shift_hz=-1e5)),
+    ("cascade_dc_fft", dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
+                            iq_correct=True, iq_mag=0.01, iq_phase=-0.005, filters=(("passband", 158.5e3, 113e3),), filter_taps=1025)),
+    ("s0_cu8", dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0)),
+    ("pointwise", dict(in_format="cs16", out_format="cf32", input_rate_hz=1e6, target_rate_hz=1e6, no_resample=True, shift_hz=1e5, dc_block=True)),
+])
+def test_block_samples_does_not_change_results(gpu, name, kw):
+    n = 3000017
+    raw = synth.raw_stream(n, kw["input_rate_hz"], 60, kw["in_format"])
+    base = run_gpu(gpu, raw, **kw)
+    for bs in (2048, 32768, 1 << 20):
+        got = run_gpu(gpu, raw, splits=[n // 3, n - n // 3], **dict(kw, block_samples=bs))
+        assert got.size == base.size
+        if kw.get("dc_block"):
+            # the dc-blocker carry of a run is a rounded closed form: partitions differ in the last bits only
+            if base.dtype == np.float32:
+                assert np.abs(got - base).max() <= 2e-6
+            else:
+                assert np.abs(got.astype(np.int64) - base.astype(np.int64)).max() <= 1
+        else:
+            assert np.array_equal(got, base), (name, bs)
