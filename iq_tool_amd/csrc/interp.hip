@@ -23,6 +23,32 @@
 
 namespace iqgpu {
 
+// filter branch of one half-band interpolator: sum_t h[2t+1] x[i - 2m + 1 + t], t < 2m.
+// M > 0: compile-time semi-length (all 2M window reads in flight at once, two accumulator chains).
+template <int M>
+__device__ __forceinline__ cf2 interp_branch(const cf2 *p, const float *taps, int m_rt)
+{
+    float ar = 0.0f, ai = 0.0f;
+    if (M > 0) {
+        cf2 sv[M > 0 ? 2 * M : 1];
+#pragma unroll
+        for (int q = 0; q < 2 * M; ++q) sv[q] = p[q];
+        float br = 0.0f, bi = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 2 * M; q += 2) {
+            ar = fmaf(taps[q], sv[q].x, ar); ai = fmaf(taps[q], sv[q].y, ai);
+            br = fmaf(taps[q + 1], sv[q + 1].x, br); bi = fmaf(taps[q + 1], sv[q + 1].y, bi);
+        }
+        ar += br; ai += bi;
+    } else {
+        for (int q = 0; q < 2 * m_rt; ++q) {
+            const cf2 sv = p[q];
+            ar = fmaf(taps[q], sv.x, ar); ai = fmaf(taps[q], sv.y, ai);
+        }
+    }
+    return cf2{ar, ai};
+}
+
 __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -106,12 +132,13 @@ __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
                     y = src[li - m];
                 } else {
                     const cf2 *p = src + li - 2 * m + 1;
-                    float ar = 0.0f, ai = 0.0f;
-                    for (int q = 0; q < 2 * m; ++q) {
-                        const cf2 sv = p[q];
-                        ar = fmaf(taps[q], sv.x, ar); ai = fmaf(taps[q], sv.y, ai);
+                    const float *tg = a.hb_taps + a.tap_off[s];        // uniform global reads: taps in SGPRs
+                    switch (m) {
+                    case 3:  y = interp_branch<3>(p, tg, m); break;
+                    case 5:  y = interp_branch<5>(p, tg, m); break;
+                    case 10: y = interp_branch<10>(p, tg, m); break;
+                    default: y = interp_branch<0>(p, taps, m); break;
                     }
-                    y = cf2{ar, ai};
                 }
                 if (last) {
                     if (u < a.n_emit) {

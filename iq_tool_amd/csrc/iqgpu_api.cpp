@@ -680,7 +680,18 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     // ---- geometry of this call ----
     const int64_t span_samples = (int64_t)c->rem + (int64_t)frames_in;
     const int64_t total_tiles = (span_samples + kTile - 1) / kTile;
-    int n_blocks = (int)((total_tiles + c->tiles_per_block - 1) / c->tiles_per_block);
+    // blocks of the workgroup-tiled k_front: with block_samples = 0 sized from the call -- about eight blocks
+    // per CU, at least 16 tiles each when a block has to re-run a warm-up tile (decimating chains), any
+    // size for pointwise chains
+    int tpb = c->tiles_per_block;
+    if (c->auto_block) {
+        int64_t t = (total_tiles + (int64_t)c->n_cu * 8 - 1) / ((int64_t)c->n_cu * 8);
+        const int64_t t_min = c->decim ? 16 : 1;
+        if (t < t_min) t = t_min;
+        if (t > 128) t = 128;
+        tpb = (int)t;
+    }
+    int n_blocks = (int)((total_tiles + tpb - 1) / tpb);
     if (n_blocks < 1) n_blocks = 1;
 
     // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
@@ -744,8 +755,8 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
             if (dg.n_seg < 1) dg.n_seg = 1;
         } else {
             dg.mode = 0; dg.n_seg = n_blocks;
-            dg.seg_first = ((int64_t)c->tiles_per_block - c->warm_tiles) * kTile - c->rem;
-            dg.seg_len = (int64_t)c->tiles_per_block * kTile;
+            dg.seg_first = ((int64_t)tpb - c->warm_tiles) * kTile - c->rem;
+            dg.seg_len = (int64_t)tpb * kTile;
         }
         int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
         rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
@@ -813,7 +824,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         a.n_hb_taps = c->n_hb_taps; a.hb_taps = c->d_hb; a.arb_table = c->d_arb;
         a.step = c->rp.step; a.n_est = c->n_est; a.phi0 = c->phi;
         a.n_groups = p.n_groups; a.n_out = p.n_res;
-        a.total_tiles = total_tiles; a.tiles_per_block = c->tiles_per_block; a.warm_tiles = c->warm_tiles;
+        a.total_tiles = total_tiles; a.tiles_per_block = tpb; a.warm_tiles = c->warm_tiles;
         a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
         const bool nco_in_front = !filt && !c->late;     // otherwise the post NCO runs in the last stage
         a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
