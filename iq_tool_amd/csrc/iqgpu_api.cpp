@@ -700,7 +700,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (c->auto_block) {
             const int64_t slots = (int64_t)c->n_cu * waves;
             tpw64 = (w_tiles + slots - 1) / slots;
-            if (tpw64 < 16) tpw64 = 16;
+            if (tpw64 < 4) tpw64 = 4;               // short calls: more, shorter runs (each re-runs one warm-up tile)
         } else {
             tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
         }
