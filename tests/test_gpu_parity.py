@@ -699,6 +699,34 @@ def test_full_size_count_law_split_invariance_and_spot_parity(gpu, oracle):
     d_in.free(); d_out.free()
 
 
+def test_single_call_beyond_2_31_frames(gpu):
+    """more than 2^31 frames (8.6 GB of cs16) in ONE call: the count law holds and a split that straddles
+    frame 2^31 gives the same bytes -- 64-bit stream positions everywhere, 32-bit only where the SPEC wraps"""
+    import ctypes as C
+    import hashlib
+    from iq_tool_amd.chain import DeviceBuffer
+    frames = (1 << 31) + (1 << 22) + 4096
+    seg = synth.raw_stream(1 << 22, 2.4e6, 1, "cs16")
+    d_in = DeviceBuffer(((frames >> 22) + 1) * seg.nbytes)
+    for i in range((frames >> 22) + 1):
+        gpu.load().iqgpu_memcpy_h2d(0, C.c_void_p(d_in.ptr + i * seg.nbytes), seg.ctypes.data_as(C.c_void_p), seg.nbytes)
+    ch = gpu.Chain(**NRSC5)
+    cap = ch.max_out_frames(frames) * 4
+    d_out = DeviceBuffer(cap)
+    n1 = ch.process_device(d_in.ptr, frames, d_out.ptr, cap)
+    ch.synchronize()
+    assert n1 == -(-((frames >> 1) << 24) // ch.info().arb_step)
+    h1 = hashlib.sha256(d_out.download(n1 * 4).tobytes()).hexdigest()
+    ch2 = gpu.Chain(**NRSC5)
+    a = (1 << 31) - 777
+    na = ch2.process_device(d_in.ptr, a, d_out.ptr, cap)
+    nb = ch2.process_device(d_in.ptr + a * 4, frames - a, d_out.ptr + na * 4, cap - na * 4)
+    ch2.synchronize()
+    assert na + nb == n1
+    assert hashlib.sha256(d_out.download(n1 * 4).tobytes()).hexdigest() == h1
+    d_in.free(); d_out.free()
+
+
 # --------------------------------------------------------------------------------------------
 # randomised chains: every dispatch path (k_front / k_front_s1 / k_cascade / k_interp / k_fir /
 # k_fftconv / agc) against the oracle, with random call splits
