@@ -39,7 +39,6 @@ def test_library_exports_every_declared_symbol(lib):
     assert not missing, missing
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert set(names) == bound, (set(names) ^ bound)
-    import re
     hdr = open(os.path.join(ROOT, "include", "iqgpu.h")).read()
     assert lib.iqgpu_abi_version() == int(re.search(r"#define\s+IQGPU_ABI_VERSION\s+(\d+)", hdr).group(1))
 
