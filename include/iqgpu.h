@@ -185,7 +185,7 @@ int    iqgpu_chain_synchronize(iqgpu_chain *c);
 int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets every launch with HIP events  */
 int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
 
-/* diagnostic hook: copies the chain's 64 KiB scratch (store sink; per-phase cycle counters in builds
+/* diagnostic hook: copies the chain's 64 KiB scratch (per-phase cycle counters in builds
  * made with -DIQGPU_STAMPS) to the host and clears it */
 int    iqgpu_chain_debug_read_scratch(iqgpu_chain *c, void *host_64k);
 

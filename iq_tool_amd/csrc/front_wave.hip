@@ -1,11 +1,12 @@
-// front_wave.hip -- k_front_s1: the wave-autonomous fast path of the front kernel for chains with
-// ONE half-band stage (0.25 <= r < 0.5: the NRSC-5 preset 2.4 MS/s -> 744.1875 kS/s is the
-// headline case).  Same arithmetic and stream bookkeeping as k_front (kernels.hip); what differs is
-// the mapping onto CDNA4:
+// front_wave.hip -- k_front_s1: the wave-autonomous front kernel for chains with ONE half-band stage
+// (0.25 <= r < 0.5: the NRSC-5 preset 2.4 MS/s -> 744.1875 kS/s is the headline case), with NO
+// half-band stage (0.5 <= r < 1, template flag S0), and as the last stage behind k_cascade for S >= 2.
+// Same arithmetic and stream bookkeeping as k_front (kernels.hip); what differs is the mapping onto
+// CDNA4:
 //
 //   * one wavefront (64 lanes) owns a contiguous run of 512-sample tiles and carries every piece of
 //     state itself (stage windows in its private LDS slice, next output index / phase in SGPRs), so
-//     after the table load there is no workgroup barrier at all: 12 waves per CU drift apart and
+//     after the table load there is no workgroup barrier at all: 12 - 16 waves per CU drift apart and
 //     cover each other's HBM / LDS latency;
 //   * raw frames arrive by one coalesced 16-byte load per lane per 256 frames, issued one tile
 //     ahead (register prefetch) and consumed before the next prefetch is issued, so the only
@@ -15,9 +16,13 @@
 //     half-band outputs reads its 24-sample window with 12 conflict-free ds_read_b128 at constant
 //     offsets and keeps it in registers (20 taps x 4 outputs, re/im packed: v_pk_fma_f32 with the
 //     tap in an SGPR pair);
+//   * the half-band outputs go back to LDS on top of the odd-stream rows (dead by then), which keeps a
+//     wave's slice at 6.8 KB;
 //   * the polyphase stage gives each lane the 4 half-band samples it just produced: the output
 //     (if any) that falls on each of them is found in closed form from the 24-bit phase, its 14
-//     taps come from the 256-arm table in LDS, the 18-sample window again sits in registers.
+//     taps come from the 256-arm table in LDS, the 18-sample window again sits in registers;
+//   * a lane's 2 .. 4 outputs of a tile are consecutive: they are compacted and (cs16) stored as one
+//     8-byte store plus at most one more, a tile later.
 //
 // Tiles that touch the stream history, the end of the call, or an unaligned buffer ("edge" tiles)
 // are handled by a scalar-load instantiation of the same tile routine; the host gives those tiles
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(FAST ? kS1Threads : kWThreads) void k_front_s1(cons
 
     const int64_t gw = (int64_t)blockIdx.x * kWv + wave;
 #ifdef IQGPU_STAGGER
-    // de-synchronise the 12 waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
+    // de-synchronise the waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
     // otherwise march through them in lockstep, so that LDS time and VALU time add up
     for (int i = 0; i < wave * IQGPU_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
 #endif

@@ -128,7 +128,7 @@ struct iqgpu_chain {
     cf2 *d_hist2[2] = {nullptr, nullptr}; int hist2_cur = 0;
     DevBuf mid;
     cd2 *d_dc_state = nullptr;
-    void *d_sink = nullptr;      // store sink of k_front_s1
+    void *d_sink = nullptr;      // diagnostic scratch of k_front_s1 (iqgpu_chain_debug_read_scratch)
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
     // output AGC (digital profile)

@@ -81,7 +81,7 @@ struct FrontArgs {
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
-    void       *sink;         // 64 KiB scratch that absorbs the stores of lanes without an output
+    void       *sink;         // 64 KiB diagnostic scratch (per-phase cycle counters of -DIQGPU_STAMPS builds)
     // k_cascade (cascade_wave.hip): the first casc_K stages of an S >= 2 chain, cf32 out
     int32_t     casc_K;
     int32_t     casc_wave_lds;          // bytes of LDS per wavefront
