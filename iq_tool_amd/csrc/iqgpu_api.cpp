@@ -650,52 +650,27 @@ static void drain_events(iqgpu_chain *c)
 // ------------------------------------------------------------------------------------------------
 // process
 // ------------------------------------------------------------------------------------------------
-extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
-                                          void *d_out, size_t out_capacity_bytes, size_t *frames_out)
-{
-    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
-    *frames_out = 0;
-    if (frames_in == 0) return IQGPU_OK;
-    if (!d_raw_in || !d_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL buffer");
-    if (frames_in > ((size_t)1 << 40)) return fail(IQGPU_EINVAL, "frames_in too large");
-    HIP_TRY(hipSetDevice(c->device));
+// ------------------------------------------------------------------------------------------------
+// one process() call: per-call geometry, then the stages in stream order
+//   [dc carries] -> front (k_front | k_front_s1 | k_cascade + k_front_s1) -> [filter] -> [k_interp] -> [agc]
+// ------------------------------------------------------------------------------------------------
+namespace {
 
-    const CallPlan p = plan_call(c, frames_in);
-    const size_t obps = bytes_per_frame(c->desc.out_format);
-    if ((size_t)p.n_emit * obps > out_capacity_bytes)
-        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", (size_t)p.n_emit * obps, out_capacity_bytes);
-
-    const bool filt = c->fp.enabled;
-    const size_t L1 = filt ? c->fp.taps.size() - 1 : 0;
-    const uint64_t fpending0 = c->fpending;
-
-    // with the AGC on, the last stage leaves cf32 in abuf and k_agc_apply packs
-    void *fin_out = d_out;
-    int fin_fmt = c->desc.out_format;
-    if (c->agc) {
-        int rc = c->abuf.ensure(((size_t)p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
-        fin_out = c->abuf.p; fin_fmt = IQGPU_FMT_CF32;
-    }
-
-    // ---- geometry of this call ----
-    const int64_t span_samples = (int64_t)c->rem + (int64_t)frames_in;
-    const int64_t total_tiles = (span_samples + kTile - 1) / kTile;
-    // blocks of the workgroup-tiled k_front: with block_samples = 0 sized from the call -- about eight blocks
-    // per CU, at least 16 tiles each when a block has to re-run a warm-up tile (decimating chains), any
-    // size for pointwise chains
-    int tpb = c->tiles_per_block;
-    if (c->auto_block) {
-        int64_t t = (total_tiles + (int64_t)c->n_cu * 8 - 1) / ((int64_t)c->n_cu * 8);
-        const int64_t t_min = c->decim ? 16 : 1;
-        if (t < t_min) t = t_min;
-        if (t > 128) t = 128;
-        tpb = (int)t;
-    }
-    int n_blocks = (int)((total_tiles + tpb - 1) / tpb);
-    if (n_blocks < 1) n_blocks = 1;
+struct Call {
+    iqgpu_chain *c;
+    const void *d_raw_in; size_t frames_in; void *d_out;
+    CallPlan p;
+    bool filt; size_t L1; uint64_t fpending0;
+    void *fin_out; int fin_fmt;              // where the LAST stage writes (d_out, or the AGC's cf32 buffer)
+    int64_t total_tiles; int tpb, n_blocks;  // geometry of the workgroup-tiled k_front
+    bool casc, fast_s0, fast_s1;             // which front path runs
+    int wtile, casc_K, rem_k;
+    FrontArgs cplan;                         // run geometry of the wave-autonomous kernel that sees the raw input
+    cf2 *fcur = nullptr, *icur = nullptr;    // filter-input / k_interp-input buffers of this call
 
     // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
-    auto tiles_per_wave = [&](int64_t w_tiles, int waves = kWaves) {
+    int tiles_per_wave(int64_t w_tiles, int waves) const
+    {
         int64_t tpw64;
         if (c->auto_block) {
             const int64_t slots = (int64_t)c->n_cu * waves;
@@ -707,20 +682,57 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (tpw64 < 1) tpw64 = 1;
         if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
         return (int)tpw64;
-    };
-    // ---- run geometry of the wave-autonomous kernels (needed by the dc carries as well) ----
-    //   S >= 2: k_cascade (stages 0 .. S-2) + k_front_s1 (last stage);  S == 1: k_front_s1
-    const bool casc = c->cascade && !c->force_generic;
-    const bool fast_s0 = c->decim && c->S == 0 && !c->force_generic;          // polyphase only, 256-frame tiles
-    const bool fast_s1 = fast_s0 || (c->decim && c->S == 1 && c->rp.stages[0].m == 10 && !c->force_generic);
-    const int wtile = fast_s0 ? 256 : kWTile;
-    const int casc_K = c->S - 1;
-    const int rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : c->rem;
-    FrontArgs cplan{};
+    }
+    void copy_plan(FrontArgs &dst) const
+    {
+        dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
+        dst.w_warm_tiles = cplan.w_warm_tiles; dst.w_edge_tpw = cplan.w_edge_tpw;
+        dst.w_fast_g0 = cplan.w_fast_g0; dst.w_fast_g1 = cplan.w_fast_g1;
+        dst.w_edge_ta = cplan.w_edge_ta; dst.w_edge_tb = cplan.w_edge_tb;
+        dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
+    }
+    int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
+
+    void plan_geometry();
+    int stage_dc_carries();
+    int prepare_buffers();
+    int stage_front();
+    int stage_filter();
+    int stage_late_resampler();
+    int stage_agc();
+};
+
+void Call::plan_geometry()
+{
+    const int64_t span_samples = (int64_t)c->rem + (int64_t)frames_in;
+    total_tiles = (span_samples + kTile - 1) / kTile;
+    // blocks of the workgroup-tiled k_front: with block_samples = 0 sized from the call -- about eight blocks
+    // per CU, at least 16 tiles each when a block has to re-run a warm-up tile (decimating chains), any
+    // size for pointwise chains
+    tpb = c->tiles_per_block;
+    if (c->auto_block) {
+        int64_t t = (total_tiles + (int64_t)c->n_cu * 8 - 1) / ((int64_t)c->n_cu * 8);
+        const int64_t t_min = c->decim ? 16 : 1;
+        if (t < t_min) t = t_min;
+        if (t > 128) t = 128;
+        tpb = (int)t;
+    }
+    n_blocks = (int)((total_tiles + tpb - 1) / tpb);
+    if (n_blocks < 1) n_blocks = 1;
+
+    // run geometry of the wave-autonomous kernels (needed by the dc carries as well)
+    //   S >= 2: k_cascade (stages 0 .. S-2) + k_front_s1 (last stage);  S == 1: k_front_s1;  S == 0: its S0 variant
+    casc = c->cascade && !c->force_generic;
+    fast_s0 = c->decim && c->S == 0 && !c->force_generic;          // polyphase only, 256-frame tiles
+    fast_s1 = fast_s0 || (c->decim && c->S == 1 && c->rp.stages[0].m == 10 && !c->force_generic);
+    wtile = fast_s0 ? 256 : kWTile;
+    casc_K = c->S - 1;
+    rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : c->rem;
+    cplan = FrontArgs{};
     if (casc || fast_s1) {
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
-        cplan.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
+        cplan.raw_aligned = raw_aligned();
         if (casc) {
             cplan.casc_K = casc_K;
             for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
@@ -734,233 +746,268 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
         if (warm < 1) warm = 1;
         plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? cascade_waves(cplan) : front_s1_waves(cplan)), warm, 4, wtile);
     }
-    auto copy_plan = [&](FrontArgs &dst) {
-        dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
-        dst.w_warm_tiles = cplan.w_warm_tiles; dst.w_edge_tpw = cplan.w_edge_tpw;
-        dst.w_fast_g0 = cplan.w_fast_g0; dst.w_fast_g1 = cplan.w_fast_g1;
-        dst.w_edge_ta = cplan.w_edge_ta; dst.w_edge_tb = cplan.w_edge_tb;
-        dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
-    };
+}
 
-    // ---- dc-blocker carries ----
-    if (c->dc) {
-        DcGeom dg{};
-        dg.frames_in = (int64_t)frames_in;
-        if (casc || fast_s1) {
-            dg.mode = 1;
-            dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
-            dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
-            dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k; dg.tile = wtile;
-            dg.n_seg = (int)(cplan.w_n_edge + dg.n_stream);
-            if (dg.n_seg < 1) dg.n_seg = 1;
-        } else {
-            dg.mode = 0; dg.n_seg = n_blocks;
-            dg.seg_first = ((int64_t)tpb - c->warm_tiles) * kTile - c->rem;
-            dg.seg_len = (int64_t)tpb * kTile;
-        }
-        int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
-        rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
-        DcPrefixArgs pa{};
-        pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
-        pa.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
-        pa.c = c->dc_c; pa.logc = c->dc_logc; pa.geom = dg; pa.agg = (cf2 *)c->dc_agg.p;
-        { KernelTimer kt(c, IQGPU_K_DC_PREFIX); HIP_TRY(launch_dc_prefix(pa, c->stream)); }
-        DcScanArgs sa{};
-        sa.agg = (const cf2 *)c->dc_agg.p; sa.carry = (cd2 *)c->dc_carry.p; sa.state = c->d_dc_state;
-        sa.geom = dg; sa.logc = c->dc_logc;
-        { KernelTimer kt(c, IQGPU_K_DC_SCAN); HIP_TRY(launch_dc_scan(sa, c->stream)); }
+// state of the dc blocker at the start of every independent piece of the front kernel
+int Call::stage_dc_carries()
+{
+    DcGeom dg{};
+    dg.frames_in = (int64_t)frames_in;
+    if (casc || fast_s1) {
+        dg.mode = 1;
+        dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
+        dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
+        dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k; dg.tile = wtile;
+        dg.n_seg = (int)(cplan.w_n_edge + dg.n_stream);
+        if (dg.n_seg < 1) dg.n_seg = 1;
+    } else {
+        dg.mode = 0; dg.n_seg = n_blocks;
+        dg.seg_first = ((int64_t)tpb - c->warm_tiles) * kTile - c->rem;
+        dg.seg_len = (int64_t)tpb * kTile;
     }
+    int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
+    rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
+    DcPrefixArgs pa{};
+    pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
+    pa.raw_aligned = raw_aligned();
+    pa.c = c->dc_c; pa.logc = c->dc_logc; pa.geom = dg; pa.agg = (cf2 *)c->dc_agg.p;
+    { KernelTimer kt(c, IQGPU_K_DC_PREFIX); HIP_TRY(launch_dc_prefix(pa, c->stream)); }
+    DcScanArgs sa{};
+    sa.agg = (const cf2 *)c->dc_agg.p; sa.carry = (cd2 *)c->dc_carry.p; sa.state = c->d_dc_state;
+    sa.geom = dg; sa.logc = c->dc_logc;
+    { KernelTimer kt(c, IQGPU_K_DC_SCAN); HIP_TRY(launch_dc_scan(sa, c->stream)); }
+    return IQGPU_OK;
+}
 
-    // ---- filter-input buffer ----
-    cf2 *fcur = nullptr;
+// the cf32 buffers between stages: [L-1 history][pending][new] in front of the filter, [ihist][new] in front of k_interp
+int Call::prepare_buffers()
+{
     if (filt) {
         const size_t need = (L1 + (size_t)c->fpending + (size_t)p.n_res + 1) * sizeof(cf2);
-        if (need > c->fbuf[c->fcur].cap) {
-            // grow, keeping history + pending samples
-            DevBuf nb;
-            int rc = nb.ensure(need); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(nb.p, c->fbuf[c->fcur].p, (L1 + (size_t)c->fpending) * sizeof(cf2), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->fbuf[c->fcur].release();
-            c->fbuf[c->fcur] = nb;
-        }
+        int rc = c->fbuf[c->fcur].ensure_keep(need, (L1 + (size_t)c->fpending) * sizeof(cf2), c->stream);
+        if (rc) return rc;
         fcur = (cf2 *)c->fbuf[c->fcur].p;
     }
-    // ---- k_interp input buffer (r >= 1 path) ----
-    cf2 *icur = nullptr;
     if (c->late) {
         int rc = c->ibuf[c->icur].ensure_keep(((size_t)c->ihist + (size_t)p.n_x + 1) * sizeof(cf2), (size_t)c->ihist * sizeof(cf2), c->stream);
         if (rc) return rc;
         icur = (cf2 *)c->ibuf[c->icur].p;
     }
+    return IQGPU_OK;
+}
 
-    // ---- front kernel ----
-    {
-        FrontArgs a{};
-        a.raw = d_raw_in;
-        a.hist_in = c->d_hist[c->hist_cur]; a.hist_out = c->d_hist[c->hist_cur ^ 1];
-        a.frames_in = (int64_t)frames_in; a.hist_cap = c->hist_cap; a.rem0 = c->rem;
-        a.in_fmt = c->desc.in_format; a.gain = c->desc.gain;
-        a.raw_aligned = (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0;
-        a.dc_enable = c->dc ? 1 : 0;
-        if (c->dc) {
-            a.dc_c = c->dc_c; a.dc_a = 1.0f - c->dc_c; a.dc_logc = c->dc_logc;
-            for (int k = 0; k < 6; ++k) a.dc_cpow[k] = (float)std::exp((double)(4 << k) * c->dc_logc);
-            a.dc_cpow[6] = (float)std::exp(256.0 * c->dc_logc);
-            a.dc_cpow[7] = (float)std::exp(1024.0 * c->dc_logc);
-            a.dc_carry = (const cd2 *)c->dc_carry.p;
+int Call::stage_front()
+{
+    FrontArgs a{};
+    a.raw = d_raw_in;
+    a.hist_in = c->d_hist[c->hist_cur]; a.hist_out = c->d_hist[c->hist_cur ^ 1];
+    a.frames_in = (int64_t)frames_in; a.hist_cap = c->hist_cap; a.rem0 = c->rem;
+    a.in_fmt = c->desc.in_format; a.gain = c->desc.gain;
+    a.raw_aligned = raw_aligned();
+    a.dc_enable = c->dc ? 1 : 0;
+    if (c->dc) {
+        a.dc_c = c->dc_c; a.dc_a = 1.0f - c->dc_c; a.dc_logc = c->dc_logc;
+        for (int k = 0; k < 6; ++k) a.dc_cpow[k] = (float)std::exp((double)(4 << k) * c->dc_logc);
+        a.dc_cpow[6] = (float)std::exp(256.0 * c->dc_logc);
+        a.dc_cpow[7] = (float)std::exp(1024.0 * c->dc_logc);
+        a.dc_carry = (const cd2 *)c->dc_carry.p;
+    }
+    a.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
+    a.iq_magp1 = 1.0f + c->iq_mag; a.iq_phase = c->iq_phase;
+    a.nco_mode = c->nco_mode;
+    a.nco_dtheta = c->nco_dtheta;
+    // phase of i_rel = 0, i.e. rem samples before the first new sample
+    a.nco_theta0 = c->nco_theta - (uint32_t)c->rem * c->nco_dtheta;
+    a.nco_tab = c->d_nco_tab;
+    a.mode = c->decim ? 1 : 0;
+    a.S = c->S;
+    for (int i = 0; i < c->S; ++i) { a.m[i] = c->rp.stages[(size_t)i].m; a.tap_off[i] = c->tap_off[i]; }
+    for (int i = 0; i <= c->S + 1; ++i) a.lvl_off[i] = c->lvl_off[i];
+    a.n_hb_taps = c->n_hb_taps; a.hb_taps = c->d_hb; a.arb_table = c->d_arb;
+    a.step = c->rp.step; a.n_est = c->n_est; a.phi0 = c->phi;
+    a.n_groups = p.n_groups; a.n_out = p.n_res;
+    a.total_tiles = total_tiles; a.tiles_per_block = tpb; a.warm_tiles = c->warm_tiles;
+    a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
+    const bool nco_in_front = !filt && !c->late;     // otherwise the post NCO runs in the last stage
+    a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
+    if (filt)         { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
+    else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
+    else              { a.out_fmt = fin_fmt; a.out = fin_out; }
+    a.sink = c->d_sink;
+
+    if (casc) {
+        // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
+        const int K = casc_K;
+        const int rem_1 = c->rem >> K;
+        const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> K;
+        int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
+        FrontArgs a1 = a;
+        a1.rem0 = rem_k;
+        a1.nco_theta0 = c->nco_theta - (uint32_t)rem_k * c->nco_dtheta;
+        a1.casc_K = K;
+        for (int k = 0; k < K; ++k) {
+            const std::vector<float> &br = c->rp.stages[(size_t)k].branch;
+            for (size_t q = 0; q < 12; ++q) a1.casc_taps[k][q] = q < br.size() ? 0.5f * br[q] : 0.0f;
         }
-        a.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
-        a.iq_magp1 = 1.0f + c->iq_mag; a.iq_phase = c->iq_phase;
-        a.nco_mode = c->nco_mode;
-        a.nco_dtheta = c->nco_dtheta;
-        // phase of i_rel = 0, i.e. rem samples before the first new sample
-        a.nco_theta0 = c->nco_theta - (uint32_t)c->rem * c->nco_dtheta;
-        a.nco_tab = c->d_nco_tab;
-        a.mode = c->decim ? 1 : 0;
-        a.S = c->S;
-        for (int i = 0; i < c->S; ++i) { a.m[i] = c->rp.stages[(size_t)i].m; a.tap_off[i] = c->tap_off[i]; }
-        for (int i = 0; i <= c->S + 1; ++i) a.lvl_off[i] = c->lvl_off[i];
-        a.n_hb_taps = c->n_hb_taps; a.hb_taps = c->d_hb; a.arb_table = c->d_arb;
-        a.step = c->rp.step; a.n_est = c->n_est; a.phi0 = c->phi;
-        a.n_groups = p.n_groups; a.n_out = p.n_res;
-        a.total_tiles = total_tiles; a.tiles_per_block = tpb; a.warm_tiles = c->warm_tiles;
-        a.pnco_theta0 = c->pnco_theta; a.pnco_dtheta = c->nco_dtheta;
-        const bool nco_in_front = !filt && !c->late;     // otherwise the post NCO runs in the last stage
-        a.pnco_mode = nco_in_front ? c->pnco_mode : 0;
-        if (filt)         { a.out_fmt = IQGPU_FMT_CF32; a.out = fcur + L1 + c->fpending; }
-        else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
-        else              { a.out_fmt = fin_fmt; a.out = fin_out; }
-        // wave-autonomous fast path: one half-band stage (m = 10)
-        if (fast_s1) {
-            copy_plan(a);
-            if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
-            a.sink = c->d_sink;
+        a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
+        a1.casc_wave_lds = (int)cascade_wave_lds(a1);
+        a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
+        copy_plan(a1);
+        { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
+        // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
+        if (n_mid > 0) {
+            FrontArgs a2{};
+            a2.raw = c->mid.p; a2.hist_in = c->d_hist2[c->hist2_cur]; a2.hist_out = c->d_hist2[c->hist2_cur ^ 1];
+            a2.frames_in = n_mid; a2.hist_cap = c->hist2_cap; a2.rem0 = rem_1;
+            a2.in_fmt = IQGPU_FMT_CF32; a2.gain = 1.0f; a2.raw_aligned = 1;
+            a2.nco_tab = c->d_nco_tab;
+            a2.mode = 1; a2.S = 1; a2.m[0] = c->rp.stages[(size_t)K].m;
+            a2.arb_table = c->d_arb; a2.step = c->rp.step; a2.phi0 = c->phi;
+            a2.n_groups = p.n_groups; a2.n_out = p.n_res;
+            a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
+            a2.out_fmt = a.out_fmt; a2.out = a.out;
+            a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
+            plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, front_s1_waves(a2)), 1, 4);
+            for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
+            a2.sink = c->d_sink;
+            { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
+            c->hist2_cur ^= 1;
         }
-        if (casc) {
-            // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
-            const int K = casc_K;
-            const int rem_1 = c->rem >> K;
-            const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> K;
-            int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
-            FrontArgs a1 = a;
-            a1.rem0 = rem_k;
-            a1.nco_theta0 = c->nco_theta - (uint32_t)rem_k * c->nco_dtheta;
-            a1.casc_K = K;
-            for (int k = 0; k < K; ++k) {
-                const std::vector<float> &br = c->rp.stages[(size_t)k].branch;
-                for (size_t q = 0; q < 12; ++q) a1.casc_taps[k][q] = q < br.size() ? 0.5f * br[q] : 0.0f;
-            }
-            a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
-            a1.casc_wave_lds = (int)cascade_wave_lds(a1);
-            a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
-            copy_plan(a1);
-            { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
-            // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
-            if (n_mid > 0) {
-                FrontArgs a2{};
-                a2.raw = c->mid.p; a2.hist_in = c->d_hist2[c->hist2_cur]; a2.hist_out = c->d_hist2[c->hist2_cur ^ 1];
-                a2.frames_in = n_mid; a2.hist_cap = c->hist2_cap; a2.rem0 = rem_1;
-                a2.in_fmt = IQGPU_FMT_CF32; a2.gain = 1.0f; a2.raw_aligned = 1;
-                a2.nco_tab = c->d_nco_tab;
-                a2.mode = 1; a2.S = 1; a2.m[0] = c->rp.stages[(size_t)K].m;
-                a2.arb_table = c->d_arb; a2.step = c->rp.step; a2.phi0 = c->phi;
-                a2.n_groups = p.n_groups; a2.n_out = p.n_res;
-                a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
-                a2.out_fmt = a.out_fmt; a2.out = a.out;
-                a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-                plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, front_s1_waves(a2)), 1, 4);
-                for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
-                a2.sink = c->d_sink;
-                { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
-                c->hist2_cur ^= 1;
-            }
-        } else {
-            KernelTimer kt(c, IQGPU_K_FRONT);
-            if (fast_s1) HIP_TRY(launch_front_s1(a, c->stream));
-            else HIP_TRY(launch_front(a, n_blocks, c->stream));
-        }
+    } else if (fast_s1) {
+        // wave-autonomous kernel: one half-band stage (m = 10), or none
+        copy_plan(a);
+        if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
+        KernelTimer kt(c, IQGPU_K_FRONT);
+        HIP_TRY(launch_front_s1(a, c->stream));
+    } else {
+        KernelTimer kt(c, IQGPU_K_FRONT);
+        HIP_TRY(launch_front(a, n_blocks, c->stream));
     }
     if (c->decim) c->hist_cur ^= 1;
+    return IQGPU_OK;
+}
 
-    // ---- filter stage ----
-    if (filt) {
-        FirArgs fa{};
-        fa.fbuf = fcur; fa.taps = c->d_ftaps; fa.ntaps = (int)c->fp.taps.size(); fa.is_complex = c->fp.is_complex ? 1 : 0;
-        const int64_t n_filt = c->late ? p.n_x : p.n_emit;
-        fa.n_emit = n_filt;
-        fa.pnco_mode = c->late ? 0 : c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
-        if (c->late) { fa.out_fmt = IQGPU_FMT_CF32; fa.out = icur + c->ihist; }
-        else         { fa.out_fmt = fin_fmt; fa.out = fin_out; }
-        if (c->d_hfreq) {
-            FftConvArgs ca{};
-            ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
-            ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
-            ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = n_filt;
-            ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
-            ca.out_fmt = fa.out_fmt; ca.out = fa.out;
-            KernelTimer kt(c, IQGPU_K_FILTER);
-            HIP_TRY(launch_fftconv(ca, c->stream));
-        } else {
-            KernelTimer kt(c, IQGPU_K_FILTER);
-            HIP_TRY(launch_fir(fa, c->stream));
-        }
-        // next call's buffer front: history (L-1) + still-pending samples
-        const size_t keep = L1 + (size_t)p.fpending_next;
-        int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;
-        { KernelTimer kt(c, IQGPU_K_MOVE);
-          HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream)); }
-        c->fcur ^= 1;
-        c->fpending = p.fpending_next;
+int Call::stage_filter()
+{
+    FirArgs fa{};
+    fa.fbuf = fcur; fa.taps = c->d_ftaps; fa.ntaps = (int)c->fp.taps.size(); fa.is_complex = c->fp.is_complex ? 1 : 0;
+    const int64_t n_filt = c->late ? p.n_x : p.n_emit;
+    fa.n_emit = n_filt;
+    fa.pnco_mode = c->late ? 0 : c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
+    if (c->late) { fa.out_fmt = IQGPU_FMT_CF32; fa.out = icur + c->ihist; }
+    else         { fa.out_fmt = fin_fmt; fa.out = fin_out; }
+    if (c->d_hfreq) {
+        FftConvArgs ca{};
+        ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
+        ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
+        ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = n_filt;
+        ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
+        ca.out_fmt = fa.out_fmt; ca.out = fa.out;
+        KernelTimer kt(c, IQGPU_K_FILTER);
+        HIP_TRY(launch_fftconv(ca, c->stream));
+    } else {
+        KernelTimer kt(c, IQGPU_K_FILTER);
+        HIP_TRY(launch_fir(fa, c->stream));
     }
+    // next call's buffer front: history (L-1) + still-pending samples
+    const size_t keep = L1 + (size_t)p.fpending_next;
+    int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;
+    { KernelTimer kt(c, IQGPU_K_MOVE);
+      HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream)); }
+    c->fcur ^= 1;
+    c->fpending = p.fpending_next;
+    return IQGPU_OK;
+}
 
-    // ---- resampler behind the front stage / pre filter ----
-    if (c->late) {
-        InterpArgs ia = c->ia;
-        ia.xbuf = icur; ia.hist = c->ihist; ia.n_in = p.n_x;
-        ia.phi0 = c->phi; ia.n_arb = p.n_arb; ia.n_emit = p.n_emit;
-        ia.n_tiles = (p.n_emit + kInterpTile - 1) / kInterpTile;
-        ia.hb_taps = c->d_ihb; ia.arb_table = c->d_arb;
-        ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
-        ia.out_fmt = fin_fmt; ia.out = fin_out;
-        { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
-        int rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
-        { KernelTimer kt(c, IQGPU_K_MOVE);
-          HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
-        c->icur ^= 1;
-    }
+// r >= 1: the resampler behind the front stage / pre filter
+int Call::stage_late_resampler()
+{
+    InterpArgs ia = c->ia;
+    ia.xbuf = icur; ia.hist = c->ihist; ia.n_in = p.n_x;
+    ia.phi0 = c->phi; ia.n_arb = p.n_arb; ia.n_emit = p.n_emit;
+    ia.n_tiles = (p.n_emit + kInterpTile - 1) / kInterpTile;
+    ia.hb_taps = c->d_ihb; ia.arb_table = c->d_arb;
+    ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
+    ia.out_fmt = fin_fmt; ia.out = fin_out;
+    { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
+    int rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
+    { KernelTimer kt(c, IQGPU_K_MOVE);
+      HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
+    c->icur ^= 1;
+    return IQGPU_OK;
+}
 
-    // ---- output AGC: agc_apply per reference chunk (src/post_processor.c:55-57) ----
+// output AGC: agc_apply per reference chunk (src/post_processor.c:55-57)
+int Call::stage_agc()
+{
+    AgcArgs ga{};
+    AgcGeom &g = ga.geom;
+    g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
+    g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
+    g.mode = c->late ? 2 : (c->decim ? 1 : 0);
+    g.rem = c->rem; g.S = c->late ? c->ia.S : c->S; g.phi = c->phi; g.step = c->rp.step;
+    g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
+    if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
+    int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
+    rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
+    ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
+    ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p;
+    ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
+    ga.target = c->agc_target; ga.rate = c->target_rate;
+    ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
+    ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;
+    const int64_t avg = p.n_emit / g.n_chunks + 1;
+    int64_t splits = (avg + 16383) / 16384; if (splits > 1024) splits = 1024;
+    ga.splits = (int)splits;
+    ga.out_fmt = c->desc.out_format; ga.out = d_out;
+    KernelTimer kt(c, IQGPU_K_AGC);
+    HIP_TRY(launch_agc(ga, c->stream));
+    return IQGPU_OK;
+}
+
+} // namespace
+
+extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                                          void *d_out, size_t out_capacity_bytes, size_t *frames_out)
+{
+    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
+    *frames_out = 0;
+    if (frames_in == 0) return IQGPU_OK;
+    if (!d_raw_in || !d_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL buffer");
+    if (frames_in > ((size_t)1 << 40)) return fail(IQGPU_EINVAL, "frames_in too large");
+    HIP_TRY(hipSetDevice(c->device));
+
+    Call k{};
+    k.c = c; k.d_raw_in = d_raw_in; k.frames_in = frames_in; k.d_out = d_out;
+    k.p = plan_call(c, frames_in);
+    const size_t obps = bytes_per_frame(c->desc.out_format);
+    if ((size_t)k.p.n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", (size_t)k.p.n_emit * obps, out_capacity_bytes);
+    k.filt = c->fp.enabled;
+    k.L1 = k.filt ? c->fp.taps.size() - 1 : 0;
+    k.fpending0 = c->fpending;
+    // with the AGC on, the last stage leaves cf32 in abuf and k_agc_apply packs
+    k.fin_out = d_out; k.fin_fmt = c->desc.out_format;
     if (c->agc) {
-        AgcArgs ga{};
-        AgcGeom &g = ga.geom;
-        g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
-        g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
-        g.mode = c->late ? 2 : (c->decim ? 1 : 0);
-        g.rem = c->rem; g.S = c->late ? c->ia.S : c->S; g.phi = c->phi; g.step = c->rp.step;
-        g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
-        if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
-        int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
-        rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
-        ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
-        ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p; ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
-        ga.target = c->agc_target; ga.rate = c->target_rate;
-        ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
-        ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;
-        const int64_t avg = p.n_emit / g.n_chunks + 1;
-        int64_t splits = (avg + 16383) / 16384; if (splits > 1024) splits = 1024;
-        ga.splits = (int)splits;
-        ga.out_fmt = c->desc.out_format; ga.out = d_out;
-        KernelTimer kt(c, IQGPU_K_AGC);
-        HIP_TRY(launch_agc(ga, c->stream));
+        int rc = c->abuf.ensure(((size_t)k.p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
+        k.fin_out = c->abuf.p; k.fin_fmt = IQGPU_FMT_CF32;
     }
+    k.plan_geometry();
+
+    int rc;
+    if (c->dc && (rc = k.stage_dc_carries()) != IQGPU_OK) return rc;
+    if ((rc = k.prepare_buffers()) != IQGPU_OK) return rc;
+    if ((rc = k.stage_front()) != IQGPU_OK) return rc;
+    if (k.filt && (rc = k.stage_filter()) != IQGPU_OK) return rc;
+    if (c->late && (rc = k.stage_late_resampler()) != IQGPU_OK) return rc;
+    if (c->agc && (rc = k.stage_agc()) != IQGPU_OK) return rc;
 
     // ---- advance the stream position ----
     c->nco_theta += (uint32_t)frames_in * c->nco_dtheta;
-    c->pnco_theta += (uint32_t)(uint64_t)p.n_emit * c->nco_dtheta;
-    c->rem = p.rem_next;
-    c->phi = p.phi_next;
-    *frames_out = (size_t)p.n_emit;
+    c->pnco_theta += (uint32_t)(uint64_t)k.p.n_emit * c->nco_dtheta;
+    c->rem = k.p.rem_next;
+    c->phi = k.p.phi_next;
+    *frames_out = (size_t)k.p.n_emit;
     return IQGPU_OK;
 }
 
