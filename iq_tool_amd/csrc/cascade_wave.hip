@@ -348,9 +348,12 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
     }
 #define IQGPU_LAUNCH_CASC(BPS)                                                                                         \
     do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)k_cascade<BPS>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                           (int)lds);                                                                 \
-        if (e != hipSuccess) return e;                                                                                \
+        static LdsAttrCache cache;                /* per instantiation */                                          \
+        if (cache.needs(lds)) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute((const void *)k_cascade<BPS>,                                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) return e;                                                                            \
+        }                                                                                                             \
         hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(waves * 64), lds, s, a);                                   \
     } while (0)
     if (cls == 2) IQGPU_LAUNCH_CASC(2);

@@ -298,7 +298,8 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
         if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
         const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
         const size_t lds = (size_t)(N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
-        if (lds > 64 * 1024) {
+        static LdsAttrCache cache16;
+        if (lds > 64 * 1024 && cache16.needs(lds)) {
             hipError_t e = hipFuncSetAttribute((const void *)k_fftconv16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
@@ -310,7 +311,8 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
     if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
     const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
-    if (lds > 64 * 1024) {
+    static LdsAttrCache cache;
+    if (lds > 64 * 1024 && cache.needs(lds)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fftconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }

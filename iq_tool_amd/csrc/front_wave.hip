@@ -599,9 +599,12 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     }
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0)                                                                                \
     do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST, S0>,                                   \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        if (e != hipSuccess) return e;                                                                                \
+        static LdsAttrCache cache;                /* per instantiation */                                          \
+        if (cache.needs(lds)) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST, S0>,                                                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) return e;                                                                            \
+        }                                                                                                             \
         hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0>), dim3(grid), dim3(waves * 64), lds, s, a);                     \
     } while (0)
     if (a.S == 0) {

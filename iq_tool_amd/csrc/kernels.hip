@@ -322,11 +322,10 @@ size_t front_lds_bytes(const FrontArgs &a)
 hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s)
 {
     const size_t lds = front_lds_bytes(a);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
+    static LdsAttrCache cache;
+    if (lds > 64 * 1024 && cache.needs(lds)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     hipLaunchKernelGGL(k_front, dim3((unsigned)n_blocks), dim3(kThreads), lds, s, a);
     return hipGetLastError();

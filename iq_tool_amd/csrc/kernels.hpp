@@ -22,6 +22,20 @@ constexpr int kFirOutTile = 1024;  // outputs per workgroup tile in the FIR kern
 constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
 constexpr int kFftMinTaps = 96;    // FIR-kind filters at least this long run as overlap-save (k_fftconv)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and costs a few microseconds: launchers
+// call it once per (kernel instantiation, device, size) through this little cache
+struct LdsAttrCache {
+    size_t configured[64] = {0};
+    bool needs(size_t lds)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (lds <= configured[dev]) return false;
+        configured[dev] = lds;
+        return true;
+    }
+};
+
 struct cf2 { float x, y; };
 struct cd2 { double x, y; };
 
