@@ -762,15 +762,25 @@ def _random_chain(rng):
             bw = float(rng.uniform(0.1, 0.3) * lim)
             req = (typ, float(rng.uniform(-0.5, 0.5) * lim), bw)
         kw["filters"] = (req,)
+        if rng.random() < 0.25:                                   # a chain of two (src/filter.c:114-136 convolves them)
+            kw["filters"] = (req, ("lowpass", float(rng.uniform(0.5, 0.9) * lim), 0.0))
         kw["filter_impl"] = str(rng.choice(["auto", "fir", "fft"]))
         if rng.random() < 0.5:
             kw["filter_taps"] = int(rng.choice([31, 101, 257, 1025]))
+        elif rng.random() < 0.3:
+            kw["transition_width_hz"] = float(rng.uniform(0.02, 0.1) * lim)
+            kw["attenuation_db"] = float(rng.choice([40.0, 60.0, 80.0]))
     if rng.random() < 0.25:
         kw["agc"] = True
+    if rng.random() < 0.3:
+        kw["block_samples"] = int(rng.choice([2048, 16384, 1 << 20]))
     return kw
 
 
-@pytest.mark.parametrize("seed", range(96))
+import os as _os
+
+
+@pytest.mark.parametrize("seed", range(int(_os.environ.get("IQGPU_FUZZ_SEEDS", "96"))))   # IQGPU_FUZZ_SEEDS=3000 for a long soak
 def test_random_chain_matches_oracle(gpu, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     kw = _random_chain(rng)
