@@ -5,6 +5,8 @@ Bars (DESIGN.md "Parity contract"):
   * cf32 results of every liquid-derived operator: max |delta| <= 1e-5 on unit-scale signals;
   * integer outputs of full chains: never more than +-1 LSB apart, >= 97 % identical codes.
 """
+import os as _os_agc
+
 import numpy as np
 import pytest
 
@@ -509,6 +511,39 @@ def test_agc_operator_scan_lock_ratchet_creep(gpu, oracle, chunk, splits):
     st = op.state
     assert not st["locked"] and st["gain"] == 1.0 and st["samples_seen"] == 0 and st["peak_memory"] == np.float32(0.05)
     assert np.abs(op.apply(x[:5000]) - oracle.Agc(rate).apply_chunked(x[:5000], chunk)).max() <= 2e-6
+
+
+@pytest.mark.parametrize("seed", range(int(_os_agc.environ.get("IQGPU_FUZZ_SEEDS", "24"))))
+def test_agc_random_envelopes(gpu, oracle, seed):
+    """the speculative gain scan against the sequential agc_apply: random envelopes (bursts, fades longer
+    and shorter than the hang time), random chunk sizes, random multi-chunk calls"""
+    from iq_tool_amd import ops
+    rng = np.random.default_rng(7000 + seed)
+    rate = float(rng.choice([4000.0, 8000.0, 20000.0]))
+    n = int(rng.integers(15, 40) * rate)                       # 15 .. 40 s of signal
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.05)
+    env = np.ones(n, np.float32)
+    t = 0
+    while t < n:                                               # piecewise-constant envelope, segments of 0.1 .. 6 s
+        seg = int(rng.uniform(0.1, 6.0) * rate)
+        env[t:t + seg] = np.float32(10.0 ** rng.uniform(-1.5, 1.0))
+        t += seg
+    x = x * env
+    chunk = int(rng.choice([100, 250, 1000, 4096, 16384]))
+    target = float(rng.choice([0.0, 0.5, 0.9]))
+    a = oracle.Agc(rate, target=target)
+    want = a.apply_chunked(x, chunk)
+    op = ops.Agc(rate, target=target, chunk_frames=chunk)
+    outs, pos = [], 0
+    while pos < n:
+        k = int(rng.integers(1, 200)) * chunk
+        outs.append(op.apply(x[pos:pos + k])); pos += k
+    got = np.concatenate(outs)
+    assert got.size == want.size
+    assert np.abs(got - want).max() <= 4e-6 * max(1.0, float(np.abs(want).max()))
+    st = op.state
+    assert st["locked"] == a.locked and st["samples_seen"] == n
+    assert abs(st["gain"] - a.gain) <= 2e-6 * a.gain and st["peak_memory"] == a.peak_memory
 
 
 def test_agc_many_chunks_per_call(gpu, oracle):
