@@ -336,6 +336,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 }
             }
         }
+        // wave priority: a wave that is about to feed the LDS pipe (the busiest of the three) goes ahead of waves
+        // that are in their FMA runs (measured -3 % on the NRSC-5 chain)
+        if (!EDGE) __builtin_amdgcn_s_setprio(1);
         if (S0) {
             // no half-band stage: the lane's four samples ARE its polyphase-input row
             if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;         // history rows of the polyphase input
@@ -374,6 +377,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             const float4 o0 = ld4(wo + 2 * kRowB + 16), o1 = ld4(wo + 3 * kRowB);
             v2f acc[4] = {v2f{0.5f * o0.x, 0.5f * o0.y}, v2f{0.5f * o0.z, 0.5f * o0.w},
                           v2f{0.5f * o1.x, 0.5f * o1.y}, v2f{0.5f * o1.z, 0.5f * o1.w}};
+            if (!EDGE) __builtin_amdgcn_s_setprio(0);
             const v2f *hbp = (const v2f *)a.hb0;          // 10 SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
             for (int q2 = 0; q2 < 10; ++q2) {
@@ -387,6 +391,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             // the odd stream for this tile has been issued above, so its data rows are dead.  The 4 history rows of
             // the half-band output (the previous tile's last rows, kept in sl_hist) are put back first: they share
             // XO rows 5 .. 8, which this tile's pointwise phase has just used.
+            if (!EDGE) __builtin_amdgcn_s_setprio(1);
             if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
@@ -444,6 +449,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 if (EDGE) { const int64_t left = a.n_groups - q_tile0; if (left < 256) q_lim = (uint32_t)left; }
                 char *obase = (char *)a.out + (int64_t)k_tile0 * obps;
                 const uint32_t pth0 = a.pnco_theta0 + (uint32_t)k_tile0 * a.pnco_dtheta;
+                if (!EDGE) __builtin_amdgcn_s_setprio(0);
                 uint32_t kk = n0;
                 uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
