@@ -54,6 +54,7 @@ __device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int l
             O[4] = v2f{u0.x, u0.y}; O[5] = v2f{u0.z, u0.w}; O[6] = v2f{u1.x, u1.y}; O[7] = v2f{u1.z, u1.w};
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -204,6 +205,7 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 }
             }
         }
+        if (!EDGE) __builtin_amdgcn_s_setprio(1);       // feeding the LDS pipe goes ahead of FMA runs (as in k_front_s1)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int off = woff + 32 * c * kRowB;
@@ -231,6 +233,7 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 if (lane < 12 * Hk) { se = *(const float *)(w.XE[k] + rows * kRowB + lane * 4); so = *(const float *)(w.XO[k] + rows * kRowB + lane * 4); }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 12 * Hk) { *(float *)(w.XE[k] + lane * 4) = se; *(float *)(w.XO[k] + lane * 4) = so; }
+                if (!EDGE) __builtin_amdgcn_s_setprio(1);
                 if (k + 1 < K) {
                     // outputs 4l .. 4l+3 -> even / odd rows of the next stage
                     if (lane < n_act) {
