@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-frames-log2", type=int, default=28, help="bounded CPU-baseline sample (2^28 = one step's batch, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="2 = BASELINE configs[1] (the metric's config, default); 3 / 4 = configs[2] / configs[3], secondary timings")
-    ap.add_argument("--traffic-bytes", type=float, default=1430617088.0,
+    ap.add_argument("--traffic-bytes", type=float, default=1431220224.0,
                     help="HBM bytes per k_front launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes); reported as roofline.traffic when the workload is the default 2^28 frames")
     return ap.parse_args()
 
