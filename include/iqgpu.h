@@ -11,7 +11,9 @@
  *   - the caller owns every host buffer; handles are opaque; one thread per handle; handles are
  *     independent (one per GPU shard);
  *   - the stream is continuous across calls: any split of the input into calls produces the
- *     same output bytes (all in-scope operators are chunk-size invariant);
+ *     same output bytes (all in-scope operators are chunk-size invariant).  The
+ *     one exception is the reference's own: the output AGC works chunk by chunk, so with
+ *     agc_enable every call is cut into agc_chunk_frames-sized chunks from its first frame;
  *   - nothing is flushed at end of stream (resampler / FIR tails and the FFT-filter remainder
  *     are dropped exactly as the reference drops them, src/filter.c:521-525);
  *   - frames_out may be 0 (resampler group buffering, FFT block quantisation);
@@ -57,7 +59,7 @@ enum {
     IQGPU_EFILTER = -7,     /* filter band beyond output Nyquist, fft size too small, too many stages (src/filter.c:80-84, 321-325) */
     IQGPU_ECAPACITY = -8,   /* out_capacity_bytes too small for this call */
     IQGPU_EHIP = -9,        /* a HIP runtime call failed */
-    IQGPU_EUNSUPPORTED = -10/* configuration valid for the reference but not built yet */
+    IQGPU_EUNSUPPORTED = -10/* valid for the reference but not built: AGC profiles dx / local (liquid agc_crcf), see DESIGN.md */
 };
 
 typedef struct iqgpu_chain iqgpu_chain; /* opaque, like resampler_t (include/resampler.h:25-26) */
