@@ -518,12 +518,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      shape) -- the same arithmetic with every run-time switch resolved at compile time
 //      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
-//      The FAST instantiation fits 4 waves per SIMD (121 VGPRs): 16 waves per workgroup; the others run 12.
+//      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
 template <int BPS, bool FAST, bool S0 = false>
-__global__ __launch_bounds__(FAST ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
+__global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int kThr = FAST ? kS1Threads : kWThreads, kWv = FAST ? kS1Waves : kWaves;
+    constexpr int kThr = (FAST || BPS == 2) ? kS1Threads : kWThreads, kWv = (FAST || BPS == 2) ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf2   *s_nco = (cf2 *)smem;
@@ -586,12 +586,19 @@ static bool front_s1_fast_shape(const FrontArgs &a)
            !a.dc_enable && a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
 }
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
-int front_s1_waves(const FrontArgs &a) { return front_s1_fast_shape(a) ? kS1Waves : kWaves; }
+static bool front_s1_sixteen(const FrontArgs &a)
+{
+    // 4 waves per SIMD where the instantiation fits 128 VGPRs (nearly) without scratch: the specialised one,
+    // and the 8-bit-input ones (2 - 4 spilled dwords; measured -8 % on the cu8-nrsc5 shape, -4 % on cu8 -> cs16).
+    // The cs16 / cf32-input run-time-switched ones spill 7 - 21 dwords there and are faster with 12 waves.
+    return front_s1_fast_shape(a) || a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8;
+}
+int front_s1_waves(const FrontArgs &a) { return front_s1_sixteen(a) ? kS1Waves : kWaves; }
 
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 {
     const bool fast = front_s1_fast_shape(a);
-    const int waves = fast ? kS1Waves : kWaves;
+    const int waves = front_s1_sixteen(a) ? kS1Waves : kWaves;
     const size_t lds = (size_t)kTabLds + (size_t)waves * kWaveLds;
     const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
