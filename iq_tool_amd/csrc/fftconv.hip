@@ -253,7 +253,7 @@ __device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int N, int lo
     }
 }
 
-__global__ __launch_bounds__(512) void k_fftconv16(const FftConvArgs a)
+__global__ __launch_bounds__(1024) void k_fftconv16(const FftConvArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, T = blockDim.x;                     // T = N / 16
@@ -308,7 +308,7 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
     }
     if (a.n_emit <= 0) return hipSuccess;
     const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
-    if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
+    if (V <= 0 || N > kMaxFftN4) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
     const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
     static LdsAttrCache cache;

@@ -413,8 +413,9 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         const size_t Lt = c->fp.taps.size();
         if (c->fp.enabled && !c->force_generic && Lt >= 2 && 2 * (Lt - 1) <= (size_t)kMaxFftN &&
             (c->fp.block > 0 || Lt >= (size_t)kFftMinTaps)) {
-            // N = 4 (L-1) rounded up to a power of two in [256, 4096] (two workgroups per CU), 8192 only
-            // when the taps need it; measured on config 3: N 4096 0.61 ms, N 8192 0.70 ms
+            // N = 4 (L-1) rounded up to a power of two in [256, 4096], larger (up to 16384, in place in LDS) only
+            // when the taps need it; measured with k_fftconv16 on config 3 (1025 taps): N 4096 0.39 ms, 8192 0.44,
+            // 16384 0.59; on config 4 (4097 taps): N 8192 0.275 ms, 16384 0.30
             int lg = 8;
             while ((size_t)(1 << lg) < 4 * (Lt - 1) && (1 << lg) < 4096) ++lg;
             while ((size_t)(1 << lg) < 2 * (Lt - 1)) ++lg;

@@ -205,7 +205,8 @@ hipError_t launch_fir(const FirArgs &a, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // k_fftconv: FFT-kind user filter as overlap-save block convolution in LDS (fftconv.hip)
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxFftN = 8192;     // 2 x N cf32 ping-pong = 128 KiB of LDS
+constexpr int kMaxFftN = 16384;    // k_fftconv16 transforms in place: N cf32 = 128 KiB (+ pad) of LDS
+constexpr int kMaxFftN4 = 8192;    // the radix-4 ping-pong kernel (only used below N = 1024)
 constexpr int kFftMaxThreads = 1024;
 struct FftConvArgs {
     const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]

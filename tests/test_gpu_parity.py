@@ -360,7 +360,7 @@ def test_fft_filter_block_quantised_counts(gpu, oracle):
         pos += n
 
 
-@pytest.mark.parametrize("taps,fft_size", [(33, 0), (129, 1024), (1025, 0), (2049, 8192)])
+@pytest.mark.parametrize("taps,fft_size", [(33, 0), (129, 1024), (1025, 0), (2049, 8192), (6001, 0)])
 def test_fft_overlap_save_kernel_agrees_with_direct_form(gpu, oracle, monkeypatch, taps, fft_size):
     """k_fftconv (overlap-save in LDS) and k_fir (direct form) are the same linear convolution"""
     from iq_tool_amd import ops
