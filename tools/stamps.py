@@ -24,7 +24,7 @@ ch._lib.iqgpu_chain_debug_read_scratch(ch._h, buf.ctypes.data_as(C.c_void_p))
 ch.process_device(d_in.ptr, frames, d_out.ptr, d_out.nbytes)
 ch._lib.iqgpu_chain_debug_read_scratch(ch._h, buf.ctypes.data_as(C.c_void_p))
 acc = buf[32768:32768 + 64].view(np.uint64).astype(np.float64)
-names = ["wait loads", "unpack+nco+lds write", "half-band", "arb: window+taps read", "arb: fma", "pack+store+k", "slide", "-"]
+names = ["wait loads + unpack", "stores + cmul + X write", "(unused)", "half-band + window + tap gathers", "polyphase fma", "pack + k", "slide", "-"]
 tiles = frames / 512 * (1 + 1 / 32.0)
 tot = acc.sum()
 for n, v in zip(names, acc):
