@@ -3,19 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (launched with torch.distributed.run for N > 1).  A step is one pass of the
+One process per GPU: under torch.distributed.run the ranks come from the environment; run plainly with
+--gpus N > 1 the script spawns its N workers itself (before anything touches the GPU) and rank 0's
+line is printed.  A step is one pass of the
 hot path (iqgpu_chain_process_device: unpack -> NCO +200 kHz -> half-band -> 256-arm polyphase ->
 pack) over one batch of 2^28 synthetic cs16 frames that is already resident in HBM; the stream is
 continuous from step to step.  Every rank works on its own independent shard (seed 10 + rank), as
 BASELINE.json configs[4] prescribes: no data-path collective, weak scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_front) with HIP events
-recorded on the chain's stream inside the timed region; `cpu_baseline` times the oracle's
-float-accumulator build (a port, 1 core) on a bounded sample of the same workload (N = 1 only).
+recorded on the chain's stream inside the timed region; `host_end_to_end` is a second, separate timed
+leg through the pipelined host entry point (pinned host buffers -> H2D -> kernels -> D2H, PCIe-bound,
+never `value`); `cpu_baseline` times the oracle's float-accumulator build (a port) on a bounded
+sample of the same workload (N = 1 only).  Barrier and MAX-over-ranks time go over gloo: the data path
+has no collective and no RCCL.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,9 +59,67 @@ def parse():
     ap.add_argument("--cpu-frames-log2", type=int, default=28, help="bounded CPU-baseline sample (2^28 = one step's batch, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="2 = BASELINE configs[1] (the metric's config, default); 3 / 4 = configs[2] / configs[3], secondary timings")
-    ap.add_argument("--traffic-bytes", type=float, default=1431220224.0,
-                    help="HBM bytes per k_front launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes); reported as roofline.traffic when the workload is the default 2^28 frames")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host_end_to_end leg")
+    ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
+    ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
     return ap.parse_args()
+
+
+KERNEL_SOURCES = ("front_wave.hip", "wave_common.hpp", "dsp_device.hpp", "kernels.hpp")
+
+
+def kernel_sha():
+    """identity of the headline kernel's sources: PMC traffic measured for another build is not reported"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "iq_tool_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(log2_frames):
+    """HBM bytes per k_front launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/traffic_from_pmc.py writes profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes).
+    Only reported for the very kernel sources and workload size it was measured on; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        if t.get("kernel_sha") == kernel_sha() and int(t.get("log2_frames", -1)) == log2_frames:
+            return float(t["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def spawn_workers(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent
+    never imports torch or touches HIP (a process that has initialised the GPU must not be replaced or
+    forked on this pool); it only relays rank 0's line and the worst exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def shard_plan(world_size, rank, frames_per_gpu):
@@ -75,12 +141,63 @@ def timed_region(dist, sync, step_fn, steps):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        if torch.cuda.is_available() and dist.get_backend() == "nccl":
-            t = t.cuda()
+        t = torch.tensor([dt], dtype=torch.float64)          # host tensor: the control plane is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def host_leg(dist, chain, seg, frames_total, batch):
+    """The same chain fed from pinned HOST memory through iqgpu_chain_submit / _collect: H2D copy, kernels
+    and D2H copy of consecutive batches overlap on the library's internal streams (what the reference's
+    reader -> DSP threads -> writer hand-off becomes, src/pipeline.c:96-116).  PCIe-bound; returns
+    (seconds MAX over ranks, frames, bytes up, bytes down) for this rank."""
+    from iq_tool_amd.chain import PinnedBuffer
+    depth = chain._lib.iqgpu_chain_pipeline_depth()
+    in_b, out_b = chain.in_bytes, chain.out_bytes
+    cap = chain.max_out_frames(batch) * out_b
+    seg_u8 = np.ascontiguousarray(seg).view(np.uint8).reshape(-1)
+    slots = []
+    for _ in range(depth):
+        ib, ob = PinnedBuffer(batch * in_b), PinnedBuffer(cap)
+        reps = -(-ib.nbytes // seg_u8.size)
+        ib.array[:] = np.tile(seg_u8, reps)[:ib.nbytes]
+        slots.append((ib, ob))
+    n_batches = max(depth, frames_total // batch)
+    state = dict(down=0)
+
+    def run():
+        flight = []
+        for i in range(n_batches):
+            if len(flight) == depth:
+                chain.collect(flight.pop(0))
+            ib, ob = slots[i % depth]
+            got, t = chain.submit(ib.ptr, batch, ob.ptr, cap)
+            state["down"] += got * out_b
+            flight.append(t)
+        for t in flight:
+            chain.collect(t)
+
+    run()                                             # warm: buffers grown, pages touched
+    state["down"] = 0
+    dt = timed_region(dist, lambda: None, run, 1)
+    for ib, ob in slots:
+        ib.free(); ob.free()
+    return dt, n_batches * batch, n_batches * batch * in_b, state["down"]
+
+
+def algorithmic_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
+    """FP32 flops of one step in the reference's own formulation: real x complex MAC = 4,
+    complex x complex = 8; half-band stage i: 2 m_i taps per output at rate / 2^(i+1); polyphase 14 taps
+    per output; user filter as the direct form it is specified as (the product may run it as overlap-save)."""
+    f = frames * (2.0 + (6.0 if desc_kw.get("shift_hz") else 0.0) + (8.0 if desc_kw.get("dc_block") else 0.0)
+                  + (3.0 if desc_kw.get("iq_correct") else 0.0))
+    for i in range(info.num_halfband_stages):
+        f += (frames / float(1 << (i + 1))) * (2 * info.stage_m[i] * 4 + 2)
+    f += n_res * 14 * 4
+    f += n_emit * ntaps * (8 if taps_complex else 4)
+    f += n_emit * 4.0
+    return f
 
 
 def cpu_baseline(frames_log2):
@@ -107,7 +224,7 @@ def cpu_baseline(frames_log2):
     dt3 = time.perf_counter() - t0
     assert out3.size == out.size
     v1, v3 = n / dt1 / 1e6, n / dt3 / 1e6
-    return dict(value=round(max(v1, v3), 3), unit="MS/s", cores=3 if v3 > v1 else 1, kind="port",
+    return dict(value=round(max(v1, v3), 3), unit="MS/s", cores=3 if v3 > v1 else 1, cpu=cpu_model(), host_cores=os.cpu_count(), kind="port",
                 sample="2^%d cs16 frames of the same NRSC-5 chain, oracle/liboracle_fast.so (float accumulators): "
                        "%.1f MS/s on 1 thread, %.1f MS/s as 3 stage threads (pre / resampler / post, 16384-frame chunks)"
                        % (frames_log2, v1, v3))
@@ -115,27 +232,41 @@ def cpu_baseline(frames_log2):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_workers(args))         # parent: no torch, no HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
     import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)                                  # gloo announces its mesh on stdout: rank 0's stdout is ONE JSON line
+        try:
+            dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)   # barrier + MAX only
+            dist_mod.barrier()
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+        dist = dist_mod
+    if os.environ.get("IQGPU_BENCH_STUB") == "1":
+        return stub_main(args, dist, world, rank)     # launcher / reduction plumbing test (tests/test_host_logic.py)
+
     import iq_tool_amd
     from iq_tool_amd import synth
 
     lib = iq_tool_amd.load()                          # raises when libiqgpu.so is missing
     if lib.iqgpu_device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
-        dist = dist_mod
+    if local_rank >= lib.iqgpu_device_count():
+        raise SystemExit("rank %d has no GPU: %d devices visible" % (local_rank, lib.iqgpu_device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -187,6 +318,17 @@ def main():
     alg_bytes = frames * in_bps + n_out_avg * chain.out_bytes   # in_bytes + r * out_bytes per input frame
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
+    # ---- second leg: the same chain fed from pinned host memory (PCIe-inclusive; never `value`) ----
+    host = None
+    if not args.no_host_leg and args.config == 2:
+        chain.set_stream(0)                            # back to the chain's own stream
+        chain.reset()
+        h_dt, h_frames, h_up, h_down = host_leg(dist, chain, seg, 1 << args.host_log2_frames, 1 << args.host_batch_log2)
+        host = {"value": round(world * h_frames / h_dt / 1e6, 2), "unit": "MS/s",
+                "h2d_GBs": round(h_up / h_dt / 1e9, 2), "d2h_GBs": round(h_down / h_dt / 1e9, 2),
+                "frames_per_gpu": h_frames, "batch_frames": 1 << args.host_batch_log2,
+                "path": "pinned host buffers -> iqgpu_chain_submit (H2D, kernels, D2H on %d internal streams) -> iqgpu_chain_collect; h2d/d2h per GPU" % chain._lib.iqgpu_chain_pipeline_depth()}
+
     if rank == 0:
         line = {
             "metric": "complex MS/s end-to-end on NRSC-5 resample+filter chain; % HBM roofline",
@@ -197,23 +339,44 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(seg_frames)), args.log2_frames),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES,
-                       "sharding": "independent stream per GPU, no collective"},
+                       "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic_bytes if args.log2_frames == 28 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.log2_frames) if args.config == 2 else None,
                          "kernel": "k_front_s1<4, true>" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
+            "host_end_to_end": host,
         }
         if args.config != 2:
+            # configs 3 / 4 are ALU-bound: price them against the FP32 vector peak, HBM fraction kept beside it
+            info = chain.info()
+            flops = algorithmic_flops(info, frames, n_out_avg if not info.filter_ntaps else n_out_avg, n_out_avg, chain_kw,
+                                      int(info.filter_ntaps), info.filter_impl in (2, 4))
+            tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             line["config"]["workload"] = workload
-            line["roofline"]["traffic"] = None
-            line["roofline"]["kernel"] = "all kernels of the step"
-            line["roofline"]["note"] = "per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])
+            line["roofline"] = {"bound": "fp32", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                                "traffic": None, "kernel": "all kernels of the step", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
+                                "algorithmic_flops_per_step": int(flops), "algorithmic_bytes_per_step": int(alg_bytes),
+                                "hbm_GBs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                                "note": "per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])}
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def stub_main(args, dist, world, rank):
+    """IQGPU_BENCH_STUB=1: the launcher, barrier and MAX-over-ranks plumbing with a sleep in place of the GPU
+    step -- what tests/test_host_logic.py runs on a machine without a GPU.  Never a measurement."""
+    plan = shard_plan(world, rank, 1 << args.log2_frames)
+    dt = timed_region(dist, lambda: None, lambda: time.sleep(0.002 * (1 + rank)), args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * args.steps * plan["frames"] / dt / 1e6, "unit": "MS/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "data": "stub (no GPU work)",
+                          "scaling": "weak"}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

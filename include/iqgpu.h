@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IQGPU_ABI_VERSION 2
+#define IQGPU_ABI_VERSION 3
 
 /* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
 enum {
@@ -168,6 +168,18 @@ int    iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t frames_in,
  * chain's stream; *frames_out is exact on return (it is a closed form of the stream position). */
 int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
                                   void *d_out, size_t out_capacity_bytes, size_t *frames_out);
+/* Pipelined form of iqgpu_chain_process for a stage thread that must not stall on PCIe: submit() queues the
+ * H2D copy, the kernels and the D2H copy of one batch on an internal stream and returns at once with the
+ * batch's exact *frames_out (a closed form of the stream position) and a ticket; collect() blocks until that
+ * batch's output bytes are in `out`.  Up to iqgpu_chain_pipeline_depth() batches may be in flight; copies of one
+ * batch overlap the kernels of its neighbours.  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
+ * pageable memory works but serialises -- and must stay untouched until the ticket is collected.  Batches are
+ * processed in submit order: the stream is continuous across them exactly as across iqgpu_chain_process calls
+ * (this is what replaces the reference's chunk hand-off between its three stage threads, src/pipeline.c:436-595). */
+int    iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t frames_in,
+                          void *out, size_t out_capacity_bytes, size_t *frames_out, uint64_t *ticket);
+int    iqgpu_chain_collect(iqgpu_chain *c, uint64_t ticket);
+int    iqgpu_chain_pipeline_depth(void);
 /* == pre_processor_reset + resampler_reset + post_processor_reset (stream discontinuity) */
 int    iqgpu_chain_reset(iqgpu_chain *c);
 /* what the I/Q optimiser thread publishes (src/iq_correct.c:141-152 reads them once per chunk) */

@@ -75,6 +75,9 @@ SYMBOLS = [
     ("iqgpu_design_probe", C.c_int, [C.POINTER(ChainDesc), C.POINTER(ChainInfo), _vp, _sz, _vp, _sz, _vp, _sz]),
     ("iqgpu_chain_process", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_process_device", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("iqgpu_chain_submit", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64)]),
+    ("iqgpu_chain_collect", C.c_int, [_vp, C.c_uint64]),
+    ("iqgpu_chain_pipeline_depth", C.c_int, []),
     ("iqgpu_chain_reset", C.c_int, [_vp]),
     ("iqgpu_chain_get_agc_state", C.c_int, [_vp, C.POINTER(AgcState)]),
     ("iqgpu_chain_set_iq_factors", C.c_int, [_vp, C.c_float, C.c_float]),

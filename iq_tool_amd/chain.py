@@ -122,6 +122,48 @@ class Chain:
                                                    C.c_void_p(d_out), out_capacity_bytes, C.byref(got)))
         return got.value
 
+    def submit(self, in_ptr, frames_in, out_ptr, out_capacity_bytes):
+        """Queues H2D copy -> kernels -> D2H copy of one batch (host addresses, preferably pinned) and
+        returns (frames_out, ticket) at once; collect(ticket) waits for the output bytes."""
+        got, ticket = C.c_size_t(0), C.c_uint64(0)
+        check(self._lib.iqgpu_chain_submit(self._h, C.c_void_p(in_ptr), frames_in, C.c_void_p(out_ptr),
+                                           out_capacity_bytes, C.byref(got), C.byref(ticket)))
+        return got.value, ticket.value
+
+    def collect(self, ticket):
+        check(self._lib.iqgpu_chain_collect(self._h, C.c_uint64(ticket)))
+
+    def process_pipelined(self, raw, batch_frames):
+        """process() through submit / collect: the stream in batches of batch_frames with up to
+        iqgpu_chain_pipeline_depth() of them in flight, pinned staging buffers on both sides."""
+        raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        n = raw.nbytes // self.in_bytes
+        depth = self._lib.iqgpu_chain_pipeline_depth()
+        cap = self.max_out_frames(batch_frames) * self.out_bytes
+        slots = [(PinnedBuffer(batch_frames * self.in_bytes), PinnedBuffer(cap)) for _ in range(depth)]
+        outs, flight = [], []
+
+        def drain_one():
+            t, got, ob = flight.pop(0)
+            self.collect(t)
+            outs.append(ob.array[:got * self.out_bytes].copy())
+
+        pos = i = 0
+        while pos < n:
+            f = min(batch_frames, n - pos)
+            if len(flight) == depth:
+                drain_one()
+            ib, ob = slots[i % depth]
+            ib.array[:f * self.in_bytes] = raw[pos * self.in_bytes:(pos + f) * self.in_bytes]
+            got, t = self.submit(ib.ptr, f, ob.ptr, cap)
+            flight.append((t, got, ob))
+            pos += f
+            i += 1
+        while flight:
+            drain_one()
+        out = np.concatenate(outs) if outs else np.empty(0, np.uint8)
+        return out.view(_NP_VIEW[self.desc.out_format]).copy()
+
     def reset(self):
         check(self._lib.iqgpu_chain_reset(self._h))
 
@@ -153,6 +195,26 @@ class Chain:
         check(self._lib.iqgpu_chain_get_profile(self._h, C.byref(p)))
         return {name: dict(launches=int(p.launches[i]), ms=float(p.ms[i]))
                 for i, name in enumerate(_lib.K_NAMES)}
+
+
+class PinnedBuffer:
+    """hipHostMalloc'd (page-locked) host buffer with a numpy view, for submit() / collect()."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(self._lib.iqgpu_host_malloc_pinned(self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.iqgpu_host_free_pinned(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    __del__ = free
 
 
 class DeviceBuffer:

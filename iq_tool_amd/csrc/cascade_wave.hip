@@ -307,14 +307,14 @@ __global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
         // position of this run among the dc-carry segments: edge runs of the first region, streaming runs,
         // edge runs of the second region (kernels.hpp, DcGeom mode 1)
-        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + (a.w_fast_g1 - a.w_fast_g0));
+        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);
         casc_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
-        const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
-        if (g >= a.w_fast_g1) return;
-        const int64_t t0 = g * a.w_tiles_per_wave;
-        const int seg = (int)(a.w_n_edge1 + (gw - a.w_n_edge));
-        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
+        const int64_t r = gw - a.w_n_edge;
+        if (r >= a.w_n_stream) return;
+        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        const int seg = (int)(a.w_n_edge1 + r);
+        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -339,7 +339,7 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
 {
     const int waves = cascade_waves(a);
     const size_t lds = 1024 * 8 + (size_t)waves * a.casc_wave_lds;
-    const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
+    const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
     int cls;
@@ -352,11 +352,7 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
 #define IQGPU_LAUNCH_CASC(BPS)                                                                                         \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        if (cache.needs(lds)) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void *)k_cascade<BPS>,                                          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-            if (e != hipSuccess) return e;                                                                            \
-        }                                                                                                             \
+        { const hipError_t e = cache.ensure((const void *)k_cascade<BPS>, lds); if (e != hipSuccess) return e; }     \
         hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(waves * 64), lds, s, a);                                   \
     } while (0)
     if (cls == 2) IQGPU_LAUNCH_CASC(2);

@@ -299,10 +299,7 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
         const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
         const size_t lds = (size_t)(N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
         static LdsAttrCache cache16;
-        if (lds > 64 * 1024 && cache16.needs(lds)) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_fftconv16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
+        if (lds > 64 * 1024) { const hipError_t e = cache16.ensure((const void *)k_fftconv16, lds); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_fftconv16, dim3(nb), dim3(N / 16), lds, s, a);
         return hipGetLastError();
     }
@@ -312,10 +309,7 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
     const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
     const size_t lds = (size_t)2 * (N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
     static LdsAttrCache cache;
-    if (lds > 64 * 1024 && cache.needs(lds)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_fftconv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 64 * 1024) { const hipError_t e = cache.ensure((const void *)k_fftconv, lds); if (e != hipSuccess) return e; }
     int nthr = a.threads > 0 ? a.threads : (N >= 8192 ? 1024 : (N >= 4096 ? 512 : 256));
     if (nthr > kFftMaxThreads) nthr = kFftMaxThreads;
     while (nthr * kFftMaxB < (N >> 2)) nthr *= 2;                   // at most kFftMaxB radix-4 butterflies per thread

@@ -99,6 +99,24 @@ __device__ __forceinline__ int out_bytes(int fmt)
 #define STAMP_FLUSH(sinkbase) do { } while (0)
 #endif
 
+// in-kernel shader clock of the streaming loop (diagnostic build only: -DIQGPU_CLOCKSTAMP): per wave,
+// cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of its whole run, summed into a.sink[32 KiB + 128 ...]
+#ifdef IQGPU_CLOCKSTAMP
+#define CLOCK_BEGIN const unsigned long long ck_c0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime()
+#define CLOCK_END(sinkbase) do { const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime(); \
+        if (lane == 0) { unsigned long long *d_ = (unsigned long long *)((char *)(sinkbase) + 32768 + 128); \
+            if (!EDGE) { atomicAdd(d_, c1_ - ck_c0); atomicAdd(d_ + 1, r1_ - ck_r0); atomicAdd(d_ + 2, 1ull); } \
+            const unsigned gw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                               \
+            if (gw_ < 4096u) { unsigned *w_ = (unsigned *)(sinkbase);                                               \
+                w_[gw_] = (unsigned)ck_r0; w_[4096 + gw_] = (unsigned)r1_;                                         \
+                unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                \
+                w_[(32768 + 256) / 4 + gw_] = (hw_ & 0xffffu) | (xcc_ << 16) | (EDGE ? 0x80000000u : 0u); } } } while (0)
+#else
+#define CLOCK_BEGIN do { } while (0)
+#define CLOCK_END(sinkbase) do { } while (0)
+#endif
+
 struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };
 
 // first output at or after the lane's first half-band sample (4*lane), for a tile whose first
@@ -223,6 +241,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     float sl_hist = 0.0f;         // one dword per lane (< 48) of the last 4 rows of the polyphase input
     STAMP_DECL
     STAMP_BEGIN;
+    CLOCK_BEGIN;
     for (int64_t t = t_begin; t < t_emit1; ++t) {
         const int64_t i0 = t * TILE;
         const int64_t j0 = i0 - a.rem0;
@@ -510,6 +529,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         STAMP(6);
     }
     if (defer) flush_pending();
+    CLOCK_END(a.sink);
     STAMP_FLUSH(a.sink);
 }
 
@@ -569,14 +589,14 @@ __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
-        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + (a.w_fast_g1 - a.w_fast_g0));   // DcGeom mode 1 order
+        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);   // DcGeom mode 1 order
         run_tiles<BPS, true, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
-        const int64_t g = a.w_fast_g0 + (gw - a.w_n_edge);
-        if (g >= a.w_fast_g1) return;
-        const int64_t t0 = g * a.w_tiles_per_wave;
-        const int seg = (int)(a.w_n_edge1 + (gw - a.w_n_edge));
-        if (BPS != 0) run_tiles<BPS, false, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t0 + a.w_tiles_per_wave, seg);
+        const int64_t r = gw - a.w_n_edge;
+        if (r >= a.w_n_stream) return;
+        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        const int seg = (int)(a.w_n_edge1 + r);
+        if (BPS != 0) run_tiles<BPS, false, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -600,7 +620,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     const bool fast = front_s1_fast_shape(a);
     const int waves = front_s1_sixteen(a) ? kS1Waves : kWaves;
     const size_t lds = (size_t)kTabLds + (size_t)waves * kWaveLds;
-    const int64_t n_items = a.w_n_edge + (a.w_fast_g1 - a.w_fast_g0);
+    const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
     int cls;
@@ -613,11 +633,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0)                                                                                \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        if (cache.needs(lds)) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void *)k_front_s1<BPS, FAST, S0>,                                                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-            if (e != hipSuccess) return e;                                                                            \
-        }                                                                                                             \
+        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0>, lds); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0>), dim3(grid), dim3(waves * 64), lds, s, a);                     \
     } while (0)
     if (a.S == 0) {
@@ -635,8 +651,12 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// Splits the call's tiles into streaming sub-blocks (all tiles vector-loadable) and edge runs.
-void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tpw, int tile_frames)
+// Splits the call's tiles into streaming runs (all tiles vector-loadable) and edge runs.  With fixed_tpw == 0
+// the streaming tiles are dealt out as evenly as possible over the wave slots the edge runs leave free, so
+// that the whole call is ONE round of resident workgroups: a grid one workgroup over the CU count runs that
+// workgroup behind the first one to finish and nearly doubles the launch (measured in round 2: wave runs
+// 0.39 ms, launch 0.58 ms with 4 workgroups of edge runs in front of 256 streaming ones).
+void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames)
 {
     const int kWTile = tile_frames;                 // 512 with a half-band stage in the kernel, 256 without
     const int64_t total = a.w_total_tiles;
@@ -647,28 +667,37 @@ void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tp
     case IQGPU_FMT_CF32: vb = 8; break;
     default: vb = 0; break;
     }
-    a.w_tiles_per_wave = tiles_per_wave;
     a.w_warm_tiles = warm_tiles;
     a.w_edge_tpw = edge_tpw;
-    int64_t g0 = 0, g1 = 0;
+    int64_t ta = total, tb = total;
     // (cs24 output takes six byte stores per frame: the streaming loop counts on one)
     if (vb != 0 && a.out_fmt != IQGPU_FMT_CS24 && a.raw_aligned && (((int64_t)a.rem0 * vb) & 15) == 0) {
         // tile t is streamable iff 512 t - rem0 >= 0 and 512 (t + 1) - rem0 <= frames_in - hist_cap
         const int64_t t_min = (a.rem0 + kWTile - 1) / kWTile;
         const int64_t lim = a.frames_in - (int64_t)a.hist_cap + a.rem0;
         const int64_t t_max = lim >= kWTile ? lim / kWTile - 1 : -1;              // last streamable tile
-        // sub-block g touches tiles [g tpw - warm, (g + 1) tpw] (one past its end for the prefetch)
-        g0 = (t_min + warm_tiles + tiles_per_wave - 1) / tiles_per_wave;
-        g1 = (t_max >= 0) ? (t_max / tiles_per_wave) : 0;                          // g1 * tpw <= t_max
-        if (g1 < g0) g1 = g0;
+        // a run over tiles [t0, t1) touches tiles [t0 - warm, t1] (one past its end for the prefetch)
+        if (t_max > t_min + warm_tiles) { ta = t_min + warm_tiles; tb = t_max; }
     }
-    a.w_fast_g0 = g0; a.w_fast_g1 = g1;
-    if (g1 > g0) { a.w_edge_ta = g0 * tiles_per_wave; a.w_edge_tb = g1 * tiles_per_wave; }
-    else { a.w_edge_ta = total; a.w_edge_tb = total; }
-    if (a.w_edge_ta > total) a.w_edge_ta = total;
-    if (a.w_edge_tb > total) a.w_edge_tb = total;
-    a.w_n_edge1 = (a.w_edge_ta + edge_tpw - 1) / edge_tpw;
-    a.w_n_edge = a.w_n_edge1 + (total - a.w_edge_tb + edge_tpw - 1) / edge_tpw;
+    if (ta > total) ta = total;
+    if (tb > total) tb = total;
+    a.w_edge_ta = ta; a.w_edge_tb = tb;
+    a.w_n_edge1 = (ta + edge_tpw - 1) / edge_tpw;
+    a.w_n_edge = a.w_n_edge1 + (total - tb + edge_tpw - 1) / edge_tpw;
+    const int64_t ns = tb - ta;
+    a.w_n_stream = 0; a.w_run_q = 0; a.w_run_r = 0;
+    if (ns > 0) {
+        int64_t w;
+        if (fixed_tpw > 0) {
+            w = (ns + fixed_tpw - 1) / fixed_tpw;
+        } else {
+            w = wave_slots - a.w_n_edge;
+            const int64_t w_cap = (ns + 3) / 4;     // short calls: runs of at least 4 tiles (each re-runs warm-up tiles)
+            if (w > w_cap) w = w_cap;
+            if (w < 1) w = 1;
+        }
+        a.w_n_stream = w; a.w_run_q = ns / w; a.w_run_r = ns % w;
+    }
 }
 
 } // namespace iqgpu

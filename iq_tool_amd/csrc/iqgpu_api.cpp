@@ -90,6 +90,7 @@ struct DevBuf {
 };
 
 struct iqgpu_chain {
+    static constexpr int kPipeSlots = 4;
     iqgpu_chain_desc desc;
     int device = 0;
     float ratio = 1.0f;
@@ -140,6 +141,17 @@ struct iqgpu_chain {
     int ihist = 0;
     float *d_ihb = nullptr;
     DevBuf stage_in, stage_out;
+    // pipelined host entry point (iqgpu_chain_submit / _collect): kPipeSlots batches in flight, each slot with
+    // its own in-order stream (H2D -> kernels -> D2H); kernels of consecutive tickets are chained by events
+    // because the chain's device state (histories, filter buffers, AGC) is carried from call to call
+    struct PipeSlot {
+        hipStream_t s = nullptr; hipEvent_t kernels_done = nullptr, all_done = nullptr;
+        DevBuf d_in, d_out; uint64_t ticket = 0; bool busy = false;
+    };
+    PipeSlot pipe[kPipeSlots];
+    bool pipe_ready = false; uint64_t pipe_seq = 0; hipEvent_t pipe_prev_kernels = nullptr;
+    bool direct_dirty = false;    // process_device ran on the chain's own stream since the last synchronisation
+    bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     // profiling
     bool profiling = false;
@@ -206,6 +218,12 @@ static void free_device_state(iqgpu_chain *c)
     c->fbuf[0].release(); c->fbuf[1].release();
     c->ibuf[0].release(); c->ibuf[1].release();
     c->stage_in.release(); c->stage_out.release();
+    for (auto &ps : c->pipe) {
+        ps.d_in.release(); ps.d_out.release();
+        if (ps.kernels_done) (void)hipEventDestroy(ps.kernels_done);
+        if (ps.all_done) (void)hipEventDestroy(ps.all_done);
+        if (ps.s) (void)hipStreamDestroy(ps.s);
+    }
     for (auto &pe : c->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -306,6 +324,9 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
         c->agc = true;
         c->agc_target = d->agc_target > 0.0f ? d->agc_target : 0.9f;      // AGC_DIGITAL_PEAK_TARGET
         c->agc_chunk = d->agc_chunk_frames ? (int64_t)d->agc_chunk_frames : 16384;   // PIPELINE_CHUNK_BASE_SAMPLES
+        // k_agc_scan adds the output lengths of 64 chunks in 32 bits
+        if ((double)c->agc_chunk * (double)(c->ratio > 1.0f ? c->ratio : 1.0f) * 64.0 >= 2147483648.0)
+            return fail(IQGPU_EINVAL, "agc_chunk_frames %lld is too large for this ratio (64 chunks must stay below 2^31 output frames)", (long long)c->agc_chunk);
     }
     if (c->late) {
         InterpArgs &ia = c->ia;
@@ -669,32 +690,30 @@ struct Call {
     FrontArgs cplan;                         // run geometry of the wave-autonomous kernel that sees the raw input
     cf2 *fcur = nullptr, *icur = nullptr;    // filter-input / k_interp-input buffers of this call
 
-    // tiles-per-wave rule of the wave-autonomous kernels (one run per resident wave when auto)
-    int tiles_per_wave(int64_t w_tiles, int waves) const
+    // run rule of the wave-autonomous kernels: one run per resident wave when auto (wave slots of ONE round of
+    // workgroups), else fixed-length runs from block_samples
+    int64_t wave_slots(int waves) const { return (int64_t)c->n_cu * waves; }
+    int fixed_tpw() const
     {
-        int64_t tpw64;
-        if (c->auto_block) {
-            const int64_t slots = (int64_t)c->n_cu * waves;
-            tpw64 = (w_tiles + slots - 1) / slots;
-            if (tpw64 < 4) tpw64 = 4;               // short calls: more, shorter runs (each re-runs one warm-up tile)
-        } else {
-            tpw64 = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
-        }
-        if (tpw64 < 1) tpw64 = 1;
-        if (tpw64 > (1 << 30)) tpw64 = 1 << 30;
-        return (int)tpw64;
+        if (c->auto_block) return 0;
+        int64_t t = (int64_t)c->tiles_per_block * kTile / (16 * kWTile);
+        if (t < 1) t = 1;
+        if (t > (1 << 30)) t = 1 << 30;
+        return (int)t;
     }
     void copy_plan(FrontArgs &dst) const
     {
-        dst.w_total_tiles = cplan.w_total_tiles; dst.w_tiles_per_wave = cplan.w_tiles_per_wave;
+        dst.w_total_tiles = cplan.w_total_tiles;
         dst.w_warm_tiles = cplan.w_warm_tiles; dst.w_edge_tpw = cplan.w_edge_tpw;
-        dst.w_fast_g0 = cplan.w_fast_g0; dst.w_fast_g1 = cplan.w_fast_g1;
+        dst.w_n_stream = cplan.w_n_stream; dst.w_run_q = cplan.w_run_q; dst.w_run_r = cplan.w_run_r;
         dst.w_edge_ta = cplan.w_edge_ta; dst.w_edge_tb = cplan.w_edge_tb;
         dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
     }
     int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
 
     void plan_geometry();
+    DcGeom dc_geom() const;
+    AgcGeom agc_geom() const;
     int stage_dc_carries();
     int prepare_buffers();
     int stage_front();
@@ -745,19 +764,19 @@ void Call::plan_geometry()
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, tiles_per_wave(cplan.w_total_tiles, casc ? cascade_waves(cplan) : front_s1_waves(cplan)), warm, 4, wtile);
+        plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : front_s1_waves(cplan)), fixed_tpw(), warm, 4, wtile);
     }
 }
 
-// state of the dc blocker at the start of every independent piece of the front kernel
-int Call::stage_dc_carries()
+// where every independent piece of the front kernel starts (the dc blocker needs its state there)
+DcGeom Call::dc_geom() const
 {
     DcGeom dg{};
     dg.frames_in = (int64_t)frames_in;
     if (casc || fast_s1) {
         dg.mode = 1;
-        dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_fast_g1 - cplan.w_fast_g0;
-        dg.edge_tpw = cplan.w_edge_tpw; dg.tpw = cplan.w_tiles_per_wave; dg.g0 = cplan.w_fast_g0; dg.tb = cplan.w_edge_tb;
+        dg.n_edge1 = cplan.w_n_edge1; dg.n_stream = cplan.w_n_stream;
+        dg.edge_tpw = cplan.w_edge_tpw; dg.run_q = cplan.w_run_q; dg.run_r = cplan.w_run_r; dg.ta = cplan.w_edge_ta; dg.tb = cplan.w_edge_tb;
         dg.warm = cplan.w_warm_tiles; dg.rem0 = rem_k; dg.tile = wtile;
         dg.n_seg = (int)(cplan.w_n_edge + dg.n_stream);
         if (dg.n_seg < 1) dg.n_seg = 1;
@@ -766,8 +785,13 @@ int Call::stage_dc_carries()
         dg.seg_first = ((int64_t)tpb - c->warm_tiles) * kTile - c->rem;
         dg.seg_len = (int64_t)tpb * kTile;
     }
-    int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
-    rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
+    return dg;
+}
+
+// state of the dc blocker at the start of every independent piece of the front kernel
+int Call::stage_dc_carries()
+{
+    const DcGeom dg = dc_geom();
     DcPrefixArgs pa{};
     pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
     pa.raw_aligned = raw_aligned();
@@ -793,6 +817,26 @@ int Call::prepare_buffers()
         int rc = c->ibuf[c->icur].ensure_keep(((size_t)c->ihist + (size_t)p.n_x + 1) * sizeof(cf2), (size_t)c->ihist * sizeof(cf2), c->stream);
         if (rc) return rc;
         icur = (cf2 *)c->ibuf[c->icur].p;
+        rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
+    }
+    // the buffers the later stages write: sized here, before the first launch touches the stream state
+    if (filt) {
+        int rc = c->fbuf[c->fcur ^ 1].ensure((L1 + (size_t)p.fpending_next + 1) * sizeof(cf2)); if (rc) return rc;
+    }
+    if (c->dc) {
+        const DcGeom dg = dc_geom();
+        int rc = c->dc_agg.ensure((size_t)dg.n_seg * sizeof(cf2)); if (rc) return rc;
+        rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
+    }
+    if (casc) {
+        const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> casc_K;
+        int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
+    }
+    if (c->agc) {
+        const AgcGeom g = agc_geom();
+        if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
+        int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
+        rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
     }
     return IQGPU_OK;
 }
@@ -841,7 +885,6 @@ int Call::stage_front()
         const int K = casc_K;
         const int rem_1 = c->rem >> K;
         const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> K;
-        int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
         FrontArgs a1 = a;
         a1.rem0 = rem_k;
         a1.nco_theta0 = c->nco_theta - (uint32_t)rem_k * c->nco_dtheta;
@@ -868,7 +911,7 @@ int Call::stage_front()
             a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
             a2.out_fmt = a.out_fmt; a2.out = a.out;
             a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-            plan_front_s1(a2, tiles_per_wave(a2.w_total_tiles, front_s1_waves(a2)), 1, 4);
+            plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 4);
             for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
             a2.sink = c->d_sink;
             { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
@@ -912,7 +955,6 @@ int Call::stage_filter()
     }
     // next call's buffer front: history (L-1) + still-pending samples
     const size_t keep = L1 + (size_t)p.fpending_next;
-    int rc = c->fbuf[c->fcur ^ 1].ensure((keep + 1) * sizeof(cf2)); if (rc) return rc;
     { KernelTimer kt(c, IQGPU_K_MOVE);
       HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream)); }
     c->fcur ^= 1;
@@ -931,7 +973,6 @@ int Call::stage_late_resampler()
     ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
     ia.out_fmt = fin_fmt; ia.out = fin_out;
     { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
-    int rc = c->ibuf[c->icur ^ 1].ensure(((size_t)c->ihist + 1) * sizeof(cf2)); if (rc) return rc;
     { KernelTimer kt(c, IQGPU_K_MOVE);
       HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
     c->icur ^= 1;
@@ -939,18 +980,22 @@ int Call::stage_late_resampler()
 }
 
 // output AGC: agc_apply per reference chunk (src/post_processor.c:55-57)
-int Call::stage_agc()
+AgcGeom Call::agc_geom() const
 {
-    AgcArgs ga{};
-    AgcGeom &g = ga.geom;
+    AgcGeom g{};
     g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
     g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
     g.mode = c->late ? 2 : (c->decim ? 1 : 0);
     g.rem = c->rem; g.S = c->late ? c->ia.S : c->S; g.phi = c->phi; g.step = c->rp.step;
     g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
-    if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
-    int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
-    rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
+    return g;
+}
+
+int Call::stage_agc()
+{
+    AgcArgs ga{};
+    ga.geom = agc_geom();
+    AgcGeom &g = ga.geom;
     ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
     ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p;
     ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
@@ -968,14 +1013,30 @@ int Call::stage_agc()
 
 } // namespace
 
+static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                               void *d_out, size_t out_capacity_bytes, size_t *frames_out);
+
 extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
                                           void *d_out, size_t out_capacity_bytes, size_t *frames_out)
+{
+    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
+    if (c->pipe_prev_kernels && frames_in) {      // batches submitted earlier come first
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_prev_kernels, 0));
+    }
+    c->direct_dirty = true;
+    return process_device_impl(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out);
+}
+
+static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                               void *d_out, size_t out_capacity_bytes, size_t *frames_out)
 {
     if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
     *frames_out = 0;
     if (frames_in == 0) return IQGPU_OK;
     if (!d_raw_in || !d_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL buffer");
     if (frames_in > ((size_t)1 << 40)) return fail(IQGPU_EINVAL, "frames_in too large");
+    if (c->poisoned) return fail(IQGPU_EHIP, "an earlier call failed half way through: the stream state is undefined until iqgpu_chain_reset()");
     HIP_TRY(hipSetDevice(c->device));
 
     Call k{};
@@ -995,13 +1056,16 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     }
     k.plan_geometry();
 
+    // every buffer the stages need is sized before the first launch, so that an allocation failure leaves the
+    // stream state untouched; a failure after that (a launch error) leaves the device state half advanced:
+    // the handle is poisoned and every later call fails until iqgpu_chain_reset()
     int rc;
-    if (c->dc && (rc = k.stage_dc_carries()) != IQGPU_OK) return rc;
     if ((rc = k.prepare_buffers()) != IQGPU_OK) return rc;
-    if ((rc = k.stage_front()) != IQGPU_OK) return rc;
-    if (k.filt && (rc = k.stage_filter()) != IQGPU_OK) return rc;
-    if (c->late && (rc = k.stage_late_resampler()) != IQGPU_OK) return rc;
-    if (c->agc && (rc = k.stage_agc()) != IQGPU_OK) return rc;
+    if (c->dc && (rc = k.stage_dc_carries()) != IQGPU_OK) { c->poisoned = true; return rc; }
+    if ((rc = k.stage_front()) != IQGPU_OK) { c->poisoned = true; return rc; }
+    if (k.filt && (rc = k.stage_filter()) != IQGPU_OK) { c->poisoned = true; return rc; }
+    if (c->late && (rc = k.stage_late_resampler()) != IQGPU_OK) { c->poisoned = true; return rc; }
+    if (c->agc && (rc = k.stage_agc()) != IQGPU_OK) { c->poisoned = true; return rc; }
 
     // ---- advance the stream position ----
     c->nco_theta += (uint32_t)frames_in * c->nco_dtheta;
@@ -1026,21 +1090,93 @@ extern "C" int iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t fr
         return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
     int rc = c->stage_in.ensure(frames_in * ibps); if (rc) return rc;
     rc = c->stage_out.ensure(n_emit * obps + 16); if (rc) return rc;
+    if (c->pipe_prev_kernels) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_prev_kernels, 0));   // batches submitted earlier come first
     HIP_TRY(hipMemcpyAsync(c->stage_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, c->stream));
     size_t produced = 0;
-    rc = iqgpu_chain_process_device(c, c->stage_in.p, frames_in, c->stage_out.p, c->stage_out.cap, &produced);
+    rc = process_device_impl(c, c->stage_in.p, frames_in, c->stage_out.p, c->stage_out.cap, &produced);
     if (rc) return rc;
     if (produced) HIP_TRY(hipMemcpyAsync(out, c->stage_out.p, produced * obps, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->direct_dirty = false;
     *frames_out = produced;
     return IQGPU_OK;
 }
+
+// ---- pipelined host entry point ----------------------------------------------------------------------
+// submit() queues  H2D copy -> the chain's kernels -> D2H copy  for one batch on one of kPipeSlots in-order
+// streams and returns at once; collect() waits for that batch's output.  Batches on different slots overlap
+// (the H2D copy of ticket n+1 runs under the kernels and the D2H copy of ticket n); the kernels of
+// consecutive tickets are chained by an event because the stream state lives on the device.
+static int pipe_init(iqgpu_chain *c)
+{
+    if (c->pipe_ready) return IQGPU_OK;
+    for (auto &ps : c->pipe) {
+        HIP_TRY(hipStreamCreateWithFlags(&ps.s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ps.kernels_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ps.all_done, hipEventDisableTiming));
+    }
+    c->pipe_ready = true;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t frames_in,
+                                  void *out, size_t out_capacity_bytes, size_t *frames_out, uint64_t *ticket)
+{
+    if (!c || !frames_out || !ticket) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: NULL argument");
+    *frames_out = 0; *ticket = 0;
+    if (frames_in != 0 && (!raw_in || !out)) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = pipe_init(c); if (rc) return rc;
+    iqgpu_chain::PipeSlot &ps = c->pipe[c->pipe_seq % iqgpu_chain::kPipeSlots];
+    if (ps.busy) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: %d batches are in flight; collect ticket %llu first",
+                             iqgpu_chain::kPipeSlots, (unsigned long long)ps.ticket);
+    const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
+    const size_t n_emit = (size_t)plan_call(c, frames_in).n_emit;
+    if (n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
+    size_t produced = 0;
+    if (frames_in) {
+        rc = ps.d_in.ensure(frames_in * ibps); if (rc) return rc;
+        rc = ps.d_out.ensure(n_emit * obps + 16); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ps.d_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, ps.s));
+        if (c->pipe_prev_kernels) HIP_TRY(hipStreamWaitEvent(ps.s, c->pipe_prev_kernels, 0));
+        if (c->direct_dirty) { HIP_TRY(hipStreamSynchronize(c->stream)); c->direct_dirty = false; }   // process_device calls made directly come first
+        hipStream_t keep = c->stream;
+        c->stream = ps.s;
+        rc = process_device_impl(c, ps.d_in.p, frames_in, ps.d_out.p, ps.d_out.cap, &produced);
+        c->stream = keep;
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ps.kernels_done, ps.s));
+        c->pipe_prev_kernels = ps.kernels_done;
+        if (produced) HIP_TRY(hipMemcpyAsync(out, ps.d_out.p, produced * obps, hipMemcpyDeviceToHost, ps.s));
+    }
+    HIP_TRY(hipEventRecord(ps.all_done, ps.s));
+    ps.ticket = ++c->pipe_seq; ps.busy = true;
+    *ticket = ps.ticket; *frames_out = produced;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_collect(iqgpu_chain *c, uint64_t ticket)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    if (ticket == 0 || ticket > c->pipe_seq) return fail(IQGPU_EINVAL, "iqgpu_chain_collect: unknown ticket %llu", (unsigned long long)ticket);
+    iqgpu_chain::PipeSlot &ps = c->pipe[(ticket - 1) % iqgpu_chain::kPipeSlots];
+    if (!ps.busy || ps.ticket != ticket) return IQGPU_OK;        // collected before
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(ps.all_done));
+    ps.busy = false;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_pipeline_depth(void) { return iqgpu_chain::kPipeSlots; }
 
 extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
     // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
+    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));   // batches in flight finish first
+    c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
     if (c->agc) { // agc_reset, src/agc.c:224-238

@@ -323,10 +323,7 @@ hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s)
 {
     const size_t lds = front_lds_bytes(a);
     static LdsAttrCache cache;
-    if (lds > 64 * 1024 && cache.needs(lds)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 64 * 1024) { const hipError_t e = cache.ensure((const void *)k_front, lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_front, dim3((unsigned)n_blocks), dim3(kThreads), lds, s, a);
     return hipGetLastError();
 }

@@ -1,8 +1,16 @@
 // kernels.hpp -- argument blocks and launchers of the gfx950 kernels (defined in kernels.hip).
 #pragma once
+#include <atomic>
+#include <mutex>
 
 #include <cstdint>
 #include <hip/hip_runtime_api.h>
+
+#if defined(__HIPCC__)
+#define IQGPU_HD __host__ __device__
+#else
+#define IQGPU_HD
+#endif
 
 namespace iqgpu {
 
@@ -23,16 +31,23 @@ constexpr int kFirTapChunk = 256;  // taps staged in LDS per pass
 constexpr int kFftMinTaps = 96;    // FIR-kind filters at least this long run as overlap-save (k_fftconv)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and costs a few microseconds: launchers
-// call it once per (kernel instantiation, device, size) through this little cache
+// call it once per (kernel instantiation, device, size) through this little cache.  Handles on one device may
+// be driven by different threads (the harness runs one thread per shard): the size is published only after
+// the attribute call has succeeded, under a lock, so no thread can launch ahead of it and a failure is retried.
 struct LdsAttrCache {
-    size_t configured[64] = {0};
-    bool needs(size_t lds)
+    std::mutex mu;
+    std::atomic<size_t> configured[64];
+    LdsAttrCache() { for (auto &c : configured) c.store(0, std::memory_order_relaxed); }
+    hipError_t ensure(const void *func, size_t lds)
     {
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-        if (lds <= configured[dev]) return false;
-        configured[dev] = lds;
-        return true;
+        const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        if (cached && lds <= configured[dev].load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> g(mu);
+        if (cached && lds <= configured[dev].load(std::memory_order_relaxed)) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && cached) configured[dev].store(lds, std::memory_order_release);
+        return e;
     }
 };
 
@@ -88,10 +103,11 @@ struct FrontArgs {
     int32_t     warm_tiles;
     // geometry of the wave-autonomous fast path (k_front_s1): tiles of kWTile samples
     int64_t     w_total_tiles;
-    int32_t     w_tiles_per_wave;
     int32_t     w_warm_tiles;
     int32_t     w_edge_tpw;     // tiles per wave for edge runs
-    int64_t     w_fast_g0, w_fast_g1;   // streaming sub-blocks [g0, g1): tiles [g tpw, (g+1) tpw)
+    // streaming runs: run w (0 <= w < w_n_stream) covers tiles [w_run_start(w), w_run_start(w + 1)) of
+    // [w_edge_ta, w_edge_tb): w_run_q tiles each, one more for the first w_run_r runs
+    int64_t     w_n_stream, w_run_q, w_run_r;
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
@@ -110,6 +126,11 @@ struct FrontArgs {
     void       *out;
 };
 
+IQGPU_HD inline int64_t w_run_start(const FrontArgs &a, int64_t w)
+{
+    return a.w_edge_ta + w * a.w_run_q + (w < a.w_run_r ? w : a.w_run_r);
+}
+
 size_t front_lds_bytes(const FrontArgs &a);
 hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
 // leading stages of a multi-stage decimation as a wave-autonomous kernel (cascade_wave.hip)
@@ -122,17 +143,13 @@ int cascade_waves(const FrontArgs &a);    // needs casc_wave_lds
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);
 int front_s1_waves(const FrontArgs &a);   // needs S, formats, gain, iq / dc / nco switches
-// fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set)
-void plan_front_s1(FrontArgs &a, int tiles_per_wave, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile);
+// fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
+// wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles
+void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile);
 
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
 // ---------------------------------------------------------------------------------------------
-#if defined(__HIPCC__)
-#define IQGPU_HD __host__ __device__
-#else
-#define IQGPU_HD
-#endif
 // Where the front kernel's independent pieces start in the call's new samples.  Segment s covers
 // [start(s), start(s+1)); start(0) = 0; starts clamp to [0, frames_in].
 struct DcGeom {
@@ -142,8 +159,9 @@ struct DcGeom {
     // mode 0: start(s) = seg_first + (s - 1) seg_len for s >= 1
     int64_t seg_first, seg_len;
     // mode 1: runs in stream order -- n_edge1 edge runs of edge_tpw tiles from tile 0, n_stream streaming runs
-    // of tpw tiles from tile g0 * tpw, then edge runs from tile tb; a run starts warm tiles early
-    int64_t n_edge1, n_stream, edge_tpw, tpw, g0, tb;
+    // from tile ta (run_q tiles each, one more for the first run_r), then edge runs from tile tb; a run
+    // starts warm tiles early
+    int64_t n_edge1, n_stream, edge_tpw, run_q, run_r, ta, tb;
     int32_t warm, rem0, tile;   // tile: input frames per tile of the wave kernel (512, or 256 without a half-band)
 };
 IQGPU_HD inline int64_t dc_seg_start(const DcGeom &g, int s)
@@ -155,7 +173,7 @@ IQGPU_HD inline int64_t dc_seg_start(const DcGeom &g, int s)
     } else {
         int64_t t0;
         if (s < g.n_edge1) t0 = (int64_t)s * g.edge_tpw;
-        else if (s < g.n_edge1 + g.n_stream) t0 = (g.g0 + (s - g.n_edge1)) * g.tpw;
+        else if (s < g.n_edge1 + g.n_stream) { const int64_t w = s - g.n_edge1; t0 = g.ta + w * g.run_q + (w < g.run_r ? w : g.run_r); }
         else t0 = g.tb + (s - g.n_edge1 - g.n_stream) * g.edge_tpw;
         v = (t0 - g.warm) * g.tile - g.rem0;
     }

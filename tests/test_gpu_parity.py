@@ -878,3 +878,99 @@ def test_block_samples_does_not_change_results(gpu, name, kw):
                 assert np.abs(got.astype(np.int64) - base.astype(np.int64)).max() <= 1
         else:
             assert np.array_equal(got, base), (name, bs)
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: pipelined host entry point (iqgpu_chain_submit / _collect), iq factors changed mid-stream,
+# the one-round run plan of the wave-autonomous kernels
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batch", [16384, 262144, 100003])
+def test_submit_collect_equals_process(gpu, oracle, batch):
+    raw = synth.raw_stream(1 << 21, 2.4e6, 1, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+    want = gpu.Chain(**kw).process(raw)
+    got = gpu.Chain(**kw).process_pipelined(raw, batch)
+    assert np.array_equal(got, want)                       # split invariance through the new calls: bit-identical
+    ref = run_oracle(oracle, raw, **kw)
+    int_close(got, ref)
+
+
+def test_submit_collect_with_dc_agc_filter_chain(gpu, oracle):
+    # stateful operators everywhere: dc blocker, FFT-kind filter (block-quantised counts), AGC per 16384-frame chunk
+    raw = synth.raw_stream(1 << 20, 10e6, 3, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
+              filters=(("passband", 158.5e3, 113e3),), filter_taps=257, agc=True)
+    want = gpu.Chain(**kw).process(raw)
+    got = gpu.Chain(**kw).process_pipelined(raw, 4 * 16384)      # whole reader chunks per batch keep the AGC partition
+    ref = gpu.Chain(**kw)
+    parts = [ref.process(raw.view(np.uint8)[i * 4 * 65536:(i + 1) * 4 * 65536]) for i in range((raw.nbytes + 4 * 65536 - 1) // (4 * 65536))]
+    assert np.array_equal(got, np.concatenate(parts))
+    assert got.size <= want.size + 2 and got.size > 0
+
+
+def test_submit_rules_tickets_and_mixing_with_process(gpu):
+    import ctypes as C
+    from iq_tool_amd.chain import PinnedBuffer
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+    raw = synth.raw_stream(1 << 19, 2.4e6, 5, "cs16").view(np.uint8)
+    want = gpu.Chain(**kw).process(raw)
+    ch = gpu.Chain(**kw)
+    depth = ch._lib.iqgpu_chain_pipeline_depth()
+    n = 1 << 16
+    ins = [PinnedBuffer(n * 4) for _ in range(depth + 1)]
+    outs = [PinnedBuffer(ch.max_out_frames(n) * 4) for _ in range(depth + 1)]
+    tickets, counts = [], []
+    for i in range(depth):
+        ins[i].array[:] = raw[i * n * 4:(i + 1) * n * 4]
+        got, t = ch.submit(ins[i].ptr, n, outs[i].ptr, outs[i].nbytes)
+        tickets.append(t); counts.append(got)
+    assert tickets == list(range(1, depth + 1))
+    with pytest.raises(gpu.IqgpuError):                      # every slot busy
+        ch.submit(ins[depth].ptr, n, outs[depth].ptr, outs[depth].nbytes)
+    with pytest.raises(gpu.IqgpuError):                      # unknown ticket
+        ch.collect(depth + 5)
+    pieces = []
+    for i, t in enumerate(tickets):
+        ch.collect(t)
+        ch.collect(t)                                        # collecting twice is harmless
+        pieces.append(outs[i].array[:counts[i] * 4].copy())
+    # a synchronous call continues the same stream behind the batches
+    rest = ch.process(raw[depth * n * 4:])
+    got = np.concatenate(pieces + [rest.view(np.uint8)]).view(np.int16)
+    assert np.array_equal(got, want)
+    # capacity error leaves the stream where it was
+    ch2 = gpu.Chain(**kw)
+    with pytest.raises(gpu.IqgpuError):
+        ch2.submit(ins[0].ptr, n, outs[0].ptr, 16)
+    assert np.array_equal(ch2.process(raw), want)
+
+
+def test_iq_factors_changed_between_calls(gpu, oracle):
+    # what the optimiser thread does (src/iq_correct.c:141-152 reads the factors once per chunk)
+    raw = synth.raw_stream(1 << 18, 2.4e6, 9, "cs16")
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=-50e3,
+              iq_correct=True, iq_mag=0.0, iq_phase=0.0)
+    g, o = gpu.Chain(**kw), oracle.Chain(**kw)
+    rb = raw.view(np.uint8)
+    steps = [(0.0, 0.0), (0.01, -0.005), (0.0101, -0.0049), (-0.02, 0.03)]
+    n = rb.size // len(steps) // 4 * 4
+    for i, (mag, ph) in enumerate(steps):
+        g.set_iq_factors(mag, ph); o.set_iq_factors(mag, ph)
+        a = g.process(rb[i * n:(i + 1) * n]); b = o.process(rb[i * n:(i + 1) * n])
+        assert a.shape == b.shape
+        assert np.abs(cf(a) - cf(b)).max() <= TOL, (i, mag, ph)
+
+
+@pytest.mark.parametrize("frames", [(1 << 22) + 12345, 1 << 24, (1 << 18) + 7, 5000, 513])
+def test_one_round_run_plan_any_call_size(gpu, oracle, monkeypatch, frames):
+    # the wave-autonomous kernels deal uneven contiguous runs to the wave slots of one round of workgroups:
+    # any call size must give the bytes of the workgroup-tiled generic kernel
+    raw = synth.raw_stream(frames, 2.4e6, 11, "cs16")
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+    fast = gpu.Chain(**kw).process(raw)
+    monkeypatch.setenv("IQGPU_FORCE_GENERIC", "1")
+    slow = gpu.Chain(**kw).process(raw)
+    assert fast.size == slow.size
+    int_close(fast, slow, 0.99)
+    if frames <= (1 << 22) + 12345:
+        int_close(fast, run_oracle(oracle, raw, **kw))

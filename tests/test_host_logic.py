@@ -4,6 +4,7 @@ errors carry the reference's codes, the product never touches oracle/, the hand-
 its static check, and the N > 1 shard/timing logic of bench.py works over gloo (world_size 2).
 No compute entry point is called here (there is no GPU)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -231,3 +232,44 @@ def test_sharding_and_max_reduce_over_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok" in o for o in outs)
+
+
+def _run_bench_stub(extra_env, argv):
+    env = dict(os.environ, IQGPU_BENCH_STUB="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        if k not in extra_env:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout                    # rank 0 prints ONE line, nothing else reaches stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (gloo barrier + MAX), and the one
+    line says n_gpus 2; the step is a stub here (no GPU in this container), the launcher is the real one."""
+    d = _run_bench_stub({}, ["--gpus", "2", "--steps", "4", "--warmup", "1", "--log2-frames", "12"])
+    assert d["n_gpus"] == 2 and d["steps"] == 4
+    # the slow rank (rank 1 sleeps twice as long) sets the time: MAX over ranks
+    assert d["ms_per_step"] >= 3.9
+    d1 = _run_bench_stub({}, ["--gpus", "1", "--steps", "2", "--log2-frames", "12"])
+    assert d1["n_gpus"] == 1
+
+
+def test_bench_under_a_launcher_reads_ranks_from_the_environment():
+    """the driver's form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
+    env = dict(os.environ, IQGPU_BENCH_STUB="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--log2-frames", "12"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # a mismatch between the launcher's world size and --gpus is an error, not a silent 1-GPU run
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert q.returncode != 0 and "WORLD_SIZE" in q.stderr

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-2 GPU session 2: full GPU suite on the one-round run plan + submit/collect, bench, in-kernel clock
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/s2
+mkdir -p "$OUT"
+cd "$REPO"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+IQGPU_LIB=$REPO/iq_tool_amd/lib/libiqgpu_clock.so python3 tools/clock.py > "$OUT/clock.txt" 2>&1
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --config 3 > "$OUT/bench3.json" 2>> "$OUT/bench.err"
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --config 4 > "$OUT/bench4.json" 2>> "$OUT/bench.err"
+timeout 1500 python3 -m pytest tests -x -q -m gpu > "$OUT/pytest.log" 2>&1
+tail -5 "$OUT/pytest.log"
+cat "$OUT/bench.json" "$OUT/clock.txt"
