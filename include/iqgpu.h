@@ -192,6 +192,69 @@ size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames_in);
 /* exact number of frames the NEXT call with frames_in frames will produce */
 size_t iqgpu_chain_next_out_frames(const iqgpu_chain *c, size_t frames_in);
 
+/* ---- I/Q imbalance optimiser (host CPU, like the reference's): produces the factors iq_correct_apply consumes ----
+ * iq_correct_init / iq_correct_run_optimization / helpers (src/iq_correct.c:85-139, 154-219, 315-393), the
+ * optimiser thread's body (src/utility_threads.c:35-47) and the 1024-sample hand-off (src/pipeline.c:468-476).
+ * A 1024-point Hamming-windowed spectrum of a pre-processed block, the squared dB asymmetry of its two halves over
+ * the inner 90 % of the bins as utility, 25 random +-1e-4 steps per run, 5 % smoothing, at most one run per 500 ms
+ * and only on blocks whose peak-to-average power is >= 20 dB. */
+typedef struct iqgpu_iq_optimizer iqgpu_iq_optimizer;
+typedef float (*iqgpu_rand_dir_fn)(void *user);   /* > 0: +1, else -1  (stands in for _get_random_direction, iq_correct.c:391) */
+typedef struct {
+    uint64_t calls, runs, skipped_interval, skipped_power, accepted;   /* accepted: candidates that raised the metric */
+    float    initial_metric, final_metric;                            /* of the last run */
+    float    average_power_db, power_range_db;                        /* of the last power estimate (iq_correct.c:362-389) */
+} iqgpu_iq_optimizer_stats;
+int   iqgpu_iq_optimizer_create(iqgpu_iq_optimizer **out);            /* factors (0, 0); srand(time) like iq_correct_init */
+void  iqgpu_iq_optimizer_destroy(iqgpu_iq_optimizer *o);
+/* direction source: by default libc rand() > RAND_MAX / 2 as in the reference (irreproducible by design);
+ * seed() switches to a private minstd generator, set_rng() to the caller's function */
+int   iqgpu_iq_optimizer_seed(iqgpu_iq_optimizer *o, uint32_t seed);
+int   iqgpu_iq_optimizer_set_rng(iqgpu_iq_optimizer *o, iqgpu_rand_dir_fn fn, void *user);
+int   iqgpu_iq_optimizer_set_factors(iqgpu_iq_optimizer *o, float mag, float phase);
+int   iqgpu_iq_optimizer_get_factors(iqgpu_iq_optimizer *o, float *mag, float *phase);
+int   iqgpu_iq_optimizer_get_stats(iqgpu_iq_optimizer *o, iqgpu_iq_optimizer_stats *st);
+/* _calculate_imbalance_metric (iq_correct.c:339-360) of one 1024-sample cf32 block for candidate factors */
+float iqgpu_iq_optimizer_metric(iqgpu_iq_optimizer *o, const float *block_re_im_1024, float mag, float phase);
+/* iq_correct_run_optimization on one 1024-sample cf32 block; now_sec < 0 reads CLOCK_MONOTONIC as the reference
+ * does, otherwise the caller's clock (e.g. stream time) gates the 500 ms interval.  *updated = 1 if factors changed. */
+int   iqgpu_iq_optimizer_run(iqgpu_iq_optimizer *o, const float *block_re_im_1024, double now_sec, int *updated);
+int   iqgpu_iq_optimizer_touch(iqgpu_iq_optimizer *o, double now_sec); /* restart the interval (iq_correct.c:294-297) */
+/* The block the reference hands over: the first 1024 samples of a chunk AFTER unpack / dc block / iq correct / pre NCO
+ * (src/pipeline.c:468-476).  With the probe enabled every process call of >= 1024 frames leaves that block of its
+ * first chunk in a pinned host buffer; read() waits for it.  *valid = 0 until one exists. */
+int   iqgpu_chain_enable_iq_probe(iqgpu_chain *c, int enable);
+int   iqgpu_chain_read_iq_probe(iqgpu_chain *c, float *block_re_im_1024, int *valid);
+/* the optimiser thread's loop body: read the probe, run, publish with iqgpu_chain_set_iq_factors */
+int   iqgpu_iq_optimizer_service(iqgpu_iq_optimizer *o, iqgpu_chain *c, double now_sec, int *updated);
+
+/* ---- WAV capture metadata -> frequency shift (host only): the step in front of the path for real captures ----
+ * SdrMetadata and its parsers (src/input_wav.c:54-100, 146-438), the shift rule of wav_initialize (592-629). */
+enum { IQGPU_SDR_UNKNOWN = 0, IQGPU_SDR_CONSOLE = 1, IQGPU_SDR_SHARP = 2, IQGPU_SDR_UNO = 3, IQGPU_SDR_CONNECT = 4 };
+typedef struct {
+    int     source_software;                    /* IQGPU_SDR_*                                                  */
+    char    software_name[64], software_version[64], radio_model[128];
+    int     software_name_present, software_version_present, radio_model_present;
+    double  center_freq_hz;  int center_freq_hz_present;
+    int64_t timestamp_unix;  int timestamp_unix_present;
+    char    timestamp_str[64]; int timestamp_str_present;
+    int     sdr_info_present;                   /* any metadata source produced something                      */
+    /* what sf_open reports (SF_INFO) and the path needs */
+    int32_t sample_rate, channels, bits_per_sample, format_tag;
+    int     in_format;                          /* IQGPU_FMT_CS16 or IQGPU_FMT_CU8 (the two subtypes the reference accepts) */
+    uint64_t data_offset, data_bytes, frames;
+} iqgpu_wav_info;
+void iqgpu_wav_info_init(iqgpu_wav_info *md);
+/* one `auxi` chunk: SDR Console XML first, SDRuno / SDRconnect binary otherwise; 1 if anything was parsed */
+int  iqgpu_wav_parse_auxi(const void *chunk, size_t size, iqgpu_wav_info *md);
+/* SDR#-style base name: ..._<freq>Hz... and _YYYYMMDD_HHMMSSZ; fills only what the chunk left unset */
+int  iqgpu_wav_parse_filename(const char *base_filename, iqgpu_wav_info *md);
+/* header walk (RIFF / RF64: fmt, auxi, data) + both parsers; IQGPU_EFORMAT for != 2 channels or an unsupported subtype */
+int  iqgpu_wav_probe(const char *path, iqgpu_wav_info *md);
+/* resources->nco_shift_hz = center_freq_hz - (double)center_target (float option); IQGPU_ESHIFT when --freq-shift is also
+ * given or the file has no centre frequency; 0 shift when the option is not used */
+int  iqgpu_wav_shift_hz(const iqgpu_wav_info *md, float center_target_hz, float freq_shift_hz_arg, double *nco_shift_hz);
+
 /* ---- stream / profiling plumbing ---- */
 int    iqgpu_chain_set_stream(iqgpu_chain *c, void *hip_stream);   /* hipStream_t; NULL = chain's own stream */
 void  *iqgpu_chain_get_stream(const iqgpu_chain *c);

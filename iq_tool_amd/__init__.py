@@ -3,5 +3,6 @@ post_processor sample path.  The compute lives in lib/libiqgpu.s
 importing the package never falls back to a CPU implementation."""
 from ._lib import FMT, IqgpuError, LIB_PATH, load          # noqa: F401
 from .chain import Chain, DeviceBuffer, PinnedBuffer, make_desc   # noqa: F401
+from .iq_optimizer import IqOptimizer                            # noqa: F401
 
-__all__ = ["Chain", "DeviceBuffer", "PinnedBuffer", "make_desc", "FMT", "IqgpuError", "load", "LIB_PATH"]
+__all__ = ["Chain", "DeviceBuffer", "PinnedBuffer", "IqOptimizer", "make_desc", "FMT", "IqgpuError", "load", "LIB_PATH"]

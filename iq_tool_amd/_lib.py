@@ -55,6 +55,29 @@ class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64 * 8), ("ms", C.c_double * 8)]
 
 
+class IqOptimizerStats(C.Structure):
+    _fields_ = [("calls", C.c_uint64), ("runs", C.c_uint64), ("skipped_interval", C.c_uint64),
+                ("skipped_power", C.c_uint64), ("accepted", C.c_uint64),
+                ("initial_metric", C.c_float), ("final_metric", C.c_float),
+                ("average_power_db", C.c_float), ("power_range_db", C.c_float)]
+
+
+RAND_DIR_FN = C.CFUNCTYPE(C.c_float, C.c_void_p)
+
+
+class WavInfo(C.Structure):
+    _fields_ = [("source_software", C.c_int),
+                ("software_name", C.c_char * 64), ("software_version", C.c_char * 64), ("radio_model", C.c_char * 128),
+                ("software_name_present", C.c_int), ("software_version_present", C.c_int), ("radio_model_present", C.c_int),
+                ("center_freq_hz", C.c_double), ("center_freq_hz_present", C.c_int),
+                ("timestamp_unix", C.c_int64), ("timestamp_unix_present", C.c_int),
+                ("timestamp_str", C.c_char * 64), ("timestamp_str_present", C.c_int),
+                ("sdr_info_present", C.c_int),
+                ("sample_rate", C.c_int32), ("channels", C.c_int32), ("bits_per_sample", C.c_int32), ("format_tag", C.c_int32),
+                ("in_format", C.c_int),
+                ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64), ("frames", C.c_uint64)]
+
+
 class IqgpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libiqgpu %s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
@@ -83,6 +106,24 @@ SYMBOLS = [
     ("iqgpu_chain_set_iq_factors", C.c_int, [_vp, C.c_float, C.c_float]),
     ("iqgpu_chain_max_out_frames", _sz, [_vp, _sz]),
     ("iqgpu_chain_next_out_frames", _sz, [_vp, _sz]),
+    ("iqgpu_iq_optimizer_create", C.c_int, [C.POINTER(_vp)]),
+    ("iqgpu_iq_optimizer_destroy", None, [_vp]),
+    ("iqgpu_iq_optimizer_seed", C.c_int, [_vp, C.c_uint32]),
+    ("iqgpu_iq_optimizer_set_rng", C.c_int, [_vp, RAND_DIR_FN, _vp]),
+    ("iqgpu_iq_optimizer_set_factors", C.c_int, [_vp, C.c_float, C.c_float]),
+    ("iqgpu_iq_optimizer_get_factors", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("iqgpu_iq_optimizer_get_stats", C.c_int, [_vp, C.POINTER(IqOptimizerStats)]),
+    ("iqgpu_iq_optimizer_metric", C.c_float, [_vp, _vp, C.c_float, C.c_float]),
+    ("iqgpu_iq_optimizer_run", C.c_int, [_vp, _vp, C.c_double, C.POINTER(C.c_int)]),
+    ("iqgpu_iq_optimizer_touch", C.c_int, [_vp, C.c_double]),
+    ("iqgpu_chain_enable_iq_probe", C.c_int, [_vp, C.c_int]),
+    ("iqgpu_chain_read_iq_probe", C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
+    ("iqgpu_iq_optimizer_service", C.c_int, [_vp, _vp, C.c_double, C.POINTER(C.c_int)]),
+    ("iqgpu_wav_info_init", None, [C.POINTER(WavInfo)]),
+    ("iqgpu_wav_parse_auxi", C.c_int, [_vp, _sz, C.POINTER(WavInfo)]),
+    ("iqgpu_wav_parse_filename", C.c_int, [C.c_char_p, C.POINTER(WavInfo)]),
+    ("iqgpu_wav_probe", C.c_int, [C.c_char_p, C.POINTER(WavInfo)]),
+    ("iqgpu_wav_shift_hz", C.c_int, [C.POINTER(WavInfo), C.c_float, C.c_float, C.POINTER(C.c_double)]),
     ("iqgpu_chain_set_stream", C.c_int, [_vp, _vp]),
     ("iqgpu_chain_get_stream", _vp, [_vp]),
     ("iqgpu_chain_synchronize", C.c_int, [_vp]),

@@ -177,6 +177,17 @@ class Chain:
     def set_iq_factors(self, mag, phase):
         check(self._lib.iqgpu_chain_set_iq_factors(self._h, mag, phase))
 
+    def enable_iq_probe(self, on=True):
+        check(self._lib.iqgpu_chain_enable_iq_probe(self._h, int(on)))
+
+    def read_iq_probe(self):
+        """the block the reference hands its optimiser (src/pipeline.c:468-476): first 1024 pre-processed
+        samples of the most recent call of >= 1024 frames, or None"""
+        blk = np.empty(1024, np.complex64)
+        valid = C.c_int(0)
+        check(self._lib.iqgpu_chain_read_iq_probe(self._h, blk.ctypes.data_as(C.c_void_p), C.byref(valid)))
+        return blk if valid.value else None
+
     # ---- plumbing ----
     def set_stream(self, hip_stream):
         check(self._lib.iqgpu_chain_set_stream(self._h, C.c_void_p(hip_stream)))

@@ -150,6 +150,9 @@ struct iqgpu_chain {
     };
     PipeSlot pipe[kPipeSlots];
     bool pipe_ready = false; uint64_t pipe_seq = 0; hipEvent_t pipe_prev_kernels = nullptr;
+    // I/Q optimiser probe: first 1024 pre-processed samples of a call (device -> pinned host), src/pipeline.c:468-476
+    bool probe_on = false, probe_pending = false, probe_valid = false;
+    cf2 *d_probe = nullptr; cf2 *h_probe = nullptr; hipEvent_t probe_done = nullptr;
     bool direct_dirty = false;    // process_device ran on the chain's own stream since the last synchronisation
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
@@ -218,6 +221,9 @@ static void free_device_state(iqgpu_chain *c)
     c->fbuf[0].release(); c->fbuf[1].release();
     c->ibuf[0].release(); c->ibuf[1].release();
     c->stage_in.release(); c->stage_out.release();
+    if (c->d_probe) (void)hipFree(c->d_probe);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
+    if (c->probe_done) (void)hipEventDestroy(c->probe_done);
     for (auto &ps : c->pipe) {
         ps.d_in.release(); ps.d_out.release();
         if (ps.kernels_done) (void)hipEventDestroy(ps.kernels_done);
@@ -764,7 +770,7 @@ void Call::plan_geometry()
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : front_s1_waves(cplan)), fixed_tpw(), warm, 4, wtile);
+        plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : front_s1_waves(cplan)), fixed_tpw(), warm, 1, wtile);
     }
 }
 
@@ -911,7 +917,7 @@ int Call::stage_front()
             a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
             a2.out_fmt = a.out_fmt; a2.out = a.out;
             a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-            plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 4);
+            plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 1);
             for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
             a2.sink = c->d_sink;
             { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
@@ -1061,6 +1067,20 @@ static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t fram
     // the handle is poisoned and every later call fails until iqgpu_chain_reset()
     int rc;
     if ((rc = k.prepare_buffers()) != IQGPU_OK) return rc;
+    if (c->probe_on && frames_in >= 1024) {
+        // before k_dc_scan moves the dc state to the end of this call
+        IqProbeArgs pa{};
+        pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
+        pa.dc_enable = c->dc ? 1 : 0; pa.dc_c = c->dc_c; pa.dc_state = c->d_dc_state;
+        pa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; pa.iq_magp1 = 1.0f + c->iq_mag; pa.iq_phase = c->iq_phase;
+        pa.nco_mode = c->nco_mode; pa.nco_theta0 = c->nco_theta; pa.nco_dtheta = c->nco_dtheta; pa.nco_tab = c->d_nco_tab;
+        pa.out = c->d_probe;
+        if (c->probe_pending) HIP_TRY(hipEventSynchronize(c->probe_done));      // the previous block has left the device buffer
+        HIP_TRY(launch_iq_probe(pa, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_probe, c->d_probe, 1024 * sizeof(cf2), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->probe_done, c->stream));
+        c->probe_pending = true;
+    }
     if (c->dc && (rc = k.stage_dc_carries()) != IQGPU_OK) { c->poisoned = true; return rc; }
     if ((rc = k.stage_front()) != IQGPU_OK) { c->poisoned = true; return rc; }
     if (k.filt && (rc = k.stage_filter()) != IQGPU_OK) { c->poisoned = true; return rc; }
@@ -1169,6 +1189,56 @@ extern "C" int iqgpu_chain_collect(iqgpu_chain *c, uint64_t ticket)
 }
 
 extern "C" int iqgpu_chain_pipeline_depth(void) { return iqgpu_chain::kPipeSlots; }
+
+// ---- I/Q optimiser hand-off (src/pipeline.c:468-476, src/utility_threads.c:35-47) -------------------------
+extern "C" int iqgpu_chain_enable_iq_probe(iqgpu_chain *c, int enable)
+{
+    if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->d_probe) {
+        if (hipMalloc((void **)&c->d_probe, 1024 * sizeof(cf2)) != hipSuccess) return fail(IQGPU_ENOMEM, "hipMalloc failed");
+        if (hipHostMalloc((void **)&c->h_probe, 1024 * sizeof(cf2), hipHostMallocDefault) != hipSuccess) return fail(IQGPU_ENOMEM, "hipHostMalloc failed");
+        HIP_TRY(hipEventCreateWithFlags(&c->probe_done, hipEventDisableTiming));
+    }
+    c->probe_on = enable != 0;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_chain_read_iq_probe(iqgpu_chain *c, float *block_re_im_1024, int *valid)
+{
+    if (!c || !block_re_im_1024 || !valid) return fail(IQGPU_EINVAL, "iqgpu_chain_read_iq_probe: NULL argument");
+    *valid = 0;
+    if (!c->h_probe) return fail(IQGPU_EINVAL, "the probe is not enabled (iqgpu_chain_enable_iq_probe)");
+    if (c->probe_pending) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipEventSynchronize(c->probe_done));
+        c->probe_pending = false; c->probe_valid = true;
+    }
+    if (!c->probe_valid) return IQGPU_OK;
+    memcpy(block_re_im_1024, c->h_probe, 1024 * sizeof(cf2));
+    *valid = 1;
+    return IQGPU_OK;
+}
+
+extern "C" int iqgpu_iq_optimizer_service(iqgpu_iq_optimizer *o, iqgpu_chain *c, double now_sec, int *updated)
+{
+    if (!o || !c) return fail(IQGPU_EINVAL, "iqgpu_iq_optimizer_service: NULL argument");
+    if (updated) *updated = 0;
+    static_assert(sizeof(cf2) == 2 * sizeof(float), "cf32 layout");
+    float block[2048];
+    int valid = 0, upd = 0;
+    int rc = iqgpu_chain_read_iq_probe(c, block, &valid);
+    if (rc != IQGPU_OK || !valid) return rc;
+    rc = iqgpu_iq_optimizer_run(o, block, now_sec, &upd);
+    if (rc != IQGPU_OK) return fail(rc, "iqgpu_iq_optimizer_run failed");
+    if (upd) {
+        float mag = 0.0f, phase = 0.0f;
+        (void)iqgpu_iq_optimizer_get_factors(o, &mag, &phase);
+        rc = iqgpu_chain_set_iq_factors(c, mag, phase);
+    }
+    if (updated) *updated = upd;
+    return rc;
+}
 
 extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
 {

@@ -534,4 +534,40 @@ hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_iq_probe: the block the reference hands to its I/Q optimiser -- the first 1024 samples of a chunk after
+// unpack -> [dc block] -> [iq correct] -> [pre NCO]  (src/pipeline.c:468-476 copies them out of buffer A right
+// behind pre_processor_apply_chain).  One wavefront; the dc recurrence (1024 steps) runs on one lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_iq_probe(const IqProbeArgs a)
+{
+    __shared__ cf2 x[1024];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 1024; i += 64) x[i] = unpack_one(a.raw, i, a.in_fmt, a.gain);
+    __syncthreads();
+    if (a.dc_enable && lane == 0) {
+        const cd2 st = *a.dc_state;                // v[n-1] in front of this call's first sample
+        float vr = (float)st.x, vi = (float)st.y;
+        const float aa = 1.0f - a.dc_c;
+        for (int i = 0; i < 1024; ++i) {
+            const cf2 v = x[i];
+            x[i] = cf2{fmaf(-aa, vr, v.x), fmaf(-aa, vi, v.y)};
+            vr = fmaf(a.dc_c, vr, v.x); vi = fmaf(a.dc_c, vi, v.y);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < 1024; i += 64) {
+        cf2 v = x[i];
+        if (a.iq_enable) { const float re = v.x; v.x = re * a.iq_magp1; v.y = fmaf(a.iq_phase, re, v.y); }
+        if (a.nco_mode != 0) v = nco_mix(v, nco_phasor(a.nco_tab, a.nco_theta0 + (uint32_t)i * a.nco_dtheta), a.nco_mode);
+        a.out[i] = v;
+    }
+}
+
+hipError_t launch_iq_probe(const IqProbeArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_iq_probe, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 } // namespace iqgpu

@@ -340,4 +340,14 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s);   // peak, scan, apply
 // dst[i] = src[i], i < n (cf32)
 hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);
 
+// k_iq_probe: first 1024 pre-processed samples of a call for the I/Q optimiser (src/pipeline.c:468-476)
+struct IqProbeArgs {
+    const void *raw; int32_t in_fmt; float gain;
+    int32_t dc_enable; float dc_c; const cd2 *dc_state;
+    int32_t iq_enable; float iq_magp1, iq_phase;
+    int32_t nco_mode; uint32_t nco_theta0, nco_dtheta; const cf2 *nco_tab;
+    cf2 *out;                 // [1024]
+};
+hipError_t launch_iq_probe(const IqProbeArgs &a, hipStream_t s);
+
 } // namespace iqgpu

@@ -1185,3 +1185,122 @@ size_t orc_chain_process_pipelined(orc_chain *c, const void *raw_in, size_t fram
     for (i = 0; i < ORC_TRAYS; i++) { free(trays[i].A); free(trays[i].B); }
     return p.total_out;
 }
+
+
+/* ================================================================================================
+ * I/Q imbalance optimiser -- restates iq_correct_run_optimization and its helpers
+ * (src/iq_correct.c:154-219, 307-393; constants include/constants.h:157-162).  The spectrum is an exact DFT
+ * in double (the reference uses liquid's FFT plan, src/iq_correct.c:116, 326: any exact transform to float
+ * rounding), everything the reference computes in float is float here.  The random direction source is the
+ * minstd generator the product uses when seeded (the reference's rand() seeded by time() is irreproducible).
+ * ================================================================================================ */
+#define ORC_IQ_N 1024
+struct orc_iqopt {
+    float window[ORC_IQ_N];
+    double ct[ORC_IQ_N], st[ORC_IQ_N];
+    float spectrum[ORC_IQ_N];
+    float mag, phase, average_power, power_range;
+    double last_time;
+    uint32_t lcg;
+};
+
+orc_iqopt *orc_iqopt_create(void)
+{
+    orc_iqopt *q = (orc_iqopt *)calloc(1, sizeof(*q));
+    int i;
+    if (!q) return NULL;
+    for (i = 0; i < ORC_IQ_N; i++) {   /* src/iq_correct.c:122-124 */
+        q->window[i] = 0.54f - 0.46f * cosf(2.0f * (float)M_PI * (float)i / (float)(ORC_IQ_N - 1));
+        q->ct[i] = cos(2.0 * M_PI * (double)i / ORC_IQ_N);
+        q->st[i] = sin(2.0 * M_PI * (double)i / ORC_IQ_N);
+    }
+    q->lcg = 1;
+    return q;
+}
+void orc_iqopt_destroy(orc_iqopt *q) { free(q); }
+void orc_iqopt_seed(orc_iqopt *q, uint32_t seed) { q->lcg = seed % 2147483647u; if (!q->lcg) q->lcg = 1; }
+void orc_iqopt_set_factors(orc_iqopt *q, float mag, float phase) { q->mag = mag; q->phase = phase; }
+void orc_iqopt_get_factors(const orc_iqopt *q, float *mag, float *phase) { *mag = q->mag; *phase = q->phase; }
+float orc_iqopt_power_range(const orc_iqopt *q) { return q->power_range; }
+
+static float iqopt_direction(orc_iqopt *q)   /* _get_random_direction, src/iq_correct.c:391-393, on minstd */
+{
+    q->lcg = (uint32_t)(((uint64_t)q->lcg * 48271u) % 2147483647u);
+    return q->lcg > 2147483647u / 2u ? 1.0f : -1.0f;
+}
+
+/* _calculate_power_spectrum, src/iq_correct.c:315-337 */
+static void iqopt_spectrum(orc_iqopt *q, const orc_cf32 *block, float gain_adj, float phase_adj)
+{
+    static float wr[ORC_IQ_N], wi[ORC_IQ_N];
+    const float magp1 = 1.0f + gain_adj;
+    int i, k;
+    for (i = 0; i < ORC_IQ_N; i++) {
+        const float re = block[i].re * magp1;                      /* _apply_correction_to_buffer, 307-313 */
+        const float im = block[i].im + phase_adj * block[i].re;
+        wr[i] = re * q->window[i]; wi[i] = im * q->window[i];
+    }
+    for (k = 0; k < ORC_IQ_N; k++) {
+        /* forward transform, bin k; the shifted spectrum puts bin k at (k + N/2) mod N */
+        double sr = 0.0, si = 0.0;
+        unsigned idx = 0;
+        float m;
+        for (i = 0; i < ORC_IQ_N; i++) {
+            const double c = q->ct[idx], s = -q->st[idx];
+            sr += (double)wr[i] * c - (double)wi[i] * s;
+            si += (double)wr[i] * s + (double)wi[i] * c;
+            idx = (idx + (unsigned)k) & (ORC_IQ_N - 1);
+        }
+        m = hypotf((float)sr, (float)si);
+        m /= (float)ORC_IQ_N;
+        q->spectrum[(k + ORC_IQ_N / 2) & (ORC_IQ_N - 1)] = 20.0f * log10f(m + 1e-12f);
+    }
+}
+
+/* _calculate_imbalance_metric, src/iq_correct.c:339-360 */
+float orc_iqopt_metric(orc_iqopt *q, const orc_cf32 *block, float gain_adj, float phase_adj)
+{
+    const int half = ORC_IQ_N / 2;
+    const int lo = (int)(0.05f * half), hi = (int)(0.95f * half);
+    float total = 0.0f;
+    int i;
+    iqopt_spectrum(q, block, gain_adj, phase_adj);
+    for (i = lo; i < hi; i++) {
+        const float p_neg = q->spectrum[i], p_pos = q->spectrum[ORC_IQ_N - 1 - i];
+        if (p_pos > -80.0f || p_neg > -80.0f) { const float d = p_pos - p_neg; total += d * d; }
+    }
+    return total;
+}
+
+/* iq_correct_run_optimization, src/iq_correct.c:154-219; returns 1 when the factors were updated */
+int orc_iqopt_run(orc_iqopt *q, const orc_cf32 *block, double now_sec)
+{
+    const int half = ORC_IQ_N / 2;
+    const int lo = (int)(0.05f * half), hi = (int)(0.95f * half);
+    float max_power = -1000.0f, cur_gain, cur_phase, best;
+    double sum = 0.0;
+    int count = 0, i;
+    if ((now_sec - q->last_time) * 1000.0 < 500.0) return 0;       /* IQ_CORRECTION_INTERVAL_MS */
+    iqopt_spectrum(q, block, 0.0f, 0.0f);                          /* _estimate_power, 362-389 */
+    for (i = lo; i < hi; i++) {
+        const float p_neg = q->spectrum[i], p_pos = q->spectrum[ORC_IQ_N - 1 - i];
+        if (p_pos > max_power) max_power = p_pos;
+        if (p_neg > max_power) max_power = p_neg;
+        sum += p_pos + p_neg; count += 2;
+    }
+    q->average_power = (float)(sum / count);
+    q->power_range = max_power - q->average_power;
+    if (q->power_range < 20.0f) return 0;                          /* IQ_CORRECTION_POWER_THRESHOLD_DB */
+    q->last_time = now_sec;
+    cur_gain = q->mag; cur_phase = q->phase;
+    best = orc_iqopt_metric(q, block, cur_gain, cur_phase);
+    for (i = 0; i < 25; i++) {                                     /* IQ_MAX_PASSES, IQ_BASE_INCREMENT */
+        const float cand_gain = cur_gain + 0.0001f * iqopt_direction(q);
+        const float cand_phase = cur_phase + 0.0001f * iqopt_direction(q);
+        const float m = orc_iqopt_metric(q, block, cand_gain, cand_phase);
+        if (m > best) { best = m; cur_gain = cand_gain; cur_phase = cand_phase; }
+    }
+    q->mag = ((1.0f - 0.05f) * q->mag) + (0.05f * cur_gain);       /* IQ_CORRECTION_SMOOTHING_FACTOR */
+    q->phase = ((1.0f - 0.05f) * q->phase) + (0.05f * cur_phase);
+    return 1;
+}

@@ -172,6 +172,17 @@ size_t orc_chain_process(orc_chain *c, const void *raw_in, size_t frames_in, voi
  * 436-595).  Same results as orc_chain_process; exists for bench.py's cpu_baseline ("cores": 3). */
 size_t orc_chain_process_pipelined(orc_chain *c, const void *raw_in, size_t frames_in, void *out);
 
+/* ---- I/Q imbalance optimiser (src/iq_correct.c:154-219, 307-393); restated from the reference's own source ---- */
+typedef struct orc_iqopt orc_iqopt;
+orc_iqopt *orc_iqopt_create(void);
+void   orc_iqopt_destroy(orc_iqopt *q);
+void   orc_iqopt_seed(orc_iqopt *q, uint32_t seed);
+void   orc_iqopt_set_factors(orc_iqopt *q, float mag, float phase);
+void   orc_iqopt_get_factors(const orc_iqopt *q, float *mag, float *phase);
+float  orc_iqopt_power_range(const orc_iqopt *q);
+float  orc_iqopt_metric(orc_iqopt *q, const orc_cf32 *block_1024, float gain_adj, float phase_adj);
+int    orc_iqopt_run(orc_iqopt *q, const orc_cf32 *block_1024, double now_sec);
+
 #ifdef __cplusplus
 }
 #endif

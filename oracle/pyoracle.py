@@ -121,6 +121,14 @@ def _proto(lib):
     P("orc_chain_max_out_frames", sz, [vp, sz])
     P("orc_chain_process", sz, [vp, vp, sz, vp, vp])
     P("orc_chain_process_pipelined", sz, [vp, vp, sz, vp])
+    P("orc_iqopt_create", vp, [])
+    P("orc_iqopt_destroy", None, [vp])
+    P("orc_iqopt_seed", None, [vp, C.c_uint32])
+    P("orc_iqopt_set_factors", None, [vp, C.c_float, C.c_float])
+    P("orc_iqopt_get_factors", None, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)])
+    P("orc_iqopt_power_range", C.c_float, [vp])
+    P("orc_iqopt_metric", C.c_float, [vp, vp, C.c_float, C.c_float])
+    P("orc_iqopt_run", C.c_int, [vp, vp, C.c_double])
     return lib
 
 
@@ -473,3 +481,36 @@ class Chain:
         if want_cf32:
             return res, tap[:k].copy()
         return res
+
+
+class IqOptimizer:
+    """orc_iqopt_*: iq_correct_run_optimization (src/iq_correct.c:154-219) on 1024-sample cf32 blocks"""
+
+    def __init__(self, seed=1, L=None):
+        self.L = L or lib()
+        self.q = self.L.orc_iqopt_create()
+        self.L.orc_iqopt_seed(self.q, seed)
+
+    def __del__(self):
+        if getattr(self, "q", None):
+            self.L.orc_iqopt_destroy(self.q)
+            self.q = None
+
+    def set_factors(self, mag, phase):
+        self.L.orc_iqopt_set_factors(self.q, mag, phase)
+
+    def factors(self):
+        m, p = C.c_float(0), C.c_float(0)
+        self.L.orc_iqopt_get_factors(self.q, C.byref(m), C.byref(p))
+        return m.value, p.value
+
+    def metric(self, block, mag, phase):
+        b = np.ascontiguousarray(block, np.complex64)
+        return self.L.orc_iqopt_metric(self.q, b.ctypes.data_as(C.c_void_p), mag, phase)
+
+    def run(self, block, now_sec):
+        b = np.ascontiguousarray(block, np.complex64)
+        return bool(self.L.orc_iqopt_run(self.q, b.ctypes.data_as(C.c_void_p), now_sec))
+
+    def power_range(self):
+        return self.L.orc_iqopt_power_range(self.q)
