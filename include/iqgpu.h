@@ -160,6 +160,11 @@ int    iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *info,
                           float *filter_taps_re_im, size_t cap_taps,
                           float *hb_taps, size_t cap_hb, float *arb_proto, size_t cap_arb);
 
+/* frames a FRESH chain of this description emits for a stream of frames_in frames (no device needed): the
+ * closed form of the resampler law and the FFT-block quantisation on whichever side of the resampler the filter
+ * sits.  What a stitching writer uses to place the outputs of independent shards (8 iq_tool runs + cat). */
+int    iqgpu_design_out_frames(const iqgpu_chain_desc *d, size_t frames_in, size_t *frames_out);
+
 /* ---- per-chunk: replaces pre_processor_apply_chain (src/pre_processor.c:10), resampler_execute
  *      (include/resampler.h:48) and post_processor_apply_chain (src/post_processor.c:9) in one call ---- */
 int    iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t frames_in,

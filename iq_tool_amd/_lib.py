@@ -96,6 +96,7 @@ SYMBOLS = [
     ("iqgpu_chain_get_info", C.c_int, [_vp, C.POINTER(ChainInfo)]),
     ("iqgpu_chain_get_filter_taps", C.c_int, [_vp, _vp, _sz]),
     ("iqgpu_design_probe", C.c_int, [C.POINTER(ChainDesc), C.POINTER(ChainInfo), _vp, _sz, _vp, _sz, _vp, _sz]),
+    ("iqgpu_design_out_frames", C.c_int, [C.POINTER(ChainDesc), _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_process", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_process_device", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("iqgpu_chain_submit", C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64)]),

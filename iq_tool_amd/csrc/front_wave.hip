@@ -42,18 +42,7 @@ constexpr int kXRows = 5 + 64;                              // 20 history + 256 
 constexpr int kHRows = 4 + 64;                              // 16 history + 256 half-band outputs, aliased onto
 constexpr int kHBOff = 5;                                   //   XO rows kHBOff .. kHBOff + kHRows - 1
 constexpr int kWaveLds = (kXRows + kHBOff + kHRows) * kRowB; // 6816 B per wave
-constexpr int kCtlLds = 2 * 4 * 16;                         // run-stealing control: {next tile, end of run} per wave
-constexpr int kTabLds = 1024 * 8 + 256 * 14 * 4 + kCtlLds;  // NCO {cos,sin} + polyphase taps [256][14] + control words
-// Run stealing (streaming waves, chains without a dc blocker): the waves of a workgroup do not progress at the
-// same rate (measured in round 2: runs of equal length end between 0.31 and 0.47 ms, and a CU with fewer resident
-// waves hides less latency), so a wave that runs out of tiles takes the second half of the longest remaining run
-// of its workgroup -- one compare-and-swap on the victim's end word in LDS, then a warm-up tile of its own.
-// A tile's output does not depend on which run it is in, so the bytes are those of the static plan.
-#ifndef IQGPU_STEAL
-#define IQGPU_STEAL 1
-#endif
-constexpr unsigned kStealMin = 6;                           // do not split runs shorter than this
-typedef __attribute__((address_space(3))) unsigned lds_u32;   // control words are touched with DS instructions only
+constexpr int kTabLds = 1024 * 8 + 256 * 14 * 4;            // NCO {cos,sin} + polyphase taps [256][14]
 
 size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveLds; }   // the larger of the two shapes
 
@@ -128,38 +117,6 @@ __device__ __forceinline__ int out_bytes(int fmt)
 #define CLOCK_END(sinkbase) do { } while (0)
 #endif
 
-// Wave priority.  IQGPU_PRIO_MODE (experiments, round 2): 0 = phase toggle (LDS-feeding phases 1, FMA runs 0);
-// 1 = rotate by tile and age rank (each of a SIMD's 4 waves is top priority every 4th tile), no phase toggle;
-// 2 = phase toggle in the upper bit, rotation in the lower; 3 = never set; 4 = static, youngest highest
-#ifndef IQGPU_PRIO_MODE
-#define IQGPU_PRIO_MODE 0
-#endif
-__device__ __forceinline__ void set_prio_imm(int p)
-{
-    switch (p & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-#if IQGPU_PRIO_MODE == 0
-#define PRIO_TILE(rank, t) do { } while (0)
-#define PRIO_PHASE(hi, rank, t) __builtin_amdgcn_s_setprio((hi) ? 1 : 0)
-#elif IQGPU_PRIO_MODE == 1
-#define PRIO_TILE(rank, t) set_prio_imm((rank) + (int)(t))
-#define PRIO_PHASE(hi, rank, t) do { } while (0)
-#elif IQGPU_PRIO_MODE == 2
-#define PRIO_TILE(rank, t) do { } while (0)
-#define PRIO_PHASE(hi, rank, t) set_prio_imm(((hi) ? 2 : 0) + ((((rank) >> 1) + (int)(t)) & 1))
-#elif IQGPU_PRIO_MODE == 3
-#define PRIO_TILE(rank, t) do { } while (0)
-#define PRIO_PHASE(hi, rank, t) do { } while (0)
-#else
-#define PRIO_TILE(rank, t) do { if ((t) == t_begin) set_prio_imm(rank); } while (0)
-#define PRIO_PHASE(hi, rank, t) do { } while (0)
-#endif
-
 struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };
 
 // first output at or after the lane's first half-band sample (4*lane), for a tile whose first
@@ -211,8 +168,7 @@ __device__ __forceinline__ void gather_taps2(unsigned row_a, unsigned row_b, v2f
 // EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
 template <int BPS, bool EDGE, bool FAST, bool S0>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
-                                          const int64_t t_begin, const int64_t t_emit0, int64_t t_emit1, const int seg,
-                                          const unsigned ctl_addr = 0)     // LDS byte address of this wave's {next tile, end}, 0 = fixed run
+                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
     // dc blocker (never in the FAST instantiation): wave-uniform state, carries per run as in k_cascade
     float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
@@ -283,28 +239,13 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         }
     };
     float sl_hist = 0.0f;         // one dword per lane (< 48) of the last 4 rows of the polyphase input
-    [[maybe_unused]] const int prio_rank = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) & 3;   // age rank among the 4 waves of its SIMD
     STAMP_DECL
     STAMP_BEGIN;
     CLOCK_BEGIN;
-    for (int64_t t = t_begin; ; ++t) {
-        if (!EDGE && ctl_addr) {
-            // publish the next tile this wave will need and pick up the end of its run (a thief may have lowered it).
-            // One asm block with the LDS address rebuilt from its SGPR: no VGPR stays live across the tile for this.
-            const unsigned nx = (unsigned)(t >= t_emit0 ? t + 1 : t_emit0);
-            unsigned tmp, e;
-            unsigned long long ex;
-            // (the store is issued by ONE lane: 64 lanes storing to one address would serialise in the LDS)
-            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 %2, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\t"
-                         "s_mov_b64 exec, %2\n\tds_read_b32 %1, %0 offset:4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(tmp), "=&v"(e), "=&s"(ex) : "s"(ctl_addr), "s"(nx) : "memory");
-            t_emit1 = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e);
-        }
-        if (t >= t_emit1) break;
+    for (int64_t t = t_begin; t < t_emit1; ++t) {
         const int64_t i0 = t * TILE;
         const int64_t j0 = i0 - a.rem0;
         const bool emit = t >= t_emit0;
-        if (!EDGE) PRIO_TILE(prio_rank, t);
 
         // ------------------------------------------------------------ pointwise -> LDS
         cf2 x[2][4];
@@ -416,7 +357,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         }
         // wave priority: a wave that is about to feed the LDS pipe (the busiest of the three) goes ahead of waves
         // that are in their FMA runs (measured -3 % on the NRSC-5 chain)
-        if (!EDGE) PRIO_PHASE(1, prio_rank, t);
+        if (!EDGE) __builtin_amdgcn_s_setprio(1);
         if (S0) {
             // no half-band stage: the lane's four samples ARE its polyphase-input row
             if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;         // history rows of the polyphase input
@@ -455,7 +396,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             const float4 o0 = ld4(wo + 2 * kRowB + 16), o1 = ld4(wo + 3 * kRowB);
             v2f acc[4] = {v2f{0.5f * o0.x, 0.5f * o0.y}, v2f{0.5f * o0.z, 0.5f * o0.w},
                           v2f{0.5f * o1.x, 0.5f * o1.y}, v2f{0.5f * o1.z, 0.5f * o1.w}};
-            if (!EDGE) PRIO_PHASE(0, prio_rank, t);
+            if (!EDGE) __builtin_amdgcn_s_setprio(0);
             const v2f *hbp = (const v2f *)a.hb0;          // 10 SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
             for (int q2 = 0; q2 < 10; ++q2) {
@@ -469,7 +410,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             // the odd stream for this tile has been issued above, so its data rows are dead.  The 4 history rows of
             // the half-band output (the previous tile's last rows, kept in sl_hist) are put back first: they share
             // XO rows 5 .. 8, which this tile's pointwise phase has just used.
-            if (!EDGE) PRIO_PHASE(1, prio_rank, t);
+            if (!EDGE) __builtin_amdgcn_s_setprio(1);
             if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
@@ -527,7 +468,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 if (EDGE) { const int64_t left = a.n_groups - q_tile0; if (left < 256) q_lim = (uint32_t)left; }
                 char *obase = (char *)a.out + (int64_t)k_tile0 * obps;
                 const uint32_t pth0 = a.pnco_theta0 + (uint32_t)k_tile0 * a.pnco_dtheta;
-                if (!EDGE) PRIO_PHASE(0, prio_rank, t);
+                if (!EDGE) __builtin_amdgcn_s_setprio(0);
                 uint32_t kk = n0;
                 uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -630,17 +571,9 @@ __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
     for (int i = lane; i < kWaveLds / 16; i += 64) ((float4 *)w.XE)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // run-stealing control words of this workgroup: {next tile, end} per wave; an idle or edge wave shows an empty run
-    lds_u32 *ctl_all = (lds_u32 *)(__attribute__((address_space(3))) unsigned char *)smem + (kTabLds - kCtlLds) / 4;
-    const int64_t gw = (int64_t)blockIdx.x * kWv + wave;
-    const bool steal = IQGPU_STEAL && BPS != 0 && !a.dc_enable && a.w_total_tiles < ((int64_t)1 << 31);
-    {
-        const int64_t r0 = gw - a.w_n_edge;
-        unsigned c0 = 0, e0 = 0;
-        if (steal && r0 >= 0 && r0 < a.w_n_stream) { c0 = (unsigned)w_run_start(a, r0); e0 = (unsigned)w_run_start(a, r0 + 1); }
-        if (lane == 0) { ctl_all[2 * wave] = c0; ctl_all[2 * wave + 1] = e0; }
-    }
     __syncthreads();
+
+    const int64_t gw = (int64_t)blockIdx.x * kWv + wave;
 #ifdef IQGPU_STAGGER
     // de-synchronise the waves of the CU: they run the same phases (LDS-heavy, VALU-heavy) and
     // otherwise march through them in lockstep, so that LDS time and VALU time add up
@@ -651,9 +584,6 @@ __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k
         for (int i = lane; i < keep; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
     }
 
-    int64_t rt0 = 0, rt1 = 0;
-    int rseg = 0;
-    bool have = false;
     if (gw < a.w_n_edge) {
         // edge work: tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) in runs of w_edge_tpw
         int64_t t0, t1;
@@ -663,44 +593,10 @@ __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k
         run_tiles<BPS, true, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t r = gw - a.w_n_edge;
-        if (r < a.w_n_stream) { rt0 = w_run_start(a, r); rt1 = w_run_start(a, r + 1); rseg = (int)(a.w_n_edge1 + r); have = true; }
-    }
-    if (BPS == 0) return;
-    // streaming runs: the planned one, then (out of tiles) the second half of the longest remaining run of this
-    // workgroup, until nothing worth splitting is left
-    for (;;) {
-        if (!have) {
-            if (!steal) break;
-            unsigned best_rem = 0, best_c = 0, best_e = 0;
-            int best = -1;
-            for (int v = 0; v < kWv; ++v) {
-                const unsigned c = __hip_atomic_load(ctl_all + 2 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned e = __hip_atomic_load(ctl_all + 2 * v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned rem = e > c ? e - c : 0u;
-                if (rem > best_rem) { best_rem = rem; best_c = c; best_e = e; best = v; }
-            }
-            best = __builtin_amdgcn_readfirstlane(best);
-            best_rem = __builtin_amdgcn_readfirstlane(best_rem);
-            best_c = __builtin_amdgcn_readfirstlane(best_c); best_e = __builtin_amdgcn_readfirstlane(best_e);
-            if (best < 0 || best_rem < kStealMin) break;
-            const unsigned split = best_c + (best_rem + 1) / 2;        // the victim keeps [its next tile, split)
-            unsigned got = 0;
-            if (lane == 0) {
-                unsigned expect = best_e;
-                got = __hip_atomic_compare_exchange_strong(ctl_all + 2 * best + 1, &expect, split, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-            }
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (!got) continue;                                         // another wave was faster: look again
-            if (lane == 0) {
-                __hip_atomic_store(ctl_all + 2 * wave, split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(ctl_all + 2 * wave + 1, best_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            rt0 = (int64_t)split; rt1 = (int64_t)best_e; rseg = 0;
-        }
-        have = false;
-        run_tiles<BPS, false, FAST, S0>(a, w, lane, rt0 - a.w_warm_tiles, rt0, rt1, rseg,
-                                        steal ? (unsigned)(size_t)(ctl_all + 2 * wave) : 0u);
+        if (r >= a.w_n_stream) return;
+        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        const int seg = (int)(a.w_n_edge1 + r);
+        if (BPS != 0) run_tiles<BPS, false, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -757,9 +653,11 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
 
 // Splits the call's tiles into streaming runs (all tiles vector-loadable) and edge runs.  With fixed_tpw == 0
 // the streaming tiles are dealt out as evenly as possible over the wave slots the edge runs leave free, so
-// that the whole call is ONE round of resident workgroups: a grid one workgroup over the CU count runs that
-// workgroup behind the first one to finish and nearly doubles the launch (measured in round 2: wave runs
-// 0.39 ms, launch 0.58 ms with 4 workgroups of edge runs in front of 256 streaming ones).
+// that the whole call is ONE round of resident workgroups (no workgroup waits for a CU to come free).
+// Measured in round 2 (tools/clock.py, per-wave timeline): runs of equal length end between 0.31 and 0.47 ms and
+// the XCDs finish 10 - 25 % apart, but evening that out inside a workgroup (a wave out of tiles taking half of
+// the longest remaining run over an LDS compare-and-swap) made the launch 15 % SLOWER: a CU's throughput does
+// not fall while its waves retire, so the static deal stays.
 void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames)
 {
     const int kWTile = tile_frames;                 // 512 with a half-band stage in the kernel, 256 without

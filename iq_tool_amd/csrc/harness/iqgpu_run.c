@@ -261,15 +261,11 @@ int main(int argc, char **argv)
         sh[s].first_frame = (long long)s * per;
         sh[s].frames = (s == o.shards - 1) ? total_frames - sh[s].first_frame : per;
         sh[s].out_offset_bytes = off;
-        /* frames a fresh chain will produce for sh[s].frames input frames */
-        long long nout;
-        if (o.desc.no_resample) nout = sh[s].frames;
-        else {
-            const unsigned long long q = (unsigned long long)sh[s].frames >> info.num_halfband_stages;
-            nout = (long long)(((q << 24) + info.arb_step - 1) / info.arb_step);
-        }
-        if (info.filter_block) nout = (nout / info.filter_block) * info.filter_block;
-        off += nout * (long long)obps;
+        /* frames a fresh chain will produce for sh[s].frames input frames: the library's own closed form (decimating
+         * or interpolating resampler, FFT-block quantisation in front of or behind it) */
+        size_t nout = 0;
+        if (iqgpu_design_out_frames(&o.desc, (size_t)sh[s].frames, &nout) != IQGPU_OK) { fprintf(stderr, "%s\n", iqgpu_last_error()); return 1; }
+        off += (long long)nout * (long long)obps;
     }
     if (o.out_path) { int fd = open(o.out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) close(fd); }
 

@@ -11,6 +11,7 @@
 #include <ctime>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/iqgpu.h"
@@ -151,8 +152,12 @@ struct iqgpu_chain {
     PipeSlot pipe[kPipeSlots];
     bool pipe_ready = false; uint64_t pipe_seq = 0; hipEvent_t pipe_prev_kernels = nullptr;
     // I/Q optimiser probe: first 1024 pre-processed samples of a call (device -> pinned host), src/pipeline.c:468-476
+    // (the optimiser runs on ITS OWN thread beside the stage thread: aux_mu guards the factors and the probe state;
+    //  a block in flight or not yet read is never overwritten -- the optimiser takes at most two a second)
+    std::mutex aux_mu;
     bool probe_on = false, probe_pending = false, probe_valid = false;
     cf2 *d_probe = nullptr; cf2 *h_probe = nullptr; hipEvent_t probe_done = nullptr;
+    cf2 probe_last[1024];
     bool direct_dirty = false;    // process_device ran on the chain's own stream since the last synchronisation
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
@@ -625,6 +630,21 @@ extern "C" size_t iqgpu_chain_next_out_frames(const iqgpu_chain *c, size_t frame
     return (size_t)plan_call(c, frames_in).n_emit;
 }
 
+// frames a FRESH chain of this description emits for frames_in input frames in one stream: the same closed form
+// the calls use (resampler law either way round, FFT-block quantisation in front of or behind the resampler),
+// without a device -- what a sharding writer needs to place shard outputs (BASELINE configs[4])
+extern "C" int iqgpu_design_out_frames(const iqgpu_chain_desc *d, size_t frames_in, size_t *frames_out)
+{
+    if (!d || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_design_out_frames: NULL argument");
+    *frames_out = 0;
+    iqgpu_chain *c = new (std::nothrow) iqgpu_chain();
+    if (!c) return fail(IQGPU_ENOMEM, "out of host memory");
+    const int rc = design_chain(c, d);
+    if (rc == IQGPU_OK) *frames_out = (size_t)plan_call(c, frames_in).n_emit;
+    delete c;
+    return rc;
+}
+
 extern "C" size_t iqgpu_chain_max_out_frames(const iqgpu_chain *c, size_t frames_in)
 {
     if (!c) return 0;
@@ -693,6 +713,7 @@ struct Call {
     int64_t total_tiles; int tpb, n_blocks;  // geometry of the workgroup-tiled k_front
     bool casc, fast_s0, fast_s1;             // which front path runs
     int wtile, casc_K, rem_k;
+    float iq_mag = 0.0f, iq_phase = 0.0f;    // the correction factors this call applies (snapshot under aux_mu)
     FrontArgs cplan;                         // run geometry of the wave-autonomous kernel that sees the raw input
     cf2 *fcur = nullptr, *icur = nullptr;    // filter-input / k_interp-input buffers of this call
 
@@ -864,7 +885,7 @@ int Call::stage_front()
         a.dc_carry = (const cd2 *)c->dc_carry.p;
     }
     a.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
-    a.iq_magp1 = 1.0f + c->iq_mag; a.iq_phase = c->iq_phase;
+    a.iq_magp1 = 1.0f + iq_mag; a.iq_phase = iq_phase;
     a.nco_mode = c->nco_mode;
     a.nco_dtheta = c->nco_dtheta;
     // phase of i_rel = 0, i.e. rem samples before the first new sample
@@ -1061,24 +1082,30 @@ static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t fram
         k.fin_out = c->abuf.p; k.fin_fmt = IQGPU_FMT_CF32;
     }
     k.plan_geometry();
+    { std::lock_guard<std::mutex> g(c->aux_mu); k.iq_mag = c->iq_mag; k.iq_phase = c->iq_phase; }   // read once per call
 
     // every buffer the stages need is sized before the first launch, so that an allocation failure leaves the
     // stream state untouched; a failure after that (a launch error) leaves the device state half advanced:
     // the handle is poisoned and every later call fails until iqgpu_chain_reset()
     int rc;
     if ((rc = k.prepare_buffers()) != IQGPU_OK) return rc;
-    if (c->probe_on && frames_in >= 1024) {
+    bool want_probe = false;
+    {
+        std::lock_guard<std::mutex> g(c->aux_mu);
+        want_probe = c->probe_on && frames_in >= 1024 && !c->probe_pending;
+    }
+    if (want_probe) {
         // before k_dc_scan moves the dc state to the end of this call
         IqProbeArgs pa{};
         pa.raw = d_raw_in; pa.in_fmt = c->desc.in_format; pa.gain = c->desc.gain;
         pa.dc_enable = c->dc ? 1 : 0; pa.dc_c = c->dc_c; pa.dc_state = c->d_dc_state;
-        pa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; pa.iq_magp1 = 1.0f + c->iq_mag; pa.iq_phase = c->iq_phase;
+        pa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; pa.iq_magp1 = 1.0f + k.iq_mag; pa.iq_phase = k.iq_phase;
         pa.nco_mode = c->nco_mode; pa.nco_theta0 = c->nco_theta; pa.nco_dtheta = c->nco_dtheta; pa.nco_tab = c->d_nco_tab;
         pa.out = c->d_probe;
-        if (c->probe_pending) HIP_TRY(hipEventSynchronize(c->probe_done));      // the previous block has left the device buffer
         HIP_TRY(launch_iq_probe(pa, c->stream));
         HIP_TRY(hipMemcpyAsync(c->h_probe, c->d_probe, 1024 * sizeof(cf2), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->probe_done, c->stream));
+        std::lock_guard<std::mutex> g(c->aux_mu);
         c->probe_pending = true;
     }
     if (c->dc && (rc = k.stage_dc_carries()) != IQGPU_OK) { c->poisoned = true; return rc; }
@@ -1209,13 +1236,18 @@ extern "C" int iqgpu_chain_read_iq_probe(iqgpu_chain *c, float *block_re_im_1024
     if (!c || !block_re_im_1024 || !valid) return fail(IQGPU_EINVAL, "iqgpu_chain_read_iq_probe: NULL argument");
     *valid = 0;
     if (!c->h_probe) return fail(IQGPU_EINVAL, "the probe is not enabled (iqgpu_chain_enable_iq_probe)");
-    if (c->probe_pending) {
+    bool pending;
+    { std::lock_guard<std::mutex> g(c->aux_mu); pending = c->probe_pending; }
+    if (pending) {
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipEventSynchronize(c->probe_done));
-        c->probe_pending = false; c->probe_valid = true;
+        HIP_TRY(hipEventSynchronize(c->probe_done));          // recorded behind the copy into h_probe
+        std::lock_guard<std::mutex> g(c->aux_mu);
+        memcpy(c->probe_last, c->h_probe, 1024 * sizeof(cf2));
+        c->probe_pending = false; c->probe_valid = true;       // the stage thread may stage the next block now
     }
+    std::lock_guard<std::mutex> g(c->aux_mu);
     if (!c->probe_valid) return IQGPU_OK;
-    memcpy(block_re_im_1024, c->h_probe, 1024 * sizeof(cf2));
+    memcpy(block_re_im_1024, c->probe_last, 1024 * sizeof(cf2));
     *valid = 1;
     return IQGPU_OK;
 }
@@ -1282,6 +1314,7 @@ extern "C" int iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st)
 extern "C" int iqgpu_chain_set_iq_factors(iqgpu_chain *c, float mag, float phase)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
+    std::lock_guard<std::mutex> g(c->aux_mu);                 // the reference's iq_factors_mutex (iq_correct.c:141-152)
     c->iq_mag = mag; c->iq_phase = phase;
     return IQGPU_OK;
 }

@@ -65,3 +65,61 @@ def test_harness_filter_options(gpu, tmp_path):
     assert got.size == want.size and got.size % 4096 == 0
     d = np.abs(got.astype(np.int64) - want.astype(np.int64))
     assert d.max() <= 1 and (d == 0).mean() > 0.99          # dc-blocker carries differ by rounding only
+
+
+def _harness_args(in_fmt, in_rate, out_fmt, out_rate, extra=()):
+    return ["--raw-file-input-rate", repr(in_rate), "--raw-file-input-sample-format", in_fmt, "--output-rate", repr(out_rate),
+            "--output-sample-format", out_fmt, *extra]
+
+
+@pytest.mark.parametrize("name,kw,extra", [
+    # r = 4: arbitrary stage first, then two half-band interpolators (k_interp)
+    ("interp4", dict(in_format="cs16", out_format="cs16", input_rate_hz=600e3, target_rate_hz=2.4e6), ()),
+    # r = 2.5 with an FFT-kind filter IN FRONT of the resampler: block quantisation happens before it
+    ("interp_fft", dict(in_format="cs16", out_format="cf32", input_rate_hz=1.0e6, target_rate_hz=2.5e6,
+                        filters=(("lowpass", 200e3, 0.0),), filter_taps=257, filter_impl="fft"),
+     ("--lowpass", "200e3", "--filter-taps", "257", "--filter-type", "fft")),
+    # r = 1 exactly with a pre filter
+    ("unit_fft", dict(in_format="cu8", out_format="cu8", input_rate_hz=2.0e6, target_rate_hz=2.0e6,
+                      filters=(("lowpass", 300e3, 0.0),), filter_taps=129, filter_impl="fft"),
+     ("--lowpass", "300e3", "--filter-taps", "129", "--filter-type", "fft")),
+])
+def test_harness_shards_on_non_decimating_chains(gpu, tmp_path, name, kw, extra):
+    """shard output offsets come from iqgpu_design_out_frames: r >= 1 and pre-resample FFT filters included"""
+    per, shards = 150_001, 3
+    n = per * shards + 17                                    # the last shard takes the rest
+    raw = synth.raw_stream(n, kw["input_rate_hz"], 6, kw["in_format"])
+    fin, fout = tmp_path / "in.raw", tmp_path / "out.raw"
+    raw.tofile(fin)
+    info = run("-i", str(fin), "-o", str(fout), *_harness_args(kw["in_format"], kw["input_rate_hz"], kw["out_format"], kw["target_rate_hz"], extra),
+               "--shards", str(shards), "--devices", "1", "--chunk-frames", "65536")
+    ch = gpu.Chain(**kw)
+    bpf = ch.in_bytes
+    rb = raw.view(np.uint8)
+    parts = []
+    for s in range(shards):
+        a = s * per
+        b = n if s == shards - 1 else (s + 1) * per
+        parts.append(gpu.Chain(**kw).process(rb[a * bpf:b * bpf]))
+    want = np.concatenate(parts)
+    got = np.fromfile(fout, want.dtype)
+    assert info["shards"] == shards and got.size == want.size
+    if want.dtype == np.float32:
+        assert np.abs(got - want).max() <= 2e-6            # chunked calls vs one call per shard
+    else:
+        assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1
+
+
+def test_harness_shards_over_all_visible_devices(gpu, tmp_path):
+    """--shards K --devices min(K, device_count): one chain per GPU, outputs stitched in shard order (no collective)"""
+    ndev = gpu.load().iqgpu_device_count()
+    shards = 4
+    n = shards * 400_000
+    raw = synth.raw_stream(n, 2.4e6, 12, "cs16")
+    fin, fout = tmp_path / "in.cs16", tmp_path / "out.cs16"
+    raw.tofile(fin)
+    info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", str(shards), "--devices", str(min(shards, ndev)), "--chunk-frames", "131072")
+    got = np.fromfile(fout, np.int16)
+    parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 400_000:2 * (s + 1) * 400_000]) for s in range(shards)]
+    assert np.array_equal(got, np.concatenate(parts))
+    assert info["shards"] == shards

@@ -273,3 +273,31 @@ def test_bench_under_a_launcher_reads_ranks_from_the_environment():
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534"),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert q.returncode != 0 and "WORLD_SIZE" in q.stderr
+
+
+@pytest.mark.parametrize("kw", [
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3),
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=600e3, target_rate_hz=2.4e6),
+    dict(in_format="cs16", out_format="cf32", input_rate_hz=1.0e6, target_rate_hz=2.5e6, filters=(("lowpass", 200e3, 0.0),), filter_taps=257, filter_impl="fft"),
+    dict(in_format="cu8", out_format="cu8", input_rate_hz=2.0e6, target_rate_hz=2.0e6, filters=(("lowpass", 300e3, 0.0),), filter_taps=129, filter_impl="fft"),
+    dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0, filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=2.4e6, no_resample=True),
+])
+def test_design_out_frames_is_the_oracles_count(kw):
+    """iqgpu_design_out_frames (what places shard outputs) against the oracle actually running the stream"""
+    import iq_tool_amd
+    from iq_tool_amd import synth
+    from iq_tool_amd.chain import make_desc
+    from oracle import pyoracle
+    pyoracle.build()
+    lib = iq_tool_amd.load()
+    d = make_desc(**kw)
+    for n in (0, 1, 1023, 4096, 50_001, 131_072 + 5):
+        got = C.c_size_t(0)
+        assert lib.iqgpu_design_out_frames(C.byref(d), n, C.byref(got)) == 0
+        raw = synth.raw_stream(max(n, 1), kw["input_rate_hz"], 1, kw["in_format"])
+        bpf = 2 if kw["in_format"] in ("cu8", "cs8") else 4
+        out = pyoracle.Chain(**kw).process(raw.view(np.uint8)[:n * bpf])
+        obpf = {"cs16": 2, "cu8": 2, "cf32": 2}[kw["out_format"]]
+        assert got.value == out.size // obpf, (n, got.value, out.size // obpf)
