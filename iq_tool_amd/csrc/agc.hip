@@ -23,6 +23,7 @@ constexpr float kAgcLockTime = 2.0f, kAgcHangTime = 4.0f, kAgcRecovery = 1.0005f
 
 __global__ __launch_bounds__(kThreads) void k_agc_peak(const AgcArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;
     const int c = blockIdx.x;
     const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
     const int64_t len = e - b;
@@ -77,6 +78,7 @@ __device__ __forceinline__ float wave_scan_max(float x)      // x >= 0
 
 __global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;
     const int lane = threadIdx.x;
     AgcState st = *a.state;
     const float target = a.target;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
 
 __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;
     const int c = blockIdx.x;
     const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
     const int64_t len = e - b;
@@ -175,6 +178,58 @@ __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
         const cf2 v = a.x[i];
         pack_store(a.out, i, a.out_fmt, cf2{v.x * g, v.y * g});   // samples[i] *= gain (complex * real)
     }
+}
+
+// ---- the fused path (front_wave.hip, k_front_s1<4, true, false, AGC>) ------------------------------------------
+// In the locked phase agc_apply changes the gain only when a chunk ratchets (peak * g > 1) or has been weak for more
+// than the hang time (src/agc.c:165-215); otherwise every chunk is multiplied by the same g.  The front kernel has
+// therefore already multiplied by the g it found in the state and left max |y|^2 per chunk in peak2; this kernel
+// confirms the assumption for every chunk of the call: locked, and every non-empty chunk "healthy" at g (not
+// ratcheting, above the lower threshold -- the one case in which agc.c touches nothing but the strong-peak time).
+// Then the bytes the front kernel wrote are final and the state advances here.  Anything else -- not locked, a
+// ratchet, a weak chunk (whose fate depends on the hang timer) -- sets *verify_flag: the unfused kernels queued
+// behind redo the call from the untouched state.
+__global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
+{
+    __shared__ int s_bad;
+    __shared__ int s_last;
+    if (threadIdx.x == 0) { s_bad = 0; s_last = -1; }
+    __syncthreads();
+    const AgcState st = *a.state;
+    int bad = st.locked ? 0 : 1;
+    int last_active = -1;
+    if (!bad) {
+        const float g = st.gain, target = a.target;
+        for (int c = threadIdx.x; c < a.geom.n_chunks; c += (int)blockDim.x) {
+            const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+            if (e <= b) continue;                                  // empty chunks never reach agc_apply
+            const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
+            const float outp = pk * g;
+            if (outp > 1.0f || !(outp > target * kAgcLower)) bad = 1;
+            last_active = c;
+        }
+    }
+    if (bad) atomicOr(&s_bad, 1);
+    if (last_active >= 0) atomicMax(&s_last, last_active);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *a.verify_flag = s_bad;
+        if (!s_bad) {
+            AgcState nx = st;
+            if (s_last >= 0) {                                     // every active chunk was healthy: the last one leaves its time
+                const uint64_t seen_last = st.seen + (uint64_t)agc_out_end(a.geom, (int64_t)s_last - 1);
+                nx.last_strong = a.clock_wall ? a.t_wall : (double)seen_last / a.rate;
+            }
+            nx.seen = st.seen + (uint64_t)a.n_out;
+            *a.state = nx;
+        }
+    }
+}
+
+hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_agc_verify, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_agc(const AgcArgs &a, hipStream_t s)

@@ -166,7 +166,15 @@ __device__ __forceinline__ void gather_taps2(unsigned row_a, unsigned row_b, v2f
 // EDGE = false: every tile (and the one after the last, for the prefetch) lies inside the call's
 //               new, aligned frames and outside the history the call leaves behind.
 // EDGE = true : per-frame scalar loads; handles history, end of call, alignment, history save.
-template <int BPS, bool EDGE, bool FAST, bool S0>
+// max over the wave of a non-negative double (rare: once per chunk boundary and run end)
+__device__ __forceinline__ double wave_max_d(double m)
+{
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(m, k); m = o > m ? o : m; }
+    return m;
+}
+
+template <int BPS, bool EDGE, bool FAST, bool S0, bool AGC = false>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
@@ -239,6 +247,19 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         }
     };
     float sl_hist = 0.0f;         // one dword per lane (< 48) of the last 4 rows of the polyphase input
+    // fused AGC (locked phase): gain from the device state, per-lane max |y|^2 (exact, in double) of the chunk the
+    // run is in and of the next one; a chunk ends where the input frame (c + 1) * chunk_frames - 1 completes a
+    // half-band sample (agc_out_end, kernels.hpp): at most one boundary per tile
+    float agc_g = 1.0f;
+    double agc_m0 = 0.0, agc_m1 = 0.0;
+    int64_t agc_c = 0, agc_B = 0;
+    bool agc_any = false;
+    if (AGC) {
+        agc_g = a.agc_state->gain;
+        const int64_t F0 = (int64_t)TILE * t_emit0 + 1 - a.rem0;
+        agc_c = F0 > 0 ? F0 / a.agc_chunk_frames : 0;
+        agc_B = (agc_c + 1) * a.agc_chunk_frames;
+    }
     STAMP_DECL
     STAMP_BEGIN;
     CLOCK_BEGIN;
@@ -471,11 +492,32 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 if (!EDGE) __builtin_amdgcn_s_setprio(0);
                 uint32_t kk = n0;
                 uint32_t pk[4] = {0, 0, 0, 0};
+                uint32_t agc_qb = 256u;                           // half-band samples of this tile below it are in chunk agc_c
+                if (AGC) {
+                    const int64_t F0 = (int64_t)TILE * t + 1 - a.rem0;      // last input frame that half-band sample 0 of the tile needs
+                    if (F0 >= agc_B) {                                      // the boundary fell between two tiles
+                        const double m = wave_max_d(agc_m0);
+                        if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+                        agc_m0 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
+                    }
+                    const int64_t d = agc_B - F0;
+                    if (d < 2 * 256) agc_qb = (uint32_t)((d + 1) >> 1);
+                    agc_any = true;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
                         if (!FAST && a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
+                        if (AGC) {
+                            // agc_apply: peak of the chunk over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
+                            const double re = (double)yy.x, im = (double)yy.y;
+                            const double m2 = fma(re, re, im * im);          // exact: products of floats, sum below 2^53 ulps
+                            if (agc_qb >= 256u) agc_m0 = fmax(agc_m0, m2);
+                            else if ((uint32_t)(4 * lane + r) < agc_qb) agc_m0 = fmax(agc_m0, m2);
+                            else agc_m1 = fmax(agc_m1, m2);
+                            yy = v2f{yy.x * agc_g, yy.y * agc_g};
+                        }
                         if (defer) pk[r] = pack_cs16(cf2{yy.x, yy.y});
                         else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
@@ -492,6 +534,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     pend_cnt = kk - n0;
                 }
                 pend_base = obase;
+                if (AGC && agc_qb < 256u) {                       // the tile held a boundary: chunk agc_c is complete for this run
+                    const double m = wave_max_d(agc_m0);
+                    if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+                    agc_m0 = agc_m1; agc_m1 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
+                }
             }
             // outputs of this tile, ceil((2^32 - delta0) / step) = floor((2^32 - 1 - delta0) / step) + 1
             uint32_t nt;
@@ -529,6 +576,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         STAMP(6);
     }
     if (defer) flush_pending();
+    if (AGC && agc_any) {
+        const double m = wave_max_d(agc_m0);
+        if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+    }
     CLOCK_END(a.sink);
     STAMP_FLUSH(a.sink);
 }
@@ -539,9 +590,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 //      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
-template <int BPS, bool FAST, bool S0 = false>
+template <int BPS, bool FAST, bool S0 = false, bool AGC = false>
 __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int kThr = (FAST || BPS == 2) ? kS1Threads : kWThreads, kWv = (FAST || BPS == 2) ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -590,13 +642,13 @@ __global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
         const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);   // DcGeom mode 1 order
-        run_tiles<BPS, true, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        run_tiles<BPS, true, FAST, S0, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
         const int seg = (int)(a.w_n_edge1 + r);
-        if (BPS != 0) run_tiles<BPS, false, FAST, S0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        if (BPS != 0) run_tiles<BPS, false, FAST, S0, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -605,6 +657,9 @@ static bool front_s1_fast_shape(const FrontArgs &a)
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
            !a.dc_enable && a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
 }
+// the fused AGC exists for the specialised instantiation (the shipped cs16 NRSC-5 presets); chunks at least a tile long
+bool front_s1_agc_fusable(const FrontArgs &a) { return front_s1_fast_shape(a) && a.agc_chunk_frames >= kWTile && !getenv("IQGPU_AGC_NOFUSE"); }
+
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
 {
@@ -630,12 +685,13 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_S1(BPS, FAST, S0)                                                                                \
+#define IQGPU_LAUNCH_S1X(BPS, FAST, S0, AGC)                                                                          \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0>), dim3(grid), dim3(waves * 64), lds, s, a);                     \
+        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0, AGC>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC>), dim3(grid), dim3(waves * 64), lds, s, a);                \
     } while (0)
+#define IQGPU_LAUNCH_S1(BPS, FAST, S0) IQGPU_LAUNCH_S1X(BPS, FAST, S0, false)
     if (a.S == 0) {
         if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
         else if (cls == 4) IQGPU_LAUNCH_S1(4, false, true);
@@ -643,11 +699,13 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         else IQGPU_LAUNCH_S1(0, false, true);
     }
     else if (cls == 2) IQGPU_LAUNCH_S1(2, false, false);
+    else if (cls == 4 && fast && a.agc_fused) IQGPU_LAUNCH_S1X(4, true, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);
     else if (cls == 8) IQGPU_LAUNCH_S1(8, false, false);
     else IQGPU_LAUNCH_S1(0, false, false);
 #undef IQGPU_LAUNCH_S1
+#undef IQGPU_LAUNCH_S1X
     return hipGetLastError();
 }
 

@@ -136,7 +136,12 @@ struct iqgpu_chain {
     // output AGC (digital profile)
     bool agc = false; float agc_target = 0.9f; int64_t agc_chunk = 16384;
     AgcState *d_agc_state = nullptr; AgcState agc_init{};
-    DevBuf abuf, agc_peak, agc_gain;
+    DevBuf abuf, agc_peak, agc_gain, agc_peak_b;
+    // fused AGC of the locked phase (k_front_s1<.., AGC> + k_agc_verify): which chains qualify, the host's mirror of
+    // "has the stream locked" (a closed form: the first chunk that starts after AGC_DIGITAL_LOCK_TIME of output), the
+    // flag the verifier leaves for the fallback launches
+    bool agc_fusable = false, agc_locked_host = false; uint64_t agc_seen_host = 0;
+    int32_t *d_agc_flag = nullptr;
     DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
     InterpArgs ia{};              // geometry of the r >= 1 path
     int ihist = 0;
@@ -215,7 +220,8 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_hfreq) (void)hipFree(c->d_hfreq);
     if (c->d_ihb) (void)hipFree(c->d_ihb);
     if (c->d_agc_state) (void)hipFree(c->d_agc_state);
-    c->abuf.release(); c->agc_peak.release(); c->agc_gain.release();
+    c->abuf.release(); c->agc_peak.release(); c->agc_gain.release(); c->agc_peak_b.release();
+    if (c->d_agc_flag) (void)hipFree(c->d_agc_flag);
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     for (int i = 0; i < 2; ++i) if (c->d_hist2[i]) (void)hipFree(c->d_hist2[i]);
@@ -438,6 +444,15 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             CREATE_TRY(hipMalloc((void **)&c->d_agc_state, sizeof(AgcState)));
             c->agc_init = AgcState{0, 0.05f, 1.0f, 0, c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0, 0};
             CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(int32_t)));
+            CREATE_TRY(hipMemset(c->d_agc_flag, 0, sizeof(int32_t)));
+            // the fused path exists for the specialised front kernel: the shipped cs16 NRSC-5 preset shape
+            FrontArgs fa{};
+            fa.S = c->S; fa.in_fmt = c->desc.in_format; fa.out_fmt = c->desc.out_format; fa.gain = c->desc.gain;
+            fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
+            fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk;
+            c->agc_fusable = c->decim && !c->late && !c->cascade && !c->force_generic && !c->fp.enabled && c->S == 1 &&
+                             c->rp.stages[0].m == 10 && front_s1_agc_fusable(fa);
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
         // overlap-save path: every FFT-kind filter, and FIR-kind ones long enough that two transforms
@@ -714,6 +729,7 @@ struct Call {
     bool casc, fast_s0, fast_s1;             // which front path runs
     int wtile, casc_K, rem_k;
     float iq_mag = 0.0f, iq_phase = 0.0f;    // the correction factors this call applies (snapshot under aux_mu)
+    bool agc_fused = false;                  // this call: gain applied in the front kernel, verified behind it
     FrontArgs cplan;                         // run geometry of the wave-autonomous kernel that sees the raw input
     cf2 *fcur = nullptr, *icur = nullptr;    // filter-input / k_interp-input buffers of this call
 
@@ -747,6 +763,8 @@ struct Call {
     int stage_filter();
     int stage_late_resampler();
     int stage_agc();
+    int stage_agc_verify_and_fallback(const FrontArgs &spec);
+    AgcArgs agc_args() const;
 };
 
 void Call::plan_geometry()
@@ -864,6 +882,10 @@ int Call::prepare_buffers()
         if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
         int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
         rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
+        if (agc_fused) {   // what the fallback launches need, should the verifier reject the fused pass
+            rc = c->agc_peak_b.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
+            rc = c->abuf.ensure(((size_t)p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
+        }
     }
     return IQGPU_OK;
 }
@@ -948,8 +970,13 @@ int Call::stage_front()
         // wave-autonomous kernel: one half-band stage (m = 10), or none
         copy_plan(a);
         if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
-        KernelTimer kt(c, IQGPU_K_FRONT);
-        HIP_TRY(launch_front_s1(a, c->stream));
+        if (agc_fused) {
+            a.agc_fused = 1; a.agc_state = c->d_agc_state; a.agc_peak2 = (unsigned long long *)c->agc_peak.p;
+            a.agc_chunk_frames = c->agc_chunk;
+            HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
+        }
+        { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a, c->stream)); }
+        if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
     } else {
         KernelTimer kt(c, IQGPU_K_FRONT);
         HIP_TRY(launch_front(a, n_blocks, c->stream));
@@ -1018,11 +1045,11 @@ AgcGeom Call::agc_geom() const
     return g;
 }
 
-int Call::stage_agc()
+AgcArgs Call::agc_args() const
 {
     AgcArgs ga{};
     ga.geom = agc_geom();
-    AgcGeom &g = ga.geom;
+    const AgcGeom &g = ga.geom;
     ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
     ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p;
     ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
@@ -1033,7 +1060,33 @@ int Call::stage_agc()
     int64_t splits = (avg + 16383) / 16384; if (splits > 1024) splits = 1024;
     ga.splits = (int)splits;
     ga.out_fmt = c->desc.out_format; ga.out = d_out;
+    return ga;
+}
+
+int Call::stage_agc()
+{
+    const AgcArgs ga = agc_args();
     KernelTimer kt(c, IQGPU_K_AGC);
+    HIP_TRY(launch_agc(ga, c->stream));
+    return IQGPU_OK;
+}
+
+// behind a fused front launch: the verifier, then the unfused kernels as launches that do nothing unless the
+// verifier raised its flag (same input, same history buffers, the untouched AGC state)
+int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
+{
+    AgcArgs va = agc_args();
+    va.verify_flag = c->d_agc_flag;
+    KernelTimer kt(c, IQGPU_K_AGC);
+    HIP_TRY(launch_agc_verify(va, c->stream));
+    FrontArgs fb = spec;
+    fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr;
+    fb.out_fmt = IQGPU_FMT_CF32; fb.out = c->abuf.p;
+    fb.run_if = c->d_agc_flag;
+    HIP_TRY(launch_front_s1(fb, c->stream));
+    AgcArgs ga = va;
+    ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
+    ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
     HIP_TRY(launch_agc(ga, c->stream));
     return IQGPU_OK;
 }
@@ -1055,8 +1108,68 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
     return process_device_impl(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out);
 }
 
+// first frame count (a multiple of the AGC chunk, or the whole call) that must take the unfused AGC path: everything
+// while the stream has not locked.  agc_apply locks on the first chunk that STARTS after AGC_DIGITAL_LOCK_TIME of
+// output (src/agc.c:151-155: elapsed = samples_seen / rate before this chunk is counted), a closed form of the
+// stream position; sets *locks when that chunk lies in this call.
+static size_t agc_unfused_head(const iqgpu_chain *c, size_t frames_in, bool *locks)
+{
+    *locks = false;
+    if (c->agc_locked_host) return 0;
+    AgcGeom g{};
+    g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
+    g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
+    g.mode = 1; g.rem = c->rem; g.S = c->S; g.phi = c->phi; g.step = c->rp.step;
+    int64_t lo = 0, hi = g.n_chunks;                        // first chunk whose start time exceeds the lock time
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        const uint64_t seen = c->agc_seen_host + (uint64_t)agc_out_end(g, mid - 1);
+        if ((double)seen / c->target_rate > (double)2.0f) hi = mid; else lo = mid + 1;
+    }
+    // (empty chunks never reach agc_apply; a decimating chain with chunks of at least a tile has none but a possible
+    //  first one, which the search passes over because its successor starts at the same time)
+    while (lo < g.n_chunks && agc_out_end(g, lo) == agc_out_end(g, lo - 1)) ++lo;
+    if (lo >= g.n_chunks) return frames_in;
+    *locks = true;
+    const int64_t head = (lo + 1) * c->agc_chunk;
+    return head < (int64_t)frames_in ? (size_t)head : frames_in;
+}
+
+static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                       void *d_out, size_t out_capacity_bytes, size_t *frames_out, bool agc_fused);
+
 static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
                                void *d_out, size_t out_capacity_bytes, size_t *frames_out)
+{
+    if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
+    if (!c->agc_fusable || frames_in == 0) return process_one(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out, false);
+    // output AGC on the specialised front kernel: the scanning phase (and the chunk that locks) through the unfused
+    // kernels, everything behind it fused
+    *frames_out = 0;
+    bool locks = false;
+    const size_t head = agc_unfused_head(c, frames_in, &locks);
+    const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
+    if ((size_t)plan_call(c, frames_in).n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", (size_t)plan_call(c, frames_in).n_emit * obps, out_capacity_bytes);
+    size_t n1 = 0, n2 = 0;
+    if (head > 0) {
+        const int rc = process_one(c, d_raw_in, head, d_out, out_capacity_bytes, &n1, false);
+        if (rc) return rc;
+        c->agc_seen_host += n1;
+        if (locks) c->agc_locked_host = true;
+    }
+    if (head < frames_in) {
+        const int rc = process_one(c, (const char *)d_raw_in + head * ibps, frames_in - head, (char *)d_out + n1 * obps,
+                                   out_capacity_bytes - n1 * obps, &n2, true);
+        if (rc) return rc;
+        c->agc_seen_host += n2;
+    }
+    *frames_out = n1 + n2;
+    return IQGPU_OK;
+}
+
+static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
+                       void *d_out, size_t out_capacity_bytes, size_t *frames_out, bool agc_fused)
 {
     if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
     *frames_out = 0;
@@ -1075,9 +1188,11 @@ static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t fram
     k.filt = c->fp.enabled;
     k.L1 = k.filt ? c->fp.taps.size() - 1 : 0;
     k.fpending0 = c->fpending;
-    // with the AGC on, the last stage leaves cf32 in abuf and k_agc_apply packs
+    // with the AGC on, the last stage leaves cf32 in abuf and k_agc_apply packs -- unless the call is past the lock
+    // on a chain whose front kernel applies the gain itself (fused: packed output straight to the caller)
     k.fin_out = d_out; k.fin_fmt = c->desc.out_format;
-    if (c->agc) {
+    k.agc_fused = agc_fused;
+    if (c->agc && !agc_fused) {
         int rc = c->abuf.ensure(((size_t)k.p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
         k.fin_out = c->abuf.p; k.fin_fmt = IQGPU_FMT_CF32;
     }
@@ -1112,7 +1227,7 @@ static int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t fram
     if ((rc = k.stage_front()) != IQGPU_OK) { c->poisoned = true; return rc; }
     if (k.filt && (rc = k.stage_filter()) != IQGPU_OK) { c->poisoned = true; return rc; }
     if (c->late && (rc = k.stage_late_resampler()) != IQGPU_OK) { c->poisoned = true; return rc; }
-    if (c->agc && (rc = k.stage_agc()) != IQGPU_OK) { c->poisoned = true; return rc; }
+    if (c->agc && !agc_fused && (rc = k.stage_agc()) != IQGPU_OK) { c->poisoned = true; return rc; }
 
     // ---- advance the stream position ----
     c->nco_theta += (uint32_t)frames_in * c->nco_dtheta;
@@ -1280,6 +1395,7 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));   // batches in flight finish first
     c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
+    c->agc_locked_host = false; c->agc_seen_host = 0;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
     if (c->agc) { // agc_reset, src/agc.c:224-238
         c->agc_init.last_strong = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0;

@@ -52,6 +52,7 @@ struct LdsAttrCache {
 };
 
 struct cf2 { float x, y; };
+struct AgcState;
 struct cd2 { double x, y; };
 
 // ---------------------------------------------------------------------------------------------
@@ -111,6 +112,13 @@ struct FrontArgs {
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
+    // fused output AGC of the locked phase (front_wave.hip, agc.hip): the kernel multiplies by the gain in *agc_state
+    // before the pack and records max |y|^2 per chunk; k_agc_verify then confirms that no chunk changes the gain
+    int32_t     agc_fused;
+    const struct AgcState *agc_state;
+    unsigned long long *agc_peak2;      // [n_chunks], double bits, zeroed before the launch
+    int64_t     agc_chunk_frames;       // >= the tile (at most one chunk boundary per tile)
+    const int32_t *run_if;              // not NULL: the launch does nothing unless *run_if != 0 (fallback launches)
     void       *sink;         // 64 KiB diagnostic scratch (per-phase cycle counters of -DIQGPU_STAMPS builds)
     // k_cascade (cascade_wave.hip): the first casc_K stages of an S >= 2 chain, cf32 out
     int32_t     casc_K;
@@ -334,8 +342,14 @@ struct AgcArgs {
     int32_t    splits;        // workgroups per chunk
     int32_t    out_fmt;
     void      *out;
+    const int32_t *run_if;    // not NULL: the three kernels do nothing unless *run_if != 0
+    int32_t   *verify_flag;   // k_agc_verify: set to 1 when the fused pass cannot stand (see agc.hip)
 };
 hipError_t launch_agc(const AgcArgs &a, hipStream_t s);   // peak, scan, apply
+// after a fused launch of the front kernel: all chunks healthy at the unchanged gain -> state advanced, *verify_flag = 0;
+// otherwise state untouched and *verify_flag = 1 (the caller has queued the unfused kernels behind it, run_if = verify_flag)
+hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s);
+bool front_s1_agc_fusable(const FrontArgs &a);
 
 // dst[i] = src[i], i < n (cf32)
 hipError_t launch_copy_cf(cf2 *dst, const cf2 *src, int64_t n, hipStream_t s);

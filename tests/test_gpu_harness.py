@@ -86,8 +86,9 @@ def _harness_args(in_fmt, in_rate, out_fmt, out_rate, extra=()):
 ])
 def test_harness_shards_on_non_decimating_chains(gpu, tmp_path, name, kw, extra):
     """shard output offsets come from iqgpu_design_out_frames: r >= 1 and pre-resample FFT filters included"""
-    per, shards = 150_001, 3
-    n = per * shards + 17                                    # the last shard takes the rest
+    shards = 3
+    n = 150_001 * shards + 17
+    per = n // shards                                        # the harness's plan: equal ranges, the last shard takes the rest
     raw = synth.raw_stream(n, kw["input_rate_hz"], 6, kw["in_format"])
     fin, fout = tmp_path / "in.raw", tmp_path / "out.raw"
     raw.tofile(fin)

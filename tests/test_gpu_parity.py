@@ -974,3 +974,75 @@ def test_one_round_run_plan_any_call_size(gpu, oracle, monkeypatch, frames):
     int_close(fast, slow, 0.99)
     if frames <= (1 << 22) + 12345:
         int_close(fast, run_oracle(oracle, raw, **kw))
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: output AGC fused into the front kernel past the lock (k_front_s1<.., AGC> + k_agc_verify),
+# unfused kernels as the conditional fallback
+# --------------------------------------------------------------------------------------------
+def _enveloped_stream(n, seed, segments):
+    """cs16 stream at 2.4 MS/s whose amplitude follows (start_second, factor) segments"""
+    raw = synth.raw_stream(n, 2.4e6, seed, "cs16").astype(np.float64).reshape(-1, 2)
+    env = np.ones(n)
+    for t0, f in segments:
+        env[int(t0 * 2.4e6):] = f
+    return np.clip(np.rint(raw * env[:, None]), -32768, 32767).astype(np.int16).reshape(-1)
+
+
+@pytest.mark.parametrize("case", ["steady", "ratchet", "fade_and_creep", "many_calls", "odd_chunk"])
+def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case):
+    n = int(2.4e6 * 9.5)
+    kw = dict(NRSC5, agc=True)
+    splits = [n]
+    if case == "steady":
+        raw = _enveloped_stream(n, 41, [(0.0, 0.5)])
+    elif case == "ratchet":                          # a burst 1.6 x the level the AGC locked on: peak * g > 1
+        raw = _enveloped_stream(n, 42, [(0.0, 0.4), (5.0, 0.64), (5.5, 0.4)])
+    elif case == "fade_and_creep":                   # weak for longer than the 4 s hang time: gain creeps per chunk
+        raw = _enveloped_stream(n, 43, [(0.0, 0.6), (3.0, 0.2)])
+    elif case == "many_calls":
+        raw = _enveloped_stream(n, 44, [(0.0, 0.5)])
+        rng = np.random.default_rng(3)
+        splits, left = [], n
+        while left:
+            k = int(min(left, rng.integers(1, 60) * 16384 + (rng.integers(0, 3) == 0) * 777))
+            splits.append(k); left -= k
+    else:
+        raw = _enveloped_stream(n, 45, [(0.0, 0.5)])
+        kw["agc_chunk_frames"] = 5000                 # not a multiple of the tile
+
+    def run(env):
+        if env:
+            monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+        else:
+            monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+        ch = gpu.Chain(**kw)
+        outs, pos = [], 0
+        for k in splits:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        return np.concatenate(outs), ch.agc_state()
+
+    fused, st_f = run(False)
+    plain, st_p = run(True)
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+    assert np.array_equal(fused, plain), case                    # same arithmetic either way: identical bytes
+    assert st_f == st_p, (st_f, st_p)
+    assert st_f["locked"]
+    if case in ("steady", "ratchet", "fade_and_creep", "odd_chunk"):
+        okw = dict(kw)
+        want = run_oracle(oracle, raw, **okw) if case != "odd_chunk" else None
+        if want is not None:
+            int_close(fused, want, min_same=0.95)
+
+
+def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):
+    n = int(2.4e6 * 4)
+    raw = _enveloped_stream(n, 46, [(0.0, 0.5)])
+    kw = dict(NRSC5, agc=True)
+    want = gpu.Chain(**kw).process(raw)
+    ch = gpu.Chain(**kw)
+    got = ch.process_pipelined(raw, 16 * 16384)
+    assert np.array_equal(got, want)
+    ch.reset()                                                   # back to the scanning phase: the host mirror follows
+    assert not ch.agc_state()["locked"]
+    assert np.array_equal(ch.process(raw), want)
