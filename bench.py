@@ -58,13 +58,18 @@ def parse():
     ap.add_argument("--log2-frames", type=int, default=28, help="frames per step and GPU (default 2^28 = 1 GiB of cs16)")
     ap.add_argument("--cpu-frames-log2", type=int, default=28, help="bounded CPU-baseline sample (2^28 = one step's batch, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="2 = BASELINE configs[1] (the metric's config, default); 3 / 4 = configs[2] / configs[3], secondary timings")
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "preset"],
+                    help="2 = BASELINE configs[1] (the metric's config, default); 3 / 4 = configs[2] / configs[3], secondary timings; "
+                         "preset = configs[1] as the shipped cs16-fm-nrsc5 preset runs it, digital output AGC on (iq_tool_presets.conf:216-222)")
     ap.add_argument("--settle-seconds", type=float, default=2.0,
                     help="untimed back-to-back steps before the W warm-up steps, so that the K timed steps see the clock the chip HOLDS under this load and not the first milliseconds after idle (measured: launches 1-3 0.48 ms, 4-12 up to 0.68 ms, steady state 0.49 ms)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host_end_to_end leg")
     ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
     ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.preset = a.config == "preset"
+    a.config = 2 if a.preset else int(a.config)
+    return a
 
 
 KERNEL_SOURCES = ("front_wave.hip", "wave_common.hpp", "dsp_device.hpp", "kernels.hpp")
@@ -188,18 +193,30 @@ def host_leg(dist, chain, seg, frames_total, batch):
     return dt, n_batches * batch, n_batches * batch * in_b, state["down"]
 
 
-def algorithmic_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
-    """FP32 flops of one step in the reference's own formulation: real x complex MAC = 4,
-    complex x complex = 8; half-band stage i: 2 m_i taps per output at rate / 2^(i+1); polyphase 14 taps
-    per output; user filter as the direct form it is specified as (the product may run it as overlap-save)."""
+def step_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
+    """FP32 flops of one step.  Everything in front of the user filter in the reference's own formulation (SURVEY 8d:
+    real x complex MAC = 4, complex x complex = 8; half-band stage i: 2 m_i taps per output at rate / 2^(i+1); polyphase
+    14 taps per output).  The user filter twice: `direct` as the direct form it is specified as (what liquid's firfilt
+    executes and SURVEY 8d counts), `executed` as the overlap-save block convolution the product runs for filters of
+    96 taps and more (two N-point transforms at 5 N log2 N plus the N-point product per N - L + 1 outputs, N by the rule
+    of iqgpu_api.cpp).  Returns (executed, direct)."""
     f = frames * (2.0 + (6.0 if desc_kw.get("shift_hz") else 0.0) + (8.0 if desc_kw.get("dc_block") else 0.0)
                   + (3.0 if desc_kw.get("iq_correct") else 0.0))
     for i in range(info.num_halfband_stages):
         f += (frames / float(1 << (i + 1))) * (2 * info.stage_m[i] * 4 + 2)
     f += n_res * 14 * 4
-    f += n_emit * ntaps * (8 if taps_complex else 4)
     f += n_emit * 4.0
-    return f
+    direct = n_emit * ntaps * (8 if taps_complex else 4)
+    executed = direct
+    if ntaps >= 96:
+        lg = 8
+        while (1 << lg) < 4 * (ntaps - 1) and (1 << lg) < 4096:
+            lg += 1
+        while (1 << lg) < 2 * (ntaps - 1):
+            lg += 1
+        n = 1 << lg
+        executed = (n_emit / float(n - (ntaps - 1))) * (2 * 5.0 * n * lg + 6.0 * n)
+    return f + executed, f + direct
 
 
 def cpu_baseline(frames_log2):
@@ -272,7 +289,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    chain_kw, rate, fmt, in_bps, workload = CHAIN, 2.4e6, "cs16", 4, None
+    chain_kw, rate, fmt, in_bps, workload = (dict(CHAIN, agc=True) if args.preset else CHAIN), 2.4e6, "cs16", 4, None
     if args.config != 2:
         o = OTHER[args.config]
         chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
@@ -328,7 +345,7 @@ def main():
 
     # ---- second leg: the same chain fed from pinned host memory (PCIe-inclusive; never `value`) ----
     host = None
-    if not args.no_host_leg and args.config == 2:
+    if not args.no_host_leg and args.config == 2 and not args.preset:
         chain.set_stream(0)                            # back to the chain's own stream
         chain.reset()
         h_dt, h_frames, h_up, h_down = host_leg(dist, chain, seg, 1 << args.host_log2_frames, 1 << args.host_batch_log2)
@@ -358,16 +375,24 @@ def main():
         if args.config != 2:
             # configs 3 / 4 are ALU-bound: price them against the FP32 vector peak, HBM fraction kept beside it
             info = chain.info()
-            flops = algorithmic_flops(info, frames, n_out_avg if not info.filter_ntaps else n_out_avg, n_out_avg, chain_kw,
-                                      int(info.filter_ntaps), info.filter_impl in (2, 4))
+            n_res = float(-(-((frames >> info.num_halfband_stages) << 24) // info.arb_step))
+            flops, flops_direct = step_flops(info, frames, n_res, n_out_avg, chain_kw, int(info.filter_ntaps), info.filter_impl in (2, 4))
             tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             line["config"]["workload"] = workload
             line["roofline"] = {"bound": "fp32", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                                 "traffic": None, "kernel": "all kernels of the step", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
-                                "algorithmic_flops_per_step": int(flops), "algorithmic_bytes_per_step": int(alg_bytes),
+                                "executed_flops_per_step": int(flops), "direct_form_flops_per_step": int(flops_direct),
+                                "direct_form_TFLOPs": round(flops_direct / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
+                                "algorithmic_bytes_per_step": int(alg_bytes),
                                 "hbm_GBs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
                                 "note": "per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])}
-        if world == 1 and not args.no_cpu_baseline and args.config == 2:
+        if args.preset:
+            line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
+                                          "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "
+                                          + ", ".join("%s %.3f" % (k, v["ms"] / max(args.steps, 1)) for k, v in prof.items() if v["launches"]))
+            line["roofline"]["kernel"] = "k_front_s1<4, true, false, agc>"
+            line["roofline"]["traffic"] = None
+        if world == 1 and not args.no_cpu_baseline and args.config == 2 and not args.preset:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
         else:
             line["cpu_baseline"] = None

@@ -10,11 +10,15 @@
 //
 // Mapping (as in front_wave.hip): one wavefront owns a run of 512-frame tiles, frames arrive by
 // register-prefetched 16-byte loads, every stage keeps its input split into even / odd streams in
-// rows of 4 cf32 (48-byte pitch) in the wave's private LDS slice, a lane owns 4 consecutive
-// outputs of a stage.  Stage k sees 512 >> k samples per tile, so 64 >> k lanes work on it; the
-// narrow late stages cost little next to stage 0 and in exchange there is no multi-rate cadence
-// and no alignment rule beyond the 2^K input group.  Semi-lengths 3 and 5 (what liquid designs
-// for every stage but the last at 60 dB) are compiled in; anything else stays on k_front.
+// the wave's private LDS slice.  Stage 0 (512 samples per tile) uses rows of 4 cf32 (48-byte pitch)
+// and a lane owns 4 consecutive outputs.  Stage k >= 1 sees 512 >> k samples per tile; a wave
+// instruction costs the same with 8 active lanes as with 64, so the late stages are spread over the
+// lanes instead of being run "narrow": 2 outputs per lane in stage 1, 1 output per lane from stage 2
+// on, their inputs in plain linear even / odd arrays (8 bytes a sample: consecutive lanes read
+// consecutive words, no bank conflicts, no padding).  Round 1 ran every stage 4 outputs per lane on
+// 64 >> k lanes: 112 packed FMAs and 344 LDS cycles per tile at K = 4 against 52 and about 200 now.
+// Semi-lengths 3 and 5 (what liquid designs for every stage but the last at 60 dB) are compiled in;
+// anything else stays on k_front.
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -68,6 +72,58 @@ __device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int l
         for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, E[4 * H + i - 2 * q2]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[4 * H + i - 2 * q2 - 1]);
+    }
+}
+
+// ---- stages k >= 1: linear even / odd arrays.  E[hs + i] / O[ho + i] hold samples 2i / 2i+1 of the tile, the hs / ho
+// entries in front the history; G outputs per lane (2 in stage 1, 1 behind it).
+__host__ __device__ constexpr int casc_lin_hs(int m) { return 2 * m; }                 // >= 2m - 1, even
+__host__ __device__ constexpr int casc_lin_ho(int m) { return (m + 1) & ~1; }          // >= m, even
+__host__ __device__ constexpr int casc_lin_g(int k) { return k == 1 ? 2 : 1; }         // outputs per lane
+__host__ __device__ constexpr int casc_lin_lanes(int k) { return (256 >> k) / casc_lin_g(k); }
+
+__device__ __forceinline__ v2f ld2(const char *p) { const float2 v = *(const float2 *)p; return v2f{v.x, v.y}; }
+
+template <int M, int G>
+__device__ __forceinline__ void casc_stage_lin(const char *E, const char *O, int lane, const float *taps_sgpr, v2f y[2])
+{
+    constexpr int HS = casc_lin_hs(M), HO = casc_lin_ho(M);
+    const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
+    if (G == 2) {
+        // outputs 2l, 2l+1: E[HS + 2l - (2M-1) .. HS + 2l + 1] = array entries 2l + 1 .. 2l + 2M + 1 -> 16-byte reads from entry 2l
+        v2f W[2 * M + 2];
+        const char *we = E + lane * 16;
+#pragma unroll
+        for (int r = 0; r <= M; ++r) {
+            const float4 v = ld4(we + r * 16);
+            W[2 * r] = v2f{v.x, v.y}; W[2 * r + 1] = v2f{v.z, v.w};
+        }
+        // W[i] = array entry 2l + i = E index 2l + i - HS; output j = 2l + g uses E[j - q] = W[HS + g - q]
+        const v2f o0 = ld2(O + (HO + 2 * lane - M) * 8), o1 = ld2(O + (HO + 2 * lane + 1 - M) * 8);
+        __builtin_amdgcn_s_setprio(0);
+        y[0] = v2f{0.5f * o0.x, 0.5f * o0.y}; y[1] = v2f{0.5f * o1.x, 0.5f * o1.y};
+#pragma unroll
+        for (int q2 = 0; q2 < M; ++q2) {
+            const v2f tp = hbp[q2];
+            pk_fma_lo_s(y[0], tp, W[HS - 2 * q2]);     pk_fma_lo_s(y[1], tp, W[HS + 1 - 2 * q2]);
+            pk_fma_hi_s(y[0], tp, W[HS - 2 * q2 - 1]); pk_fma_hi_s(y[1], tp, W[HS - 2 * q2]);
+        }
+    } else {
+        // output l: E[l - (2M-1) .. l] = array entries l + 1 .. l + 2M (8-byte reads, consecutive lanes consecutive words)
+        v2f W[2 * M];
+        const char *we = E + (lane + HS - (2 * M - 1)) * 8;
+#pragma unroll
+        for (int i = 0; i < 2 * M; ++i) W[i] = ld2(we + i * 8);
+        const v2f o = ld2(O + (HO + lane - M) * 8);
+        __builtin_amdgcn_s_setprio(0);
+        y[0] = v2f{0.5f * o.x, 0.5f * o.y};
+        // W[i] = E[l - (2M-1) + i]; tap q multiplies E[l - q] = W[2M - 1 - q]
+#pragma unroll
+        for (int q2 = 0; q2 < M; ++q2) {
+            const v2f tp = hbp[q2];
+            pk_fma_lo_s(y[0], tp, W[2 * M - 1 - 2 * q2]);
+            pk_fma_hi_s(y[0], tp, W[2 * M - 2 - 2 * q2]);
+        }
     }
 }
 
@@ -220,38 +276,65 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
 #pragma unroll
         for (int k = 0; k < kCascMaxK; ++k) {
             if (k < K) {
-                const int n_act = 64 >> k;                        // lanes with outputs in this stage
                 const int m = a.m[k];
+                const int g_out = k == 0 ? 4 : casc_lin_g(k);     // outputs per lane of this stage
+                const int n_act = k == 0 ? 64 : casc_lin_lanes(k);
                 v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-                if (lane < n_act) {
-                    if (m == 3) casc_stage<3>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y);
-                    else        casc_stage<5>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y);
+                if (k == 0) {
+                    if (m == 3) casc_stage<3>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
+                    else        casc_stage<5>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
+                } else if (lane < n_act) {
+                    if (k == 1) { if (m == 3) casc_stage_lin<3, 2>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); else casc_stage_lin<5, 2>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); }
+                    else        { if (m == 3) casc_stage_lin<3, 1>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); else casc_stage_lin<5, 1>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); }
                 }
-                // slide this stage's history: its last H rows become rows 0 .. H-1 (one dword per lane)
-                const int Hk = casc_hist_rows(m), rows = 64 >> k;
+                // slide this stage's history to the front of its buffers (one dword per lane)
                 float se = 0.f, so = 0.f;
-                if (lane < 12 * Hk) { se = *(const float *)(w.XE[k] + rows * kRowB + lane * 4); so = *(const float *)(w.XO[k] + rows * kRowB + lane * 4); }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 12 * Hk) { *(float *)(w.XE[k] + lane * 4) = se; *(float *)(w.XO[k] + lane * 4) = so; }
+                if (k == 0) {
+                    const int Hk = casc_hist_rows(m);
+                    if (lane < 12 * Hk) { se = *(const float *)(w.XE[0] + 64 * kRowB + lane * 4); so = *(const float *)(w.XO[0] + 64 * kRowB + lane * 4); }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 12 * Hk) { *(float *)(w.XE[0] + lane * 4) = se; *(float *)(w.XO[0] + lane * 4) = so; }
+                } else {
+                    const int hs = casc_lin_hs(m), ho = casc_lin_ho(m), pk_ = 256 >> k;     // samples per parity and tile
+                    if (lane < 2 * hs) se = *(const float *)(w.XE[k] + pk_ * 8 + lane * 4);
+                    if (lane < 2 * ho) so = *(const float *)(w.XO[k] + pk_ * 8 + lane * 4);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 2 * hs) *(float *)(w.XE[k] + lane * 4) = se;
+                    if (lane < 2 * ho) *(float *)(w.XO[k] + lane * 4) = so;
+                }
                 if (!EDGE) __builtin_amdgcn_s_setprio(1);
                 if (k + 1 < K) {
-                    // outputs 4l .. 4l+3 -> even / odd rows of the next stage
+                    // this stage's outputs -> the even / odd arrays of the next one (output j: even -> E[hs + j/2], odd -> O[ho + j/2])
+                    const int hn = casc_lin_hs(a.m[k + 1]), on = casc_lin_ho(a.m[k + 1]);
                     if (lane < n_act) {
-                        const int Hn = casc_hist_rows(a.m[k + 1]);
-                        const int off = (Hn + (lane >> 1)) * kRowB + (lane & 1) * 16;
-                        *(float4 *)(w.XE[k + 1] + off) = make_float4(y[0].x, y[0].y, y[2].x, y[2].y);
-                        *(float4 *)(w.XO[k + 1] + off) = make_float4(y[1].x, y[1].y, y[3].x, y[3].y);
+                        if (g_out == 4) {
+                            *(float4 *)(w.XE[k + 1] + (hn + 2 * lane) * 8) = make_float4(y[0].x, y[0].y, y[2].x, y[2].y);
+                            *(float4 *)(w.XO[k + 1] + (on + 2 * lane) * 8) = make_float4(y[1].x, y[1].y, y[3].x, y[3].y);
+                        } else if (g_out == 2) {
+                            *(float2 *)(w.XE[k + 1] + (hn + lane) * 8) = make_float2(y[0].x, y[0].y);
+                            *(float2 *)(w.XO[k + 1] + (on + lane) * 8) = make_float2(y[1].x, y[1].y);
+                        } else {
+                            char *dst = (lane & 1) ? w.XO[k + 1] + (on + (lane >> 1)) * 8 : w.XE[k + 1] + (hn + (lane >> 1)) * 8;
+                            *(float2 *)dst = make_float2(y[0].x, y[0].y);
+                        }
                     }
                 } else if (emit && lane < n_act) {
-                    // the last stage's outputs go to memory: 32 contiguous bytes per lane
-                    const int64_t o = ((i0 >> K) + 4 * lane);
-                    if (!EDGE || o + 4 <= a.casc_n_out) {
-                        float4 *dst = (float4 *)(a.casc_out + o);
-                        dst[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
-                        dst[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
-                    } else {
+                    // the last stage's outputs go to memory: g_out contiguous cf32 per lane
+                    const int64_t o = (i0 >> K) + (int64_t)g_out * lane;
+                    if (g_out == 4) {
+                        if (!EDGE || o + 4 <= a.casc_n_out) {
+                            float4 *dst = (float4 *)(a.casc_out + o);
+                            dst[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+                            dst[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (o + i < a.casc_n_out) a.casc_out[o + i] = cf2{y[i].x, y[i].y};
+                            for (int i = 0; i < 4; ++i) if (o + i < a.casc_n_out) a.casc_out[o + i] = cf2{y[i].x, y[i].y};
+                        }
+                    } else if (g_out == 2) {
+                        if (!EDGE || o + 2 <= a.casc_n_out) *(float4 *)(a.casc_out + o) = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+                        else if (o < a.casc_n_out) a.casc_out[o] = cf2{y[0].x, y[0].y};
+                    } else {
+                        if (!EDGE || o < a.casc_n_out) a.casc_out[o] = cf2{y[0].x, y[0].y};
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -260,10 +343,18 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
     }
 }
 
+// bytes of one stage's two buffers
+__host__ __device__ inline int casc_stage_bytes(int k, int m)
+{
+    if (k == 0) return 2 * (casc_hist_rows(m) + 64 + 1) * kRowB;
+    const int pk_ = 256 >> k;
+    return (((casc_lin_hs(m) + pk_) * 8 + 15) & ~15) + (((casc_lin_ho(m) + pk_) * 8 + 15) & ~15);
+}
+
 size_t cascade_wave_lds(const FrontArgs &a)
 {
     size_t b = 0;
-    for (int k = 0; k < a.casc_K; ++k) b += 2u * (size_t)(casc_hist_rows(a.m[k]) + (64 >> k) + 1) * kRowB;
+    for (int k = 0; k < a.casc_K; ++k) b += (size_t)casc_stage_bytes(k, a.m[k]);
     return b;
 }
 
@@ -283,9 +374,13 @@ __global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
         for (int k = 0; k < kCascMaxK; ++k) {
             w.XE[k] = p; w.XO[k] = p;
             if (k < a.casc_K) {
-                const int rows = casc_hist_rows(a.m[k]) + (64 >> k) + 1;
-                w.XE[k] = p; w.XO[k] = p + rows * kRowB;
-                p += 2 * rows * kRowB;
+                if (k == 0) {
+                    const int rows = casc_hist_rows(a.m[0]) + 64 + 1;
+                    w.XE[0] = p; w.XO[0] = p + rows * kRowB;
+                } else {
+                    w.XE[k] = p; w.XO[k] = p + (((casc_lin_hs(a.m[k]) + (256 >> k)) * 8 + 15) & ~15);
+                }
+                p += casc_stage_bytes(k, a.m[k]);
             }
         }
         for (int i = lane; i < a.casc_wave_lds / 16; i += 64) ((float4 *)p0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -1046,3 +1046,71 @@ def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):
     ch.reset()                                                   # back to the scanning phase: the host mirror follows
     assert not ch.agc_state()["locked"]
     assert np.array_equal(ch.process(raw), want)
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: BASELINE configs[2] / configs[3] at their real sizes (2^27 / 2^29 frames), device-resident:
+# count law, split invariance by checksum, spot parity with the oracle at the head of the stream
+# --------------------------------------------------------------------------------------------
+CONFIG3 = dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True, iq_correct=True,
+               iq_mag=0.01, iq_phase=-0.005, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024)
+CONFIG4 = dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0,
+               filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir")
+
+
+@pytest.mark.parametrize("name,kw,log2_frames,fmt,rate,bpf,head_log2", [
+    ("configs[2]", CONFIG3, 27, "cs16", 10e6, 4, 21),
+    ("configs[3]", CONFIG4, 29, "cu8", 61.44e6, 2, 23),
+])
+def test_full_size_secondary_configs(gpu, oracle, name, kw, log2_frames, fmt, rate, bpf, head_log2):
+    import ctypes as C
+    import hashlib
+    from iq_tool_amd.chain import DeviceBuffer
+    frames = 1 << log2_frames
+    seg = synth.raw_stream(1 << 22, rate, 3, fmt)
+    d_in = DeviceBuffer(frames * bpf)
+    for i in range(frames >> 22):
+        gpu.load().iqgpu_memcpy_h2d(0, C.c_void_p(d_in.ptr + i * seg.nbytes), seg.ctypes.data_as(C.c_void_p), seg.nbytes)
+    ch = gpu.Chain(**kw)
+    obpf = ch.out_bytes
+    cap = ch.max_out_frames(frames) * obpf
+    d_out = DeviceBuffer(cap)
+    n1 = ch.process_device(d_in.ptr, frames, d_out.ptr, cap)
+    ch.synchronize()
+    # count law: resampler law, then the FFT-kind filter's block quantisation (configs[2]); FIR-kind emits all (configs[3])
+    info = ch.info()
+    n_res = -(-((frames >> info.num_halfband_stages) << 24) // info.arb_step)
+    want_n = (n_res // info.filter_block) * info.filter_block if info.filter_block else n_res
+    assert n1 == want_n, (name, n1, want_n)
+    got = C.c_size_t(0)
+    assert gpu.load().iqgpu_design_out_frames(C.byref(ch.desc), frames, C.byref(got)) == 0 and got.value == n1
+    out1 = d_out.download(n1 * obpf)
+    h1 = hashlib.sha256(out1.tobytes()).hexdigest()
+
+    # split invariance: three ragged calls.  Equal to +-1 LSB, not bit for bit: the dc blocker's carries (configs[2]) and
+    # the overlap-save windows of the user filter (both) fall differently on the stream when the calls do
+    ch2 = gpu.Chain(**kw)
+    a, b = frames // 3 + 4321, frames // 2 + 77
+    pos, produced = 0, 0
+    for k in (a, b - a, frames - b):
+        produced += ch2.process_device(d_in.ptr + pos * bpf, k, d_out.ptr + produced * obpf, cap - produced * obpf)
+        pos += k
+    ch2.synchronize()
+    assert produced == n1
+    out2 = d_out.download(n1 * obpf)
+    dt = np.int16 if obpf == 4 else np.uint8
+    d = np.abs(out1.view(dt).astype(np.int64) - out2.view(dt).astype(np.int64))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999, (name, d.max(), (d == 0).mean())
+    # ... and a repeat of the same call pattern IS bit for bit (no atomics or races on the data path)
+    ch3 = gpu.Chain(**kw)
+    n3 = ch3.process_device(d_in.ptr, frames, d_out.ptr, cap)
+    ch3.synchronize()
+    assert n3 == n1 and hashlib.sha256(d_out.download(n1 * obpf).tobytes()).hexdigest() == h1
+
+    # spot parity with the oracle on the head of the very same stream
+    head = 1 << head_log2
+    want = run_oracle(oracle, np.tile(seg.view(np.uint8), max(1, (head * bpf) // seg.nbytes))[:head * bpf], **kw)
+    dt = want.dtype
+    g = out1.view(dt)[:want.size]
+    int_close(g, want, min_same=0.97)
+    d_in.free(); d_out.free()

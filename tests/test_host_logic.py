@@ -301,3 +301,44 @@ def test_design_out_frames_is_the_oracles_count(kw):
         out = pyoracle.Chain(**kw).process(raw.view(np.uint8)[:n * bpf])
         obpf = {"cs16": 2, "cu8": 2, "cf32": 2}[kw["out_format"]]
         assert got.value == out.size // obpf, (n, got.value, out.size // obpf)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
+    dict(input_rate_hz=61.44e6, target_rate_hz=1488375.0, filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
+    dict(input_rate_hz=2.4e6, no_resample=True, filters=(("highpass", 100e3, 0.0), ("stopband", 400e3, 50e3), ("lowpass", 900e3, 0.0))),
+    dict(input_rate_hz=2.4e6, no_resample=True, filters=(("passband", -300e3, 100e3),), transition_width_hz=20e3, attenuation_db=70.0, filter_impl="fft", fft_size=2048),
+    dict(input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("lowpass", 120e3, 0.0),)),                      # auto length, DC normalisation, post placement
+    dict(input_rate_hz=1.0e6, target_rate_hz=2.5e6, filters=(("lowpass", 200e3, 0.0),), filter_taps=256, filter_impl="fft"),   # even -> odd bump, pre placement
+    dict(input_rate_hz=2.4e6, target_rate_hz=1.2e6, filters=(("passband", 0.0, 300e3),)),                        # pass-band centred on 0: real taps, peak normalisation
+    dict(input_rate_hz=2.4e6, target_rate_hz=1.2e6, filters=(("stopband", 100e3, 20e3), ("passband", 250e3, 80e3)), attenuation_db=45.0),
+    dict(input_rate_hz=4.8e3, target_rate_hz=1.2e3, filters=(("lowpass", 3.0, 0.0),), transition_width_hz=0.2),   # transition floor 1 Hz, long filter
+])
+def test_filter_design_against_numpy_restatement(lib, kw):
+    """iqgpu_design_probe (design.cpp) against tests/np_design.py: placement, odd bump, auto length, chain convolution,
+    peak / DC normalisation, implementation choice, block size -- a formulation independent of the C oracle"""
+    import np_design
+    rc, info, ft, _, _ = probe(lib, **kw)
+    assert rc == 0, lib.iqgpu_last_error()
+    d = np_design.design(kw["filters"], kw["input_rate_hz"], kw.get("target_rate_hz", kw["input_rate_hz"]), no_resample=kw.get("no_resample", False),
+                         filter_taps=kw.get("filter_taps", 0), transition_width_hz=kw.get("transition_width_hz", 0.0),
+                         attenuation_db=kw.get("attenuation_db", 0.0), impl=kw.get("filter_impl", "auto"), fft_size=kw.get("fft_size", 0))
+    assert bool(info.filter_post_resample) == d["post"]
+    assert info.filter_ntaps == d["taps"].size
+    assert info.filter_impl == d["impl"] and info.filter_block == d["block"]
+    got = ft[:info.filter_ntaps].astype(np.complex128)
+    scale = np.abs(d["taps"]).max()
+    assert np.abs(got - d["taps"]).max() <= 3e-6 * scale, np.abs(got - d["taps"]).max() / scale
+
+
+def test_filter_design_fatal_paths_against_numpy_restatement(lib):
+    import np_design
+    bad = [dict(input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("lowpass", 400e3, 0.0),)),               # beyond output Nyquist
+           dict(input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("passband", 300e3, 200e3),)),
+           dict(input_rate_hz=2.4e6, no_resample=True, filters=(("lowpass", 100e3, 0.0),), filter_taps=1001, filter_impl="fft", fft_size=512)]
+    for kw in bad:
+        rc, *_ = probe(lib, **kw)
+        assert rc == -7, kw
+        with pytest.raises(ValueError):
+            np_design.design(kw["filters"], kw["input_rate_hz"], kw.get("target_rate_hz", kw["input_rate_hz"]), no_resample=kw.get("no_resample", False),
+                             filter_taps=kw.get("filter_taps", 0), impl=kw.get("filter_impl", "auto"), fft_size=kw.get("fft_size", 0))
