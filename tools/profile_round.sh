@@ -9,11 +9,12 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$REPO/profiles"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-leg"
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-leg --settle-seconds 0"
+TIMED="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg"     # default settle: the sustained clock
 SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES")
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $BENCH --steps 20 --warmup 5 > "$OUT/stats.log" 2>&1
-for cfg in 3 4; do
-  rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg$cfg" -o stats --output-format csv -- $BENCH --config $cfg > "$OUT/stats_cfg$cfg.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $TIMED > "$OUT/stats.log" 2>&1
+for cfg in 3 4 preset; do
+  rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg$cfg" -o stats --output-format csv -- $TIMED --config $cfg > "$OUT/stats_cfg$cfg.log" 2>&1
 done
 for cfg in 2 3 4; do
   for set in "${SETS[@]}"; do
@@ -22,6 +23,8 @@ for cfg in 2 3 4; do
   done
 done
 cd "$REPO"
+f=$(find "$OUT/stats_cfgpreset" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "profiles/${TAG}_kernel_stats_preset.csv"
 for cfg in 2 3 4; do
   sfx=""; [ $cfg != 2 ] && sfx="_config$cfg"
   d="$OUT/stats"; [ $cfg != 2 ] && d="$OUT/stats_cfg$cfg"
