@@ -40,11 +40,11 @@ OTHER = {
     3: dict(chain=dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
                        iq_correct=True, iq_mag=0.01, iq_phase=-0.005, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
             log2_frames=27, rate=10e6, fmt="cs16", bps=4,
-            workload="BASELINE configs[2]: cs16 10 MS/s -> 2.4 MS/s, dc block + iq correct, 2 half-bands, 1025-tap complex band-pass (FFT kind, block 2048), cs16 out"),
+            workload="BASELINE configs[2]: cs16 10 MS/s -> 2.4 MS/s, dc block + iq correct, 2 half-bands, 1025-tap complex band-pass (FFT kind: fftfilt block 2048 output counts; executed as 4096-point overlap-save in LDS), cs16 out"),
     4: dict(chain=dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0,
                        filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
             log2_frames=29, rate=61.44e6, fmt="cu8", bps=2,
-            workload="BASELINE configs[3]: cu8 61.44 MS/s -> 1.488375 MS/s, 5 half-bands, 4097-tap real FIR (time domain), cu8 out"),
+            workload="BASELINE configs[3]: cu8 61.44 MS/s -> 1.488375 MS/s, 5 half-bands, 4097-tap real FIR-kind low-pass behind the resampler (the same linear convolution as the time-domain form, executed as 8192-point overlap-save in LDS; the direct-form k_fir takes 6.9 ms for it), cu8 out"),
 }
 BLOCK_SAMPLES = 0               # auto: one contiguous run of tiles per resident wavefront
 SEGMENT_LOG2 = 22              # synthetic segment generated on the host, tiled on the device
