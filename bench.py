@@ -284,6 +284,8 @@ def main():
     lib = iq_tool_amd.load()                          # raises when libiqgpu.so is missing
     if lib.iqgpu_device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1":
+        local_rank %= lib.iqgpu_device_count()        # plumbing check on a box with fewer GPUs than ranks (never a scaling number)
     if local_rank >= lib.iqgpu_device_count():
         raise SystemExit("rank %d has no GPU: %d devices visible" % (local_rank, lib.iqgpu_device_count()))
     torch.cuda.set_device(local_rank)
@@ -364,7 +366,8 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(seg_frames)), args.log2_frames),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES,
-                       "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"},
+                       "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"
+                                   + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.log2_frames) if args.config == 2 else None,
                          "kernel": "k_front_s1<4, true>" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
