@@ -254,9 +254,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     double agc_m0 = 0.0, agc_m1 = 0.0;
     int64_t agc_c = 0, agc_B = 0;
     bool agc_any = false;
+    constexpr int AS = S0 ? 0 : 1;                 // polyphase-input sample q of the call needs input frames up to ((q + 1) << AS) - rem0 - 1
     if (AGC) {
         agc_g = a.agc_state->gain;
-        const int64_t F0 = (int64_t)TILE * t_emit0 + 1 - a.rem0;
+        const int64_t F0 = (int64_t)TILE * t_emit0 + ((1 << AS) - 1) - a.rem0;
         agc_c = F0 > 0 ? F0 / a.agc_chunk_frames : 0;
         agc_B = (agc_c + 1) * a.agc_chunk_frames;
     }
@@ -494,14 +495,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 uint32_t pk[4] = {0, 0, 0, 0};
                 uint32_t agc_qb = 256u;                           // half-band samples of this tile below it are in chunk agc_c
                 if (AGC) {
-                    const int64_t F0 = (int64_t)TILE * t + 1 - a.rem0;      // last input frame that half-band sample 0 of the tile needs
+                    const int64_t F0 = (int64_t)TILE * t + ((1 << AS) - 1) - a.rem0;   // last input frame that polyphase-input sample 0 of the tile needs
                     if (F0 >= agc_B) {                                      // the boundary fell between two tiles
                         const double m = wave_max_d(agc_m0);
                         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
                         agc_m0 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
                     }
                     const int64_t d = agc_B - F0;
-                    if (d < 2 * 256) agc_qb = (uint32_t)((d + 1) >> 1);
+                    if (d < (256 << AS)) agc_qb = (uint32_t)((d + AS) >> AS);
                     agc_any = true;
                 }
 #pragma unroll
@@ -590,12 +591,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      S0: no half-band stage at all (0.5 <= r < 1, e.g. the cu8-nrsc5 preset 2.4 MS/s -> 1.488375 MS/s):
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 //      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
+//      AGC: output AGC fused (gain before the pack, exact per-chunk peaks); those of the run-time-switched kernels run 12 waves
 template <int BPS, bool FAST, bool S0 = false, bool AGC = false>
-__global__ __launch_bounds__((FAST || BPS == 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
+__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
 {
     if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int kThr = (FAST || BPS == 2) ? kS1Threads : kWThreads, kWv = (FAST || BPS == 2) ? kS1Waves : kWaves;
+    constexpr bool k16 = FAST || (BPS == 2 && !AGC);
+    constexpr int kThr = k16 ? kS1Threads : kWThreads, kWv = k16 ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf2   *s_nco = (cf2 *)smem;
@@ -657,8 +660,14 @@ static bool front_s1_fast_shape(const FrontArgs &a)
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
            !a.dc_enable && a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
 }
-// the fused AGC exists for the specialised instantiation (the shipped cs16 NRSC-5 presets); chunks at least a tile long
-bool front_s1_agc_fusable(const FrontArgs &a) { return front_s1_fast_shape(a) && a.agc_chunk_frames >= kWTile && !getenv("IQGPU_AGC_NOFUSE"); }
+// the fused AGC exists for the 8- and 16-bit-input instantiations, with or without the half-band stage (the shipped
+// NRSC-5 presets: cs16 / cu8 in, cs16 or cu8 out, shift or none); chunks at least a tile long (one boundary per tile)
+bool front_s1_agc_fusable(const FrontArgs &a)
+{
+    const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8;
+    const bool in16 = a.in_fmt == IQGPU_FMT_CS16 || a.in_fmt == IQGPU_FMT_CU16 || a.in_fmt == IQGPU_FMT_SC16Q11;
+    return (a.S == 0 || a.S == 1) && (in8 || in16) && a.agc_chunk_frames >= kWTile && !getenv("IQGPU_AGC_NOFUSE");
+}
 
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
@@ -666,7 +675,7 @@ static bool front_s1_sixteen(const FrontArgs &a)
     // 4 waves per SIMD where the instantiation fits 128 VGPRs (nearly) without scratch: the specialised one,
     // and the 8-bit-input ones (2 - 4 spilled dwords; measured -8 % on the cu8-nrsc5 shape, -4 % on cu8 -> cs16).
     // The cs16 / cf32-input run-time-switched ones spill 7 - 21 dwords there and are faster with 12 waves.
-    return front_s1_fast_shape(a) || a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8;
+    return front_s1_fast_shape(a) || ((a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8) && !a.agc_fused);
 }
 int front_s1_waves(const FrontArgs &a) { return front_s1_sixteen(a) ? kS1Waves : kWaves; }
 
@@ -692,14 +701,19 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC>), dim3(grid), dim3(waves * 64), lds, s, a);                \
     } while (0)
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0) IQGPU_LAUNCH_S1X(BPS, FAST, S0, false)
+    if (a.agc_fused && !(cls == 2 || cls == 4)) return hipErrorInvalidValue;     // (front_s1_agc_fusable)
     if (a.S == 0) {
-        if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
+        if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, true, true);
+        else if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
+        else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, true, true);
         else if (cls == 4) IQGPU_LAUNCH_S1(4, false, true);
         else if (cls == 8) IQGPU_LAUNCH_S1(8, false, true);
         else IQGPU_LAUNCH_S1(0, false, true);
     }
+    else if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, false, true);
     else if (cls == 2) IQGPU_LAUNCH_S1(2, false, false);
     else if (cls == 4 && fast && a.agc_fused) IQGPU_LAUNCH_S1X(4, true, false, true);
+    else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);
     else if (cls == 8) IQGPU_LAUNCH_S1(8, false, false);

@@ -451,8 +451,8 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             fa.S = c->S; fa.in_fmt = c->desc.in_format; fa.out_fmt = c->desc.out_format; fa.gain = c->desc.gain;
             fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
             fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk;
-            c->agc_fusable = c->decim && !c->late && !c->cascade && !c->force_generic && !c->fp.enabled && c->S == 1 &&
-                             c->rp.stages[0].m == 10 && front_s1_agc_fusable(fa);
+            c->agc_fusable = c->decim && !c->late && !c->cascade && !c->force_generic && !c->fp.enabled &&
+                             (c->S == 0 || (c->S == 1 && c->rp.stages[0].m == 10)) && front_s1_agc_fusable(fa);
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
         // overlap-save path: every FFT-kind filter, and FIR-kind ones long enough that two transforms
@@ -803,6 +803,7 @@ void Call::plan_geometry()
             for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
             cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);
         }
+        cplan.agc_fused = agc_fused ? 1 : 0;
         cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
         cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
         cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;

@@ -1114,3 +1114,59 @@ def test_full_size_secondary_configs(gpu, oracle, name, kw, log2_frames, fmt, ra
     g = out1.view(dt)[:want.size]
     int_close(g, want, min_same=0.97)
     d_in.free(); d_out.free()
+
+
+def _to_cu8(cs16):
+    return np.clip(np.rint(cs16.astype(np.float64) / 256.0 + 127.5), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", ["cs16_no_shift", "cu8_preset_s0", "cu8_to_cs16", "cs16_s0_cu8_out", "switches", "sc16q11_post_shift"])
+def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, shape):
+    """the shipped presets beyond the specialised shape: no shift (cs16-fm-nrsc5 as it stands), cu8 in / out without a
+    half-band stage (cu8-nrsc5), 8-bit input with one, plus every run-time switch in front of the AGC"""
+    n = int(2.4e6 * 6.5)
+    base = _enveloped_stream(n, 51, [(0.0, 0.45), (4.0, 0.75), (4.3, 0.45)])        # a ratchet burst after the lock: fallback exercised too
+    if shape == "cs16_no_shift":
+        raw, kw = base, dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, agc=True)
+    elif shape == "cu8_preset_s0":
+        raw, kw = _to_cu8(base), dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, agc=True)
+    elif shape == "cu8_to_cs16":
+        raw, kw = _to_cu8(base), dict(in_format="cu8", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=-100e3, agc=True)
+    elif shape == "cs16_s0_cu8_out":
+        raw, kw = base, dict(in_format="cs16", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, shift_hz=200e3, agc=True, agc_target=0.5)
+    elif shape == "switches":
+        raw, kw = base, dict(in_format="cs16", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=50e3, gain=0.7,
+                             dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005, agc=True, agc_chunk_frames=20000)
+    else:
+        raw, kw = (base >> 4).astype(np.int16), dict(in_format="sc16q11", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5,
+                                                     shift_hz=120e3, shift_after_resample=True, agc=True)
+    rb = raw.view(np.uint8)
+    bpf = 2 if kw["in_format"] in ("cu8", "cs8") else 4
+    cuts = [0, 2_000_000, 2_000_000 + 7 * 16384 + 333, n]
+
+    def run(nofuse):
+        if nofuse:
+            monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+        else:
+            monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+        ch = gpu.Chain(**kw)
+        outs = [ch.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:])]
+        return np.concatenate(outs), ch.agc_state()
+
+    fused, st_f = run(False)
+    plain, st_p = run(True)
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+    assert fused.size == plain.size and fused.size > 0
+    if kw.get("dc_block"):
+        # the dc blocker's carries are recomputed per call on both paths: same values; compare with a float tolerance anyway
+        assert np.abs(fused - plain).max() <= 1e-6 * max(1.0, float(np.abs(plain).max()))
+    else:
+        assert np.array_equal(fused, plain), shape
+    assert st_f["locked"] and st_f["samples_seen"] == st_p["samples_seen"]
+    assert st_f["gain"] == st_p["gain"] and st_f["last_strong_peak_time"] == st_p["last_strong_peak_time"]
+    if shape in ("cs16_no_shift", "cu8_preset_s0"):
+        # the oracle with the same calls (the AGC's chunks are counted from the start of every call)
+        och = oracle.Chain(**kw)
+        want = np.concatenate([och.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert want.size == fused.size
+        int_close(fused, want, min_same=0.95)
