@@ -180,46 +180,77 @@ __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
     }
 }
 
-// ---- the fused path (front_wave.hip, k_front_s1<4, true, false, AGC>) ------------------------------------------
-// In the locked phase agc_apply changes the gain only when a chunk ratchets (peak * g > 1) or has been weak for more
-// than the hang time (src/agc.c:165-215); otherwise every chunk is multiplied by the same g.  The front kernel has
-// therefore already multiplied by the g it found in the state and left max |y|^2 per chunk in peak2; this kernel
-// confirms the assumption for every chunk of the call: locked, and every non-empty chunk "healthy" at g (not
-// ratcheting, above the lower threshold -- the one case in which agc.c touches nothing but the strong-peak time).
-// Then the bytes the front kernel wrote are final and the state advances here.  Anything else -- not locked, a
-// ratchet, a weak chunk (whose fate depends on the hang timer) -- sets *verify_flag: the unfused kernels queued
-// behind redo the call from the untouched state.
+// ---- the fused path (front_wave.hip, k_front_s1<.., AGC>) -------------------------------------------------------
+// In the locked phase agc_apply changes the gain only when a chunk ratchets (peak * g > 1) or has been weak (at or
+// below the lower threshold) for more than the hang time since the last healthy chunk (src/agc.c:165-215); otherwise
+// every chunk is multiplied by the same g.  The front kernel has therefore already multiplied by the g it found in the
+// state and left max |y|^2 per chunk in peak2; this kernel confirms the assumption for every chunk of the call:
+// locked, no ratchet, and no weak chunk further than the hang time from the last healthy one (a prefix maximum of the
+// healthy chunks' times, only computed when a weak chunk exists).  Then the bytes the front kernel wrote are final and
+// the state advances here: samples_seen, and the strong-peak time of the last healthy chunk.  Anything else sets
+// *verify_flag: the unfused kernels queued behind redo the call from the untouched state.
 __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
 {
-    __shared__ int s_bad;
-    __shared__ int s_last;
-    if (threadIdx.x == 0) { s_bad = 0; s_last = -1; }
+    __shared__ int s_bad, s_weak, s_last_healthy;
+    __shared__ double s_scan[1024];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, nthr = (int)blockDim.x;
+    if (tid == 0) { s_bad = 0; s_weak = 0; s_last_healthy = -1; }
     __syncthreads();
     const AgcState st = *a.state;
-    int bad = st.locked ? 0 : 1;
-    int last_active = -1;
-    if (!bad) {
-        const float g = st.gain, target = a.target;
-        for (int c = threadIdx.x; c < a.geom.n_chunks; c += (int)blockDim.x) {
+    const float g = st.gain, target = a.target;
+    int32_t *cls = a.chunk_len;                                // scratch: 0 empty, 1 healthy, 2 weak
+    auto t_of = [&](int c) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)agc_out_end(a.geom, (int64_t)c - 1)) / a.rate; };
+    if (!st.locked) {
+        if (tid == 0) s_bad = 1;
+    } else {
+        int bad = 0, weak = 0, last_h = -1;
+        for (int c = tid; c < a.geom.n_chunks; c += nthr) {
             const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
-            if (e <= b) continue;                                  // empty chunks never reach agc_apply
-            const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
-            const float outp = pk * g;
-            if (outp > 1.0f || !(outp > target * kAgcLower)) bad = 1;
-            last_active = c;
+            int k = 0;
+            if (e > b) {                                           // empty chunks never reach agc_apply
+                const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
+                const float outp = pk * g;
+                if (outp > 1.0f) bad = 1;                          // ratchet
+                else if (outp > target * kAgcLower) { k = 1; last_h = c; }
+                else { k = 2; weak = 1; }
+            }
+            cls[c] = k;
+        }
+        if (bad) atomicOr(&s_bad, 1);
+        if (weak) atomicOr(&s_weak, 1);
+        if (last_h >= 0) atomicMax(&s_last_healthy, last_h);
+    }
+    __syncthreads();
+    if (!s_bad && s_weak) {
+        // a weak chunk creeps iff its time is more than the hang time past the last healthy chunk before it
+        if (tid == 0) s_carry = st.last_strong;
+        __syncthreads();
+        for (int base = 0; base < a.geom.n_chunks; base += nthr) {
+            const int c = base + tid;
+            const int k = c < a.geom.n_chunks ? cls[c] : 0;
+            const double tc = k ? t_of(c) : 0.0;
+            s_scan[tid] = k == 1 ? tc : -1.0e300;
+            __syncthreads();
+            for (int off = 1; off < nthr; off <<= 1) {             // inclusive prefix maximum
+                const double o = tid >= off ? s_scan[tid - off] : -1.0e300;
+                __syncthreads();
+                if (o > s_scan[tid]) s_scan[tid] = o;
+                __syncthreads();
+            }
+            const double before = tid > 0 ? fmax(s_carry, s_scan[tid - 1]) : s_carry;
+            if (k == 2 && tc - before > (double)kAgcHangTime) atomicOr(&s_bad, 1);
+            __syncthreads();
+            if (tid == 0) s_carry = fmax(s_carry, s_scan[nthr - 1]);
+            __syncthreads();
         }
     }
-    if (bad) atomicOr(&s_bad, 1);
-    if (last_active >= 0) atomicMax(&s_last, last_active);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         *a.verify_flag = s_bad;
         if (!s_bad) {
             AgcState nx = st;
-            if (s_last >= 0) {                                     // every active chunk was healthy: the last one leaves its time
-                const uint64_t seen_last = st.seen + (uint64_t)agc_out_end(a.geom, (int64_t)s_last - 1);
-                nx.last_strong = a.clock_wall ? a.t_wall : (double)seen_last / a.rate;
-            }
+            if (s_last_healthy >= 0) nx.last_strong = t_of(s_last_healthy);
             nx.seen = st.seen + (uint64_t)a.n_out;
             *a.state = nx;
         }

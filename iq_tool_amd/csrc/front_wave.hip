@@ -254,10 +254,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     double agc_m0 = 0.0, agc_m1 = 0.0;
     int64_t agc_c = 0, agc_B = 0;
     bool agc_any = false;
-    constexpr int AS = S0 ? 0 : 1;                 // polyphase-input sample q of the call needs input frames up to ((q + 1) << AS) - rem0 - 1
+    // polyphase-input sample q of the call needs the chain's input frames up to ((q + 1) << AS) - agc_rem - 1; a tile holds 256 of them
+    const int AS = AGC ? a.agc_shift : 0;
     if (AGC) {
         agc_g = a.agc_state->gain;
-        const int64_t F0 = (int64_t)TILE * t_emit0 + ((1 << AS) - 1) - a.rem0;
+        const int64_t F0 = (((int64_t)256 * t_emit0 + 1) << AS) - 1 - a.agc_rem;
         agc_c = F0 > 0 ? F0 / a.agc_chunk_frames : 0;
         agc_B = (agc_c + 1) * a.agc_chunk_frames;
     }
@@ -495,14 +496,14 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 uint32_t pk[4] = {0, 0, 0, 0};
                 uint32_t agc_qb = 256u;                           // half-band samples of this tile below it are in chunk agc_c
                 if (AGC) {
-                    const int64_t F0 = (int64_t)TILE * t + ((1 << AS) - 1) - a.rem0;   // last input frame that polyphase-input sample 0 of the tile needs
+                    const int64_t F0 = (((int64_t)256 * t + 1) << AS) - 1 - a.agc_rem;   // last input frame that polyphase-input sample 0 of the tile needs
                     if (F0 >= agc_B) {                                      // the boundary fell between two tiles
                         const double m = wave_max_d(agc_m0);
                         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
                         agc_m0 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
                     }
                     const int64_t d = agc_B - F0;
-                    if (d < (256 << AS)) agc_qb = (uint32_t)((d + AS) >> AS);
+                    if (d < ((int64_t)256 << AS)) agc_qb = (uint32_t)((d + ((int64_t)1 << AS) - 1) >> AS);
                     agc_any = true;
                 }
 #pragma unroll
@@ -666,7 +667,9 @@ bool front_s1_agc_fusable(const FrontArgs &a)
 {
     const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8;
     const bool in16 = a.in_fmt == IQGPU_FMT_CS16 || a.in_fmt == IQGPU_FMT_CU16 || a.in_fmt == IQGPU_FMT_SC16Q11;
-    return (a.S == 0 || a.S == 1) && (in8 || in16) && a.agc_chunk_frames >= kWTile && !getenv("IQGPU_AGC_NOFUSE");
+    // (cf32 input: the last stage behind k_cascade, whose chunks are counted in the chain's input frames)
+    const bool mid = a.in_fmt == IQGPU_FMT_CF32 && a.S == 1 && a.agc_shift >= 2;
+    return (a.S == 0 || a.S == 1) && (in8 || in16 || mid) && a.agc_chunk_frames >= ((int64_t)256 << a.agc_shift) && !getenv("IQGPU_AGC_NOFUSE");
 }
 
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
@@ -701,7 +704,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
         hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC>), dim3(grid), dim3(waves * 64), lds, s, a);                \
     } while (0)
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0) IQGPU_LAUNCH_S1X(BPS, FAST, S0, false)
-    if (a.agc_fused && !(cls == 2 || cls == 4)) return hipErrorInvalidValue;     // (front_s1_agc_fusable)
+    if (a.agc_fused && !(cls == 2 || cls == 4 || (cls == 8 && a.S == 1))) return hipErrorInvalidValue;     // (front_s1_agc_fusable)
     if (a.S == 0) {
         if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, true, true);
         else if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
@@ -716,6 +719,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);
+    else if (cls == 8 && a.agc_fused) IQGPU_LAUNCH_S1X(8, false, false, true);
     else if (cls == 8) IQGPU_LAUNCH_S1(8, false, false);
     else IQGPU_LAUNCH_S1(0, false, false);
 #undef IQGPU_LAUNCH_S1

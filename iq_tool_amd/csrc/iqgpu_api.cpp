@@ -450,9 +450,10 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             FrontArgs fa{};
             fa.S = c->S; fa.in_fmt = c->desc.in_format; fa.out_fmt = c->desc.out_format; fa.gain = c->desc.gain;
             fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
-            fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk;
-            c->agc_fusable = c->decim && !c->late && !c->cascade && !c->force_generic && !c->fp.enabled &&
-                             (c->S == 0 || (c->S == 1 && c->rp.stages[0].m == 10)) && front_s1_agc_fusable(fa);
+            fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk; fa.agc_shift = c->S;
+            if (c->cascade) { fa.S = 1; fa.in_fmt = IQGPU_FMT_CF32; }      // k_cascade in front: the last stage sees cf32, one half-band
+            c->agc_fusable = c->decim && !c->late && !c->force_generic && !c->fp.enabled &&
+                             (c->cascade || c->S == 0 || (c->S == 1 && c->rp.stages[0].m == 10)) && front_s1_agc_fusable(fa);
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
         // overlap-save path: every FFT-kind filter, and FIR-kind ones long enough that two transforms
@@ -519,6 +520,7 @@ extern "C" void iqgpu_chain_destroy(iqgpu_chain *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->pipe_ready) for (auto &ps : c->pipe) (void)hipStreamSynchronize(ps.s);
     free_device_state(c);
     delete c;
 }
@@ -961,10 +963,17 @@ int Call::stage_front()
             a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
             a2.out_fmt = a.out_fmt; a2.out = a.out;
             a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
+            a2.agc_fused = agc_fused ? 1 : 0;
             plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 1);
             for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
             a2.sink = c->d_sink;
+            if (agc_fused) {
+                a2.agc_fused = 1; a2.agc_state = c->d_agc_state; a2.agc_peak2 = (unsigned long long *)c->agc_peak.p;
+                a2.agc_chunk_frames = c->agc_chunk; a2.agc_shift = c->S; a2.agc_rem = c->rem;
+                HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
+            }
             { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
+            if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a2); if (rc) return rc; }
             c->hist2_cur ^= 1;
         }
     } else if (fast_s1) {
@@ -973,7 +982,7 @@ int Call::stage_front()
         if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
         if (agc_fused) {
             a.agc_fused = 1; a.agc_state = c->d_agc_state; a.agc_peak2 = (unsigned long long *)c->agc_peak.p;
-            a.agc_chunk_frames = c->agc_chunk;
+            a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
             HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
         }
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a, c->stream)); }
@@ -1424,6 +1433,7 @@ extern "C" int iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st)
     static_assert(sizeof(iqgpu_agc_state) == sizeof(AgcState), "AGC state layout");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));     // batches submitted and not yet collected
     HIP_TRY(hipMemcpy(st, c->d_agc_state, sizeof(AgcState), hipMemcpyDeviceToHost));
     return IQGPU_OK;
 }
@@ -1453,6 +1463,7 @@ extern "C" int iqgpu_chain_synchronize(iqgpu_chain *c)
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));
     return IQGPU_OK;
 }
 extern "C" int iqgpu_chain_set_profiling(iqgpu_chain *c, int enable)

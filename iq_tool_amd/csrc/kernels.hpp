@@ -117,7 +117,10 @@ struct FrontArgs {
     int32_t     agc_fused;
     const struct AgcState *agc_state;
     unsigned long long *agc_peak2;      // [n_chunks], double bits, zeroed before the launch
-    int64_t     agc_chunk_frames;       // >= the tile (at most one chunk boundary per tile)
+    int64_t     agc_chunk_frames;       // >= 256 << agc_shift (at most one chunk boundary per tile)
+    int32_t     agc_shift, agc_rem;     // polyphase-input sample q of the call needs the call's input frames up to
+                                        // ((q + 1) << agc_shift) - agc_rem - 1  (S and rem of the WHOLE chain: behind
+                                        // k_cascade the kernel itself sees a one-stage chain on the intermediate stream)
     const int32_t *run_if;              // not NULL: the launch does nothing unless *run_if != 0 (fallback launches)
     void       *sink;         // 64 KiB diagnostic scratch (per-phase cycle counters of -DIQGPU_STAMPS builds)
     // k_cascade (cascade_wave.hip): the first casc_K stages of an S >= 2 chain, cf32 out

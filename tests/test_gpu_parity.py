@@ -1120,7 +1120,8 @@ def _to_cu8(cs16):
     return np.clip(np.rint(cs16.astype(np.float64) / 256.0 + 127.5), 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("shape", ["cs16_no_shift", "cu8_preset_s0", "cu8_to_cs16", "cs16_s0_cu8_out", "switches", "sc16q11_post_shift"])
+@pytest.mark.parametrize("shape", ["cs16_no_shift", "cu8_preset_s0", "cu8_to_cs16", "cs16_s0_cu8_out", "switches", "sc16q11_post_shift",
+                                   "am_preset_s5", "cascade_s3_shift"])
 def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, shape):
     """the shipped presets beyond the specialised shape: no shift (cs16-fm-nrsc5 as it stands), cu8 in / out without a
     half-band stage (cu8-nrsc5), 8-bit input with one, plus every run-time switch in front of the AGC"""
@@ -1137,6 +1138,10 @@ def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, sh
     elif shape == "switches":
         raw, kw = base, dict(in_format="cs16", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=50e3, gain=0.7,
                              dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005, agc=True, agc_chunk_frames=20000)
+    elif shape == "am_preset_s5":                    # cs16-am-nrsc5 (iq_tool_presets.conf:240-246): 5 half-bands, k_cascade in front
+        raw, kw = base, dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=46511.71875, agc=True)
+    elif shape == "cascade_s3_shift":
+        raw, kw = base, dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=186046.875, shift_hz=-30e3, agc=True)
     else:
         raw, kw = (base >> 4).astype(np.int16), dict(in_format="sc16q11", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5,
                                                      shift_hz=120e3, shift_after_resample=True, agc=True)
@@ -1164,7 +1169,7 @@ def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, sh
         assert np.array_equal(fused, plain), shape
     assert st_f["locked"] and st_f["samples_seen"] == st_p["samples_seen"]
     assert st_f["gain"] == st_p["gain"] and st_f["last_strong_peak_time"] == st_p["last_strong_peak_time"]
-    if shape in ("cs16_no_shift", "cu8_preset_s0"):
+    if shape in ("cs16_no_shift", "cu8_preset_s0", "am_preset_s5"):
         # the oracle with the same calls (the AGC's chunks are counted from the start of every call)
         och = oracle.Chain(**kw)
         want = np.concatenate([och.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:])])
