@@ -189,40 +189,45 @@ __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
 // healthy chunks' times, only computed when a weak chunk exists).  Then the bytes the front kernel wrote are final and
 // the state advances here: samples_seen, and the strong-peak time of the last healthy chunk.  Anything else sets
 // *verify_flag: the unfused kernels queued behind redo the call from the untouched state.
+// verify_flag[0] = the verdict (the fallback launches' run_if); [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk
+// (reset by k_agc_verify for the next call; zero / -1 at create)
+__global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const AgcState st = *a.state;
+    int bad = 0, weak = 0, last_h = -1;
+    if (st.locked && c < a.geom.n_chunks) {
+        const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+        int k = 0;
+        if (e > b) {                                               // empty chunks never reach agc_apply
+            const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
+            const float outp = pk * st.gain;
+            if (outp > 1.0f) bad = 1;                              // ratchet
+            else if (outp > a.target * kAgcLower) { k = 1; last_h = c; }
+            else { k = 2; weak = 1; }
+        }
+        a.chunk_len[c] = k;                                        // scratch: 0 empty, 1 healthy, 2 weak
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 1, 1);
+    if (__ballot(weak) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 2, 1);
+#pragma unroll
+    for (int k2 = 32; k2 >= 1; k2 >>= 1) { const int o = __shfl_xor(last_h, k2); last_h = o > last_h ? o : last_h; }
+    if ((threadIdx.x & 63) == 0 && last_h >= 0) atomicMax(a.verify_flag + 3, last_h);
+}
+
 __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
 {
-    __shared__ int s_bad, s_weak, s_last_healthy;
+    __shared__ int s_bad;
     __shared__ double s_scan[1024];
     __shared__ double s_carry;
     const int tid = threadIdx.x, nthr = (int)blockDim.x;
-    if (tid == 0) { s_bad = 0; s_weak = 0; s_last_healthy = -1; }
-    __syncthreads();
     const AgcState st = *a.state;
-    const float g = st.gain, target = a.target;
-    int32_t *cls = a.chunk_len;                                // scratch: 0 empty, 1 healthy, 2 weak
+    const int32_t *cls = a.chunk_len;
     auto t_of = [&](int c) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)agc_out_end(a.geom, (int64_t)c - 1)) / a.rate; };
-    if (!st.locked) {
-        if (tid == 0) s_bad = 1;
-    } else {
-        int bad = 0, weak = 0, last_h = -1;
-        for (int c = tid; c < a.geom.n_chunks; c += nthr) {
-            const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
-            int k = 0;
-            if (e > b) {                                           // empty chunks never reach agc_apply
-                const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
-                const float outp = pk * g;
-                if (outp > 1.0f) bad = 1;                          // ratchet
-                else if (outp > target * kAgcLower) { k = 1; last_h = c; }
-                else { k = 2; weak = 1; }
-            }
-            cls[c] = k;
-        }
-        if (bad) atomicOr(&s_bad, 1);
-        if (weak) atomicOr(&s_weak, 1);
-        if (last_h >= 0) atomicMax(&s_last_healthy, last_h);
-    }
+    const int any_bad = a.verify_flag[1], any_weak = a.verify_flag[2], last_healthy = a.verify_flag[3];
+    if (tid == 0) s_bad = (!st.locked || any_bad) ? 1 : 0;
     __syncthreads();
-    if (!s_bad && s_weak) {
+    if (!s_bad && any_weak) {
         // a weak chunk creeps iff its time is more than the hang time past the last healthy chunk before it
         if (tid == 0) s_carry = st.last_strong;
         __syncthreads();
@@ -247,10 +252,11 @@ __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
     }
     __syncthreads();
     if (tid == 0) {
-        *a.verify_flag = s_bad;
+        a.verify_flag[0] = s_bad;
+        a.verify_flag[1] = 0; a.verify_flag[2] = 0; a.verify_flag[3] = -1;      // ready for the next call
         if (!s_bad) {
             AgcState nx = st;
-            if (s_last_healthy >= 0) nx.last_strong = t_of(s_last_healthy);
+            if (last_healthy >= 0) nx.last_strong = t_of(last_healthy);
             nx.seen = st.seen + (uint64_t)a.n_out;
             *a.state = nx;
         }
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
 
 hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s)
 {
+    if (a.geom.n_chunks > 0) hipLaunchKernelGGL(k_agc_classify, dim3((unsigned)((a.geom.n_chunks + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_agc_verify, dim3(1), dim3(1024), 0, s, a);
     return hipGetLastError();
 }

@@ -444,8 +444,11 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             CREATE_TRY(hipMalloc((void **)&c->d_agc_state, sizeof(AgcState)));
             c->agc_init = AgcState{0, 0.05f, 1.0f, 0, c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0, 0};
             CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
-            CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(int32_t)));
-            CREATE_TRY(hipMemset(c->d_agc_flag, 0, sizeof(int32_t)));
+            {   // [0] verdict of the verifier, [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk (agc.hip)
+                const int32_t init[4] = {0, 0, 0, -1};
+                CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(init)));
+                CREATE_TRY(hipMemcpy(c->d_agc_flag, init, sizeof(init), hipMemcpyHostToDevice));
+            }
             // the fused path exists for the specialised front kernel: the shipped cs16 NRSC-5 preset shape
             FrontArgs fa{};
             fa.S = c->S; fa.in_fmt = c->desc.in_format; fa.out_fmt = c->desc.out_format; fa.gain = c->desc.gain;
@@ -1279,6 +1282,11 @@ extern "C" int iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t fr
 // streams and returns at once; collect() waits for that batch's output.  Batches on different slots overlap
 // (the H2D copy of ticket n+1 runs under the kernels and the D2H copy of ticket n); the kernels of
 // consecutive tickets are chained by an event because the stream state lives on the device.
+// Measured alternatives (round 2, tools/hostcall_bench.c, us per batch at 2^14 / 2^18 / 2^20 / 2^24 frames): this
+// layout 33 / 33 / 77 / 1315; all kernels on the chain's stream with one H2D and one D2H stream 26 / 42 / 101 / 1212;
+// all kernels on the chain's stream with per-slot copy streams 39 / 45 / 81 / 1313.  A wait on an event that has not
+// fired yet costs the waiting stream ~20 us on this runtime whichever stream it sits on; the layout kept is the best
+// at the 2^18-frame batches the reference-side stub submits (16 reader chunks).
 static int pipe_init(iqgpu_chain *c)
 {
     if (c->pipe_ready) return IQGPU_OK;
