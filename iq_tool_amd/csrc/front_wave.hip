@@ -146,20 +146,29 @@ __device__ __forceinline__ void tap_rows(const WaveLds &w, uint32_t Pl, uint32_t
 // register while its read is in flight (tools/check_isa.py).  The four slots are gathered as two such
 // pairs with the first pair's 28 FMAs in between: 28 tap registers live instead of 56, which is what
 // lets the kernel run 4 waves per SIMD (128 VGPRs) without scratch spills.
-__device__ __forceinline__ void gather_taps2(unsigned row_a, unsigned row_b, v2f ta[7], v2f tb[7])
+// Only lanes whose slot holds an output read (EXEC = the slot's hit mask for its seven reads): the rows
+// are as good as random, so the reads are bank-conflict bound and every idle lane taken out of the
+// access shortens it (for a step of 1.61 some 38 % of the slots are empty).  The registers of a masked
+// lane keep stale values; its products are dropped by the same hit test further down.
+__device__ __forceinline__ void gather_taps2(unsigned row_a, unsigned row_b, uint64_t hit_a, uint64_t hit_b, v2f ta[7], v2f tb[7])
 {
+    uint64_t ex;
     asm volatile(
-        "ds_read_b64 %0, %14\n\tds_read_b64 %1, %14 offset:8\n\tds_read_b64 %2, %14 offset:16\n\t"
-        "ds_read_b64 %3, %14 offset:24\n\tds_read_b64 %4, %14 offset:32\n\tds_read_b64 %5, %14 offset:40\n\t"
-        "ds_read_b64 %6, %14 offset:48\n\t"
-        "ds_read_b64 %7, %15\n\tds_read_b64 %8, %15 offset:8\n\tds_read_b64 %9, %15 offset:16\n\t"
-        "ds_read_b64 %10, %15 offset:24\n\tds_read_b64 %11, %15 offset:32\n\tds_read_b64 %12, %15 offset:40\n\t"
-        "ds_read_b64 %13, %15 offset:48\n\t"
+        "s_mov_b64 %[ex], exec\n\t"
+        "s_and_b64 exec, %[ex], %[ha]\n\t"
+        "ds_read_b64 %0, %[ra]\n\tds_read_b64 %1, %[ra] offset:8\n\tds_read_b64 %2, %[ra] offset:16\n\t"
+        "ds_read_b64 %3, %[ra] offset:24\n\tds_read_b64 %4, %[ra] offset:32\n\tds_read_b64 %5, %[ra] offset:40\n\t"
+        "ds_read_b64 %6, %[ra] offset:48\n\t"
+        "s_and_b64 exec, %[ex], %[hb]\n\t"
+        "ds_read_b64 %7, %[rb]\n\tds_read_b64 %8, %[rb] offset:8\n\tds_read_b64 %9, %[rb] offset:16\n\t"
+        "ds_read_b64 %10, %[rb] offset:24\n\tds_read_b64 %11, %[rb] offset:32\n\tds_read_b64 %12, %[rb] offset:40\n\t"
+        "ds_read_b64 %13, %[rb] offset:48\n\t"
+        "s_mov_b64 exec, %[ex]\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]),
-          "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6])
-        : "v"(row_a), "v"(row_b)
-        : "memory");
+          "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), [ex] "=&s"(ex)
+        : [ra] "v"(row_a), [rb] "v"(row_b), [ha] "s"(hit_a), [hb] "s"(hit_b)
+        : "memory", "scc");
 }
 
 // Tiles [t_begin, t_emit1) of kWTile frames; those from t_emit0 on produce output.
@@ -421,14 +430,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                           v2f{0.5f * o1.x, 0.5f * o1.y}, v2f{0.5f * o1.z, 0.5f * o1.w}};
             if (!EDGE) __builtin_amdgcn_s_setprio(0);
             const v2f *hbp = (const v2f *)a.hb0;          // 10 SGPR pairs {h[2i], h[2i+1]}
-#pragma unroll
-            for (int q2 = 0; q2 < 10; ++q2) {
-                const v2f tp = hbp[q2];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk_fma_lo_s(acc[r], tp, E[20 + r - 2 * q2]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk_fma_hi_s(acc[r], tp, E[19 + r - 2 * q2]);
-            }
+            // acc[r] += h[2 q2] E[20 + r - 2 q2] + h[2 q2 + 1] E[19 + r - 2 q2], q2 = 0 .. 9
+            pk_fma_hb40(acc, hbp, E + 11);
+            pk_fma_hb40(acc, hbp + 5, E + 1);
             // The half-band output rows live ON TOP of the odd-stream rows (HB row h = XO row h + 5): every read of
             // the odd stream for this tile has been issued above, so its data rows are dead.  The 4 history rows of
             // the half-band output (the previous tile's last rows, kept in sl_hist) are put back first: they share
@@ -475,15 +479,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     v2f ta[7], tb[7];
-                    gather_taps2(row[2 * half], row[2 * half + 1], ta, tb);
+                    gather_taps2(row[2 * half], row[2 * half + 1], __builtin_amdgcn_ballot_w64(hit[2 * half]),
+                                 __builtin_amdgcn_ballot_w64(hit[2 * half + 1]), ta, tb);
                     STAMP(3);
-#pragma unroll
-                    for (int n2 = 0; n2 < 7; ++n2) {
-                        pk_fma_lo(y[2 * half], ta[n2], H[14 + 2 * half - 2 * n2]);
-                        pk_fma_lo(y[2 * half + 1], tb[n2], H[15 + 2 * half - 2 * n2]);
-                        pk_fma_hi(y[2 * half], ta[n2], H[13 + 2 * half - 2 * n2]);
-                        pk_fma_hi(y[2 * half + 1], tb[n2], H[14 + 2 * half - 2 * n2]);
-                    }
+                    // y[a] += ta[n2].lo H[14 + 2 half - 2 n2] + ta[n2].hi H[13 + 2 half - 2 n2]; y[b] one sample later
+                    pk_fma_pp16(y[2 * half], y[2 * half + 1], ta, tb, H + 7 + 2 * half);
+                    pk_fma_pp12(y[2 * half], y[2 * half + 1], ta + 4, tb + 4, H + 1 + 2 * half);
                 }
                 STAMP(4);
                 // half-band samples of this tile that exist in this call

@@ -102,12 +102,63 @@ __device__ __forceinline__ void pk_fma_hi_s(v2f &acc, v2f t, v2f x)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(t), "v"(x));
 }
 // x * (c + j s) with cs = {c, s}:  t = {-xi s, xi c};  y = {xr c, xr s} + t
+// (one asm statement for the pair: between two dependent single-instruction asm statements the compiler, which cannot
+//  see inside them, puts an s_nop -- 53 of them per tile in round 1's loop)
 __device__ __forceinline__ v2f pk_cmul(v2f x, v2f cs)
 {
-    v2f t, y;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(x), "v"(cs));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y) : "v"(x), "v"(cs), "v"(t));
+    v2f y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "=&v"(y) : "v"(x), "v"(cs));
     return y;
+}
+// Dependent packed FMAs are issued from multi-instruction asm blocks: hipcc pads every boundary between two
+// single-instruction asm statements that depend on each other with an s_nop (it cannot see into the asm to
+// count wait states), which cost 53 nops per tile when every FMA was its own statement.
+// the eight FMAs of one half-band tap pair {h[2q], h[2q+1]} on four accumulators: acc[r] += h[2q] e[r+1] + h[2q+1] e[r]
+#define IQGPU_HB8(T, EA, EB, EC, ED, EE)                                               \
+    "v_pk_fma_f32 %[a0], %[" T "], %[" EB "], %[a0] op_sel_hi:[0,1,1]\n\t"              \
+    "v_pk_fma_f32 %[a1], %[" T "], %[" EC "], %[a1] op_sel_hi:[0,1,1]\n\t"              \
+    "v_pk_fma_f32 %[a2], %[" T "], %[" ED "], %[a2] op_sel_hi:[0,1,1]\n\t"              \
+    "v_pk_fma_f32 %[a3], %[" T "], %[" EE "], %[a3] op_sel_hi:[0,1,1]\n\t"              \
+    "v_pk_fma_f32 %[a0], %[" T "], %[" EA "], %[a0] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 %[a1], %[" T "], %[" EB "], %[a1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 %[a2], %[" T "], %[" EC "], %[a2] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 %[a3], %[" T "], %[" ED "], %[a3] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+// five consecutive tap pairs t[0..4] (SGPR pairs) against the 13 even-stream registers e[0..12]; pair i reads e[8 - 2i .. 12 - 2i]
+__device__ __forceinline__ void pk_fma_hb40(v2f acc[4], const v2f *t, const v2f *e)
+{
+    asm(IQGPU_HB8("t0", "e8", "e9", "e10", "e11", "e12") IQGPU_HB8("t1", "e6", "e7", "e8", "e9", "e10")
+        IQGPU_HB8("t2", "e4", "e5", "e6", "e7", "e8") IQGPU_HB8("t3", "e2", "e3", "e4", "e5", "e6")
+        IQGPU_HB8("t4", "e0", "e1", "e2", "e3", "e4")
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+        : [t0] "s"(t[0]), [t1] "s"(t[1]), [t2] "s"(t[2]), [t3] "s"(t[3]), [t4] "s"(t[4]),
+          [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]), [e4] "v"(e[4]), [e5] "v"(e[5]), [e6] "v"(e[6]),
+          [e7] "v"(e[7]), [e8] "v"(e[8]), [e9] "v"(e[9]), [e10] "v"(e[10]), [e11] "v"(e[11]), [e12] "v"(e[12]));
+}
+// the four FMAs of one polyphase tap pair on two slots: ya += ta.lo h1 + ta.hi h0,  yb += tb.lo h2 + tb.hi h1
+#define IQGPU_PP4(TA, TB, HA, HB_, HC)                                                  \
+    "v_pk_fma_f32 %[ya], %[" TA "], %[" HB_ "], %[ya] op_sel_hi:[0,1,1]\n\t"             \
+    "v_pk_fma_f32 %[yb], %[" TB "], %[" HC "], %[yb] op_sel_hi:[0,1,1]\n\t"              \
+    "v_pk_fma_f32 %[ya], %[" TA "], %[" HA "], %[ya] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 %[yb], %[" TB "], %[" HB_ "], %[yb] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+// tap pairs 0..3 of both slots against g[0..8]; pair i reads g[6 - 2i .. 8 - 2i]
+__device__ __forceinline__ void pk_fma_pp16(v2f &ya, v2f &yb, const v2f *ta, const v2f *tb, const v2f *g)
+{
+    asm(IQGPU_PP4("p0", "q0", "g6", "g7", "g8") IQGPU_PP4("p1", "q1", "g4", "g5", "g6")
+        IQGPU_PP4("p2", "q2", "g2", "g3", "g4") IQGPU_PP4("p3", "q3", "g0", "g1", "g2")
+        : [ya] "+v"(ya), [yb] "+v"(yb)
+        : [p0] "v"(ta[0]), [p1] "v"(ta[1]), [p2] "v"(ta[2]), [p3] "v"(ta[3]),
+          [q0] "v"(tb[0]), [q1] "v"(tb[1]), [q2] "v"(tb[2]), [q3] "v"(tb[3]),
+          [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]),
+          [g7] "v"(g[7]), [g8] "v"(g[8]));
+}
+// tap pairs 0..2 of both slots against g[0..6]; pair i reads g[4 - 2i .. 6 - 2i]
+__device__ __forceinline__ void pk_fma_pp12(v2f &ya, v2f &yb, const v2f *ta, const v2f *tb, const v2f *g)
+{
+    asm(IQGPU_PP4("p0", "q0", "g4", "g5", "g6") IQGPU_PP4("p1", "q1", "g2", "g3", "g4") IQGPU_PP4("p2", "q2", "g0", "g1", "g2")
+        : [ya] "+v"(ya), [yb] "+v"(yb)
+        : [p0] "v"(ta[0]), [p1] "v"(ta[1]), [p2] "v"(ta[2]), [q0] "v"(tb[0]), [q1] "v"(tb[1]), [q2] "v"(tb[2]),
+          [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]));
 }
 __device__ __forceinline__ v2f nco_phasor2(const cf2 *tab, uint32_t theta)
 {

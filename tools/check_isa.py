@@ -55,7 +55,7 @@ def check(lines):
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(l)
-            if "s_endpgm" in l:
+            if l.startswith(".Lfunc_end"):      # not s_endpgm: a kernel may hold early exits before its body
                 cur = None
     if not funcs:
         errors.append("no k_front_s1 instantiation found")
@@ -66,7 +66,7 @@ def check(lines):
             for ins in body:
                 if re.match(r"(global|buffer|flat)_load", ins):
                     errors.append("k_front_s1<%s>: asm VMEM load found: %s" % (bps, ins))
-        gather = [b for b in blocks if b[2] and all(x.startswith("ds_read_b64") or x.startswith("s_waitcnt") for x in b[2])
+        gather = [b for b in blocks if b[2] and all(x.startswith(("ds_read_b64", "s_waitcnt", "s_mov_b64", "s_and_b64")) for x in b[2])
                   and any(x.startswith("ds_read_b64") for x in b[2])]
         if len(gather) % 2 != 0 or not gather:
             errors.append("k_front_s1<%s>: %d tap-gather asm blocks (expected an even, non-zero number)" % (bps, len(gather)))
@@ -75,6 +75,10 @@ def check(lines):
             n_gathers += 1
             if sum(1 for x in g[2] if x.startswith("ds_read_b64")) != 14:
                 errors.append("k_front_s1<%s>: a gather block does not hold 14 reads" % bps)
+            ex = [x for x in g[2] if x.startswith(("s_mov_b64", "s_and_b64"))]   # EXEC = hit mask per slot, restored before the wait
+            if ex and not (re.match(r"s_mov_b64 s\[\d+:\d+\], exec", ex[0]) and re.match(r"s_mov_b64 exec, s\[\d+:\d+\]", ex[-1])
+                           and g[2][-2] == ex[-1]):
+                errors.append("k_front_s1<%s>: a gather block does not save / restore EXEC around its reads" % bps)
             if not g[2][-1].startswith("s_waitcnt lgkmcnt(0)"):
                 errors.append("k_front_s1<%s>: a gather block does not end with s_waitcnt lgkmcnt(0)" % bps)
             if any(x.startswith("s_waitcnt") for x in g[2][:-1]):

@@ -21,7 +21,7 @@ def main():
         lines = open(out).read().split("\n")
     name = "_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0EEEvNS_9FrontArgsE:"
     i0 = next(i for i, l in enumerate(lines) if l.startswith(name))
-    i1 = next(i for i in range(i0, len(lines)) if "s_endpgm" in lines[i])
+    i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith(".Lfunc_end"))
     loops = collections.defaultdict(list)      # header label -> instructions
     cur = None
     for l in lines[i0:i1]:
