@@ -91,7 +91,7 @@ struct DevBuf {
 };
 
 struct iqgpu_chain {
-    static constexpr int kPipeSlots = 4;
+    static constexpr int kPipeSlots = 8;
     iqgpu_chain_desc desc;
     int device = 0;
     float ratio = 1.0f;
@@ -147,15 +147,24 @@ struct iqgpu_chain {
     int ihist = 0;
     float *d_ihb = nullptr;
     DevBuf stage_in, stage_out;
-    // pipelined host entry point (iqgpu_chain_submit / _collect): kPipeSlots batches in flight, each slot with
-    // its own in-order stream (H2D -> kernels -> D2H); kernels of consecutive tickets are chained by events
-    // because the chain's device state (histories, filter buffers, AGC) is carried from call to call
+    // pipelined host entry point (iqgpu_chain_submit / _collect): kPipeSlots batches in flight.  H2D copies, kernels
+    // (the chain's stream) and D2H copies each have their own stream; a batch moves to the next stage inside a later
+    // submit / collect, once the host has seen the previous stage finish (no device-side event waits: see pipe_advance)
     struct PipeSlot {
-        hipStream_t s = nullptr; hipEvent_t kernels_done = nullptr, all_done = nullptr;
+        hipEvent_t in_done = nullptr, k_done = nullptr, all_done = nullptr;
         DevBuf d_in, d_out; uint64_t ticket = 0; bool busy = false;
+        size_t frames_in = 0, n_emit = 0; void *out = nullptr;
+        float iq_mag = 0.0f, iq_phase = 0.0f;          // correction factors as of submit()
     };
     PipeSlot pipe[kPipeSlots];
-    bool pipe_ready = false; uint64_t pipe_seq = 0; hipEvent_t pipe_prev_kernels = nullptr;
+    static constexpr int kCopyStreams = 4;                // small copies rotate over them, large ones keep to the first
+    hipStream_t pipe_h2d[kCopyStreams] = {}, pipe_d2h[kCopyStreams] = {};
+    bool pipe_ready = false;
+    uint64_t pipe_seq = 0;        // tickets handed out
+    uint64_t pipe_launched = 0;   // tickets whose kernels have been queued (<= pipe_seq)
+    uint64_t pipe_copied = 0;     // tickets whose D2H copy has been queued (<= pipe_launched)
+    int pipe_rem = 0; uint64_t pipe_phi = 0, pipe_fpending = 0;   // stream position behind the last ticket (valid while pipe_launched < pipe_seq)
+    bool iq_pinned = false; float iq_pin_mag = 0.0f, iq_pin_phase = 0.0f;   // factors of the batch being launched
     // I/Q optimiser probe: first 1024 pre-processed samples of a call (device -> pinned host), src/pipeline.c:468-476
     // (the optimiser runs on ITS OWN thread beside the stage thread: aux_mu guards the factors and the probe state;
     //  a block in flight or not yet read is never overwritten -- the optimiser takes at most two a second)
@@ -163,7 +172,6 @@ struct iqgpu_chain {
     bool probe_on = false, probe_pending = false, probe_valid = false;
     cf2 *d_probe = nullptr; cf2 *h_probe = nullptr; hipEvent_t probe_done = nullptr;
     cf2 probe_last[1024];
-    bool direct_dirty = false;    // process_device ran on the chain's own stream since the last synchronisation
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     // profiling
@@ -172,6 +180,9 @@ struct iqgpu_chain {
     std::vector<hipEvent_t> event_pool;
     iqgpu_profile prof{};
 };
+
+static int pipe_advance(iqgpu_chain *c, uint64_t upto);   // queues the kernels of every submitted batch up to ticket `upto`
+static int pipe_drain(iqgpu_chain *c, uint64_t upto);     // ... and their D2H copies
 
 // ------------------------------------------------------------------------------------------------
 // library-level
@@ -237,10 +248,12 @@ static void free_device_state(iqgpu_chain *c)
     if (c->probe_done) (void)hipEventDestroy(c->probe_done);
     for (auto &ps : c->pipe) {
         ps.d_in.release(); ps.d_out.release();
-        if (ps.kernels_done) (void)hipEventDestroy(ps.kernels_done);
+        if (ps.in_done) (void)hipEventDestroy(ps.in_done);
+        if (ps.k_done) (void)hipEventDestroy(ps.k_done);
         if (ps.all_done) (void)hipEventDestroy(ps.all_done);
-        if (ps.s) (void)hipStreamDestroy(ps.s);
     }
+    for (hipStream_t st : c->pipe_h2d) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : c->pipe_d2h) if (st) (void)hipStreamDestroy(st);
     for (auto &pe : c->pending_events) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -522,8 +535,10 @@ extern "C" void iqgpu_chain_destroy(iqgpu_chain *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)pipe_advance(c, c->pipe_seq);            // batches submitted and never collected still run to completion
+    (void)pipe_drain(c, c->pipe_seq);
     (void)hipStreamSynchronize(c->stream);
-    if (c->pipe_ready) for (auto &ps : c->pipe) (void)hipStreamSynchronize(ps.s);
+    for (hipStream_t st : c->pipe_d2h) if (st) (void)hipStreamSynchronize(st);
     free_device_state(c);
     delete c;
 }
@@ -605,37 +620,40 @@ struct CallPlan {
     uint64_t fpending_next = 0;
 };
 
-static CallPlan plan_call(const iqgpu_chain *c, size_t frames_in)
+// the stream position a call starts from: what plan_call reads of the chain's host-side state
+struct StreamPos { int rem = 0; uint64_t phi = 0; uint64_t fpending = 0; };
+
+static CallPlan plan_call_at(const iqgpu_chain *c, const StreamPos &at, size_t frames_in)
 {
     CallPlan p;
     if (c->late) {
         p.n_res = (int64_t)frames_in;
         p.n_x = p.n_res;
         if (c->fp.enabled && c->fp.block) { // src/filter.c:503-525
-            const uint64_t total = c->fpending + (uint64_t)p.n_res;
+            const uint64_t total = at.fpending + (uint64_t)p.n_res;
             p.n_x = (int64_t)((total / c->fp.block) * c->fp.block);
             p.fpending_next = total - (uint64_t)p.n_x;
         }
         const uint64_t span = (uint64_t)p.n_x << 24;
         const uint64_t step = c->rp.step;
-        if (span > c->phi) { p.n_arb = (int64_t)((span - c->phi + step - 1) / step); p.phi_next = c->phi + (uint64_t)p.n_arb * step - span; }
-        else { p.n_arb = 0; p.phi_next = c->phi - span; }
+        if (span > at.phi) { p.n_arb = (int64_t)((span - at.phi + step - 1) / step); p.phi_next = at.phi + (uint64_t)p.n_arb * step - span; }
+        else { p.n_arb = 0; p.phi_next = at.phi - span; }
         p.n_emit = p.n_arb << c->ia.S;
         return p;
     }
     if (c->decim) {
-        const uint64_t avail = (uint64_t)c->rem + frames_in;
+        const uint64_t avail = (uint64_t)at.rem + frames_in;
         p.n_groups = (int64_t)(avail >> c->S);
         p.rem_next = (int)(avail & (uint64_t)(c->D - 1));
         const uint64_t span = (uint64_t)p.n_groups << 24;
         const uint64_t step = c->rp.step;
-        if (span > c->phi) { p.n_res = (int64_t)((span - c->phi + step - 1) / step); p.phi_next = c->phi + (uint64_t)p.n_res * step - span; }
-        else { p.n_res = 0; p.phi_next = c->phi - span; }
+        if (span > at.phi) { p.n_res = (int64_t)((span - at.phi + step - 1) / step); p.phi_next = at.phi + (uint64_t)p.n_res * step - span; }
+        else { p.n_res = 0; p.phi_next = at.phi - span; }
     } else {
         p.n_res = (int64_t)frames_in;
     }
     if (c->fp.enabled && c->fp.block) { // src/filter.c:503-525
-        const uint64_t total = c->fpending + (uint64_t)p.n_res;
+        const uint64_t total = at.fpending + (uint64_t)p.n_res;
         p.n_emit = (int64_t)((total / c->fp.block) * c->fp.block);
         p.fpending_next = total - (uint64_t)p.n_emit;
     } else {
@@ -644,9 +662,19 @@ static CallPlan plan_call(const iqgpu_chain *c, size_t frames_in)
     return p;
 }
 
+static CallPlan plan_call(const iqgpu_chain *c, size_t frames_in)
+{
+    StreamPos at; at.rem = c->rem; at.phi = c->phi; at.fpending = c->fpending;
+    return plan_call_at(c, at, frames_in);
+}
+
 extern "C" size_t iqgpu_chain_next_out_frames(const iqgpu_chain *c, size_t frames_in)
 {
     if (!c) return 0;
+    if (c->pipe_launched < c->pipe_seq) {      // behind the batches submitted and not yet launched
+        StreamPos at; at.rem = c->pipe_rem; at.phi = c->pipe_phi; at.fpending = c->pipe_fpending;
+        return (size_t)plan_call_at(c, at, frames_in).n_emit;
+    }
     return (size_t)plan_call(c, frames_in).n_emit;
 }
 
@@ -1113,11 +1141,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
                                           void *d_out, size_t out_capacity_bytes, size_t *frames_out)
 {
     if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
-    if (c->pipe_prev_kernels && frames_in) {      // batches submitted earlier come first
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_prev_kernels, 0));
-    }
-    c->direct_dirty = true;
+    int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc;     // batches submitted earlier come first (same stream)
     return process_device_impl(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out);
 }
 
@@ -1210,7 +1234,8 @@ static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
         k.fin_out = c->abuf.p; k.fin_fmt = IQGPU_FMT_CF32;
     }
     k.plan_geometry();
-    { std::lock_guard<std::mutex> g(c->aux_mu); k.iq_mag = c->iq_mag; k.iq_phase = c->iq_phase; }   // read once per call
+    if (c->iq_pinned) { k.iq_mag = c->iq_pin_mag; k.iq_phase = c->iq_pin_phase; }                  // a pipelined batch: as of its submit()
+    else { std::lock_guard<std::mutex> g(c->aux_mu); k.iq_mag = c->iq_mag; k.iq_phase = c->iq_phase; }   // read once per call
 
     // every buffer the stages need is sized before the first launch, so that an allocation failure leaves the
     // stream state untouched; a failure after that (a launch error) leaves the device state half advanced:
@@ -1259,43 +1284,94 @@ extern "C" int iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t fr
     if (frames_in == 0) return IQGPU_OK;
     if (!raw_in || !out) return fail(IQGPU_EINVAL, "iqgpu_chain_process: NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
+    int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc;     // batches submitted earlier come first
     const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
     const size_t n_emit = (size_t)plan_call(c, frames_in).n_emit;
     if (n_emit * obps > out_capacity_bytes)
         return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
-    int rc = c->stage_in.ensure(frames_in * ibps); if (rc) return rc;
+    rc = c->stage_in.ensure(frames_in * ibps); if (rc) return rc;
     rc = c->stage_out.ensure(n_emit * obps + 16); if (rc) return rc;
-    if (c->pipe_prev_kernels) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_prev_kernels, 0));   // batches submitted earlier come first
     HIP_TRY(hipMemcpyAsync(c->stage_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, c->stream));
     size_t produced = 0;
     rc = process_device_impl(c, c->stage_in.p, frames_in, c->stage_out.p, c->stage_out.cap, &produced);
     if (rc) return rc;
     if (produced) HIP_TRY(hipMemcpyAsync(out, c->stage_out.p, produced * obps, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->direct_dirty = false;
     *frames_out = produced;
     return IQGPU_OK;
 }
 
 // ---- pipelined host entry point ----------------------------------------------------------------------
-// submit() queues  H2D copy -> the chain's kernels -> D2H copy  for one batch on one of kPipeSlots in-order
-// streams and returns at once; collect() waits for that batch's output.  Batches on different slots overlap
-// (the H2D copy of ticket n+1 runs under the kernels and the D2H copy of ticket n); the kernels of
-// consecutive tickets are chained by an event because the stream state lives on the device.
-// Measured alternatives (round 2, tools/hostcall_bench.c, us per batch at 2^14 / 2^18 / 2^20 / 2^24 frames): this
-// layout 33 / 33 / 77 / 1315; all kernels on the chain's stream with one H2D and one D2H stream 26 / 42 / 101 / 1212;
-// all kernels on the chain's stream with per-slot copy streams 39 / 45 / 81 / 1313.  A wait on an event that has not
-// fired yet costs the waiting stream ~20 us on this runtime whichever stream it sits on; the layout kept is the best
-// at the 2^18-frame batches the reference-side stub submits (16 reader chunks).
+// Three stages -- H2D copies, kernels (the chain's stream), D2H copies -- and the HOST moves a batch from one to the
+// next: submit(t) queues copy t, then the kernels of batch t-3 once hipEventSynchronize has seen its copy land, then
+// the D2H copy of batch t-5 once its kernels are done (events that have normally fired before they are asked for).
+// collect(t) pushes batch t through whatever stages it still lacks and waits for its bytes.  Nothing on the device
+// ever waits on another stream and no stream switches between the copy engine and the compute queue.  That is the
+// whole design: on this runtime a stream that waits on an event which has not fired yet -- or runs a copy behind a
+// kernel -- loses ~20 us per hand-over.  Measured (round 2, tools/hostcall_bench.c, us per batch at
+// 2^14 / 2^18 / 2^20 / 2^24 frames): one in-order stream per slot (H2D, kernels, D2H) with the kernels of consecutive
+// tickets chained by events 33 / 33 / 77 / 1315; all kernels on the chain's stream behind one H2D and one D2H stream,
+// chained by events 26 / 42 / 101 / 1212; per-slot copy streams 39 / 45 / 81 / 1313; host-ordered with the D2H copy on
+// the kernels' stream 34 / 42 / 91 / 1197; the front kernel reading the batch straight from pinned host memory (no copy
+// at all) 17 / 34 / 104 / - (tools/zc_probe.py); a shader copy instead of the copy engine 22 / 41 / 132 / -; this layout
+// 22 / 25 / 80 / 1200.  What is left at 2^18 frames is the copy engine itself: rocprofv3 shows the 1 MiB H2D copies back
+// to back at 25 us each (40 GB/s; 56 GB/s from 16 MiB up) whatever stream they are queued on, the kernel at 12 us.
+static constexpr size_t kSmallCopy = (size_t)8 << 20;      // copies up to this size rotate over the copy streams
+
 static int pipe_init(iqgpu_chain *c)
 {
     if (c->pipe_ready) return IQGPU_OK;
+    for (hipStream_t &st : c->pipe_h2d) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (hipStream_t &st : c->pipe_d2h) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto &ps : c->pipe) {
-        HIP_TRY(hipStreamCreateWithFlags(&ps.s, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ps.kernels_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ps.in_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ps.k_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ps.all_done, hipEventDisableTiming));
     }
     c->pipe_ready = true;
+    return IQGPU_OK;
+}
+
+// kernels of every submitted batch up to ticket `upto`, in ticket order, on the chain's stream
+static int pipe_advance(iqgpu_chain *c, uint64_t upto)
+{
+    if (!c->pipe_ready) return IQGPU_OK;
+    while (c->pipe_launched < upto) {
+        iqgpu_chain::PipeSlot &ps = c->pipe[c->pipe_launched % iqgpu_chain::kPipeSlots];
+        HIP_TRY(hipSetDevice(c->device));
+        int rc = IQGPU_OK;
+        if (ps.frames_in) {
+            HIP_TRY(hipEventSynchronize(ps.in_done));
+            size_t produced = 0;
+            c->iq_pinned = true; c->iq_pin_mag = ps.iq_mag; c->iq_pin_phase = ps.iq_phase;
+            rc = process_device_impl(c, ps.d_in.p, ps.frames_in, ps.d_out.p, ps.d_out.cap, &produced);
+            c->iq_pinned = false;
+            if (!rc && produced != ps.n_emit) rc = fail(IQGPU_EHIP, "internal: batch produced %zu frames, planned %zu", produced, ps.n_emit);
+            if (rc) ps.n_emit = 0;                               // nothing of a failed batch is copied back
+        }
+        ++c->pipe_launched;
+        HIP_TRY(hipEventRecord(ps.k_done, c->stream));
+        if (rc) return rc;
+    }
+    return IQGPU_OK;
+}
+
+// D2H copy of every launched batch up to ticket `upto`, on the D2H stream
+static int pipe_drain(iqgpu_chain *c, uint64_t upto)
+{
+    if (!c->pipe_ready) return IQGPU_OK;
+    if (upto > c->pipe_launched) upto = c->pipe_launched;
+    while (c->pipe_copied < upto) {
+        iqgpu_chain::PipeSlot &ps = c->pipe[c->pipe_copied % iqgpu_chain::kPipeSlots];
+        hipStream_t d2h = c->pipe_d2h[ps.n_emit * bytes_per_frame(c->desc.out_format) <= kSmallCopy ? c->pipe_copied % (uint64_t)iqgpu_chain::kCopyStreams : 0];
+        HIP_TRY(hipSetDevice(c->device));
+        if (ps.n_emit) {
+            HIP_TRY(hipEventSynchronize(ps.k_done));
+            HIP_TRY(hipMemcpyAsync(ps.out, ps.d_out.p, ps.n_emit * bytes_per_frame(c->desc.out_format), hipMemcpyDeviceToHost, d2h));
+        }
+        ++c->pipe_copied;
+        HIP_TRY(hipEventRecord(ps.all_done, ps.n_emit ? d2h : c->stream));
+    }
     return IQGPU_OK;
 }
 
@@ -1305,34 +1381,44 @@ extern "C" int iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t fra
     if (!c || !frames_out || !ticket) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: NULL argument");
     *frames_out = 0; *ticket = 0;
     if (frames_in != 0 && (!raw_in || !out)) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: NULL buffer");
+    if (frames_in > ((size_t)1 << 40)) return fail(IQGPU_EINVAL, "frames_in too large");
     HIP_TRY(hipSetDevice(c->device));
     int rc = pipe_init(c); if (rc) return rc;
     iqgpu_chain::PipeSlot &ps = c->pipe[c->pipe_seq % iqgpu_chain::kPipeSlots];
     if (ps.busy) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: %d batches are in flight; collect ticket %llu first",
                              iqgpu_chain::kPipeSlots, (unsigned long long)ps.ticket);
     const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
-    const size_t n_emit = (size_t)plan_call(c, frames_in).n_emit;
-    if (n_emit * obps > out_capacity_bytes)
-        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
-    size_t produced = 0;
+    // this batch's copy first (it needs nothing but the slot), so that the copy stream never idles while the host
+    // queues the previous batch's kernels
     if (frames_in) {
         rc = ps.d_in.ensure(frames_in * ibps); if (rc) return rc;
-        rc = ps.d_out.ensure(n_emit * obps + 16); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ps.d_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, ps.s));
-        if (c->pipe_prev_kernels) HIP_TRY(hipStreamWaitEvent(ps.s, c->pipe_prev_kernels, 0));
-        if (c->direct_dirty) { HIP_TRY(hipStreamSynchronize(c->stream)); c->direct_dirty = false; }   // process_device calls made directly come first
-        hipStream_t keep = c->stream;
-        c->stream = ps.s;
-        rc = process_device_impl(c, ps.d_in.p, frames_in, ps.d_out.p, ps.d_out.cap, &produced);
-        c->stream = keep;
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(ps.kernels_done, ps.s));
-        c->pipe_prev_kernels = ps.kernels_done;
-        if (produced) HIP_TRY(hipMemcpyAsync(out, ps.d_out.p, produced * obps, hipMemcpyDeviceToHost, ps.s));
+        hipStream_t h2d = c->pipe_h2d[frames_in * ibps <= kSmallCopy ? c->pipe_seq % (uint64_t)iqgpu_chain::kCopyStreams : 0];
+        HIP_TRY(hipMemcpyAsync(ps.d_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, h2d));
+        HIP_TRY(hipEventRecord(ps.in_done, h2d));
     }
-    HIP_TRY(hipEventRecord(ps.all_done, ps.s));
+    // ... then the kernels of the batch kLagK tickets back and the D2H copy of the batch kLagD behind that one: far
+    // enough behind for their events to have fired (a 1 MiB copy takes ~40 us from hipMemcpyAsync to a visible event,
+    // a kernel with its event ~25 us)
+    const uint64_t t = c->pipe_seq + 1;
+    constexpr uint64_t kLagK = 3, kLagD = 2;
+    static_assert(kLagK + kLagD < (uint64_t)iqgpu_chain::kPipeSlots, "a batch must leave the pipeline before its slot comes round again");
+    if (t > kLagK) { rc = pipe_advance(c, t - kLagK); if (rc) return rc; }
+    if (t > kLagK + kLagD) { rc = pipe_drain(c, t - kLagK - kLagD); if (rc) return rc; }
+    // the exact output count is a closed form of the stream position behind the tickets already handed out
+    StreamPos at;
+    if (c->pipe_launched == c->pipe_seq) { at.rem = c->rem; at.phi = c->phi; at.fpending = c->fpending; }
+    else { at.rem = c->pipe_rem; at.phi = c->pipe_phi; at.fpending = c->pipe_fpending; }
+    const CallPlan plan = plan_call_at(c, at, frames_in);
+    const size_t n_emit = (size_t)plan.n_emit;
+    if (n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
+    if (frames_in) { c->pipe_rem = plan.rem_next; c->pipe_phi = plan.phi_next; c->pipe_fpending = c->fp.enabled ? plan.fpending_next : at.fpending; }
+    else { c->pipe_rem = at.rem; c->pipe_phi = at.phi; c->pipe_fpending = at.fpending; }
+    if (frames_in) { rc = ps.d_out.ensure(n_emit * obps + 16); if (rc) return rc; }
+    ps.frames_in = frames_in; ps.n_emit = n_emit; ps.out = out;
+    { std::lock_guard<std::mutex> g(c->aux_mu); ps.iq_mag = c->iq_mag; ps.iq_phase = c->iq_phase; }
     ps.ticket = ++c->pipe_seq; ps.busy = true;
-    *ticket = ps.ticket; *frames_out = produced;
+    *ticket = ps.ticket; *frames_out = n_emit;
     return IQGPU_OK;
 }
 
@@ -1343,9 +1429,12 @@ extern "C" int iqgpu_chain_collect(iqgpu_chain *c, uint64_t ticket)
     iqgpu_chain::PipeSlot &ps = c->pipe[(ticket - 1) % iqgpu_chain::kPipeSlots];
     if (!ps.busy || ps.ticket != ticket) return IQGPU_OK;        // collected before
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(ps.all_done));
+    int rc = pipe_advance(c, ticket);
+    if (rc && c->pipe_launched < ticket) return rc;              // an earlier batch failed; this one has not run
+    { const int rc2 = pipe_drain(c, ticket); if (!rc) rc = rc2; }
+    if (c->pipe_copied >= ticket) HIP_TRY(hipEventSynchronize(ps.all_done));
     ps.busy = false;
-    return IQGPU_OK;
+    return rc;
 }
 
 extern "C" int iqgpu_chain_pipeline_depth(void) { return iqgpu_chain::kPipeSlots; }
@@ -1410,7 +1499,7 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
     // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
-    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));   // batches in flight finish first
+    { const int rc = pipe_advance(c, c->pipe_seq); if (rc && !c->poisoned) return rc; }   // batches in flight come first (same stream)
     c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
     c->agc_locked_host = false; c->agc_seen_host = 0;
@@ -1440,8 +1529,8 @@ extern "C" int iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st)
     if (!c->agc) return fail(IQGPU_EINVAL, "the chain has no output AGC");
     static_assert(sizeof(iqgpu_agc_state) == sizeof(AgcState), "AGC state layout");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc; }     // batches submitted and not yet collected
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));     // batches submitted and not yet collected
     HIP_TRY(hipMemcpy(st, c->d_agc_state, sizeof(AgcState), hipMemcpyDeviceToHost));
     return IQGPU_OK;
 }
@@ -1461,6 +1550,7 @@ extern "C" int iqgpu_chain_set_stream(iqgpu_chain *c, void *hip_stream)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return IQGPU_OK;
@@ -1470,8 +1560,9 @@ extern "C" int iqgpu_chain_synchronize(iqgpu_chain *c)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = pipe_advance(c, c->pipe_seq); if (!rc) rc = pipe_drain(c, c->pipe_seq); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->pipe_ready) for (auto &ps : c->pipe) HIP_TRY(hipStreamSynchronize(ps.s));
+    for (hipStream_t st : c->pipe_d2h) if (st) HIP_TRY(hipStreamSynchronize(st));
     return IQGPU_OK;
 }
 extern "C" int iqgpu_chain_set_profiling(iqgpu_chain *c, int enable)
