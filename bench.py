@@ -354,7 +354,7 @@ def main():
         host = {"value": round(world * h_frames / h_dt / 1e6, 2), "unit": "MS/s",
                 "h2d_GBs": round(h_up / h_dt / 1e9, 2), "d2h_GBs": round(h_down / h_dt / 1e9, 2),
                 "frames_per_gpu": h_frames, "batch_frames": 1 << args.host_batch_log2,
-                "path": "pinned host buffers -> iqgpu_chain_submit (H2D, kernels, D2H on %d internal streams) -> iqgpu_chain_collect; h2d/d2h per GPU" % chain._lib.iqgpu_chain_pipeline_depth()}
+                "path": "pinned host buffers -> iqgpu_chain_submit (H2D, kernels, D2H staged by the host, %d batches in flight) -> iqgpu_chain_collect; h2d/d2h per GPU" % chain._lib.iqgpu_chain_pipeline_depth()}
 
     if rank == 0:
         line = {

@@ -174,10 +174,11 @@ int    iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t frames_in,
 int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
                                   void *d_out, size_t out_capacity_bytes, size_t *frames_out);
 /* Pipelined form of iqgpu_chain_process for a stage thread that must not stall on PCIe: submit() queues the
- * H2D copy, the kernels and the D2H copy of one batch on an internal stream and returns at once with the
- * batch's exact *frames_out (a closed form of the stream position) and a ticket; collect() blocks until that
- * batch's output bytes are in `out`.  Up to iqgpu_chain_pipeline_depth() batches may be in flight; copies of one
- * batch overlap the kernels of its neighbours.  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
+ * batch's H2D copy and returns with the batch's exact *frames_out (a closed form of the stream position behind
+ * the batches already submitted) and a ticket; the batch's kernels and its D2H copy are queued by the submit()
+ * calls that follow (three and five batches later) or by collect(), which blocks until the batch's output
+ * bytes are in `out`.  Up to iqgpu_chain_pipeline_depth() batches may be in flight; copies of one batch
+ * overlap the kernels of its neighbours.  The pipeline makes progress inside submit() / collect() only.  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
  * pageable memory works but serialises -- and must stay untouched until the ticket is collected.  Batches are
  * processed in submit order: the stream is continuous across them exactly as across iqgpu_chain_process calls
  * (this is what replaces the reference's chunk hand-off between its three stage threads, src/pipeline.c:436-595). */
