@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kFftMaxThreads) void k_fftconv(const FftConvArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fftconv16: the same overlap-save block for N >= 1024 with radix-16 passes held in registers:
+// k_fftconv16<log2 N>: the same overlap-save block for N >= 1024 with radix-16 passes held in registers:
 // N / 16 threads, one 16-point butterfly per thread per pass, so a 4096-point transform is 3 LDS
 // round trips (+ barriers) instead of 6, and the 15 twiddles of a butterfly are fetched together
 // with its 16 points.  N = 2^a 16^b: the leading factor (2, 4 or 8) runs first as radix-2 / radix-4.
@@ -187,17 +187,76 @@ __device__ __forceinline__ void dft16(cf2 v[16])
     for (int m = 0; m < 4; ++m) dft4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
 }
 
-// in place in ONE buffer: every pass pulls its points into registers, all threads meet, then the
+// In place in ONE buffer: every pass pulls its points into registers, all threads meet, then the
 // autosorted results go back to the same buffer (half the LDS of a ping-pong pair -> twice the
-// workgroups per CU; one more barrier per pass)
-__device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int N, int log2n, int tid, int T)
+// workgroups per CU; one more barrier per pass).  N is a template parameter: with T = N / 16 and the
+// sub-transform size Ns known at compile time, the padded index of point r of a butterfly is
+//   sw(j + r T)    = sw(j)  + r T  + (r T  >> 5)      (T a multiple of 32)
+//   sw(j0 + r Ns)  = sw(j0) + r Ns + (r Ns >> 5)      (Ns a power of two, k < Ns, 16 (j - k) a multiple of 16 Ns)
+// i.e. one base address per pass and constant offsets (the run-time-N version spent more VALU
+// instructions on these indices than on the butterflies: 1250 integer against 770 floating-point).
+// The 15 twiddles of a radix-16 butterfly, W^r with W = exp(-2 pi i k / (16 Ns)): four of them (r = 1, 2, 4, 8) come
+// from the table in global memory -- fetched one pass AHEAD, before the barriers of the pass in front, so that
+// their latency never sits between two passes -- and the other eleven are products of two or three of those
+// (error <= 3 roundings of exactly rounded table values, ~2e-7).  Fetching all fifteen where they are used made
+// the kernel latency-bound: 0.27 ms on config 4 against 0.15 ms with no twiddle loads at all.
+struct Tw4 { cf2 w1, w2, w4, w8; };
+
+template <int N, int Ns>
+__device__ __forceinline__ Tw4 load_tw4(const cf2 *tw, int tid)
 {
-    int Ns = 1;
-    if (log2n & 1) {                                                  // radix-2, Ns = 1: no twiddles
-        const int nb = N >> 1;                                        // 8 butterflies per thread
-        cf2 v0[8], v1[8];
+    Tw4 t{cf2{1.f, 0.f}, cf2{1.f, 0.f}, cf2{1.f, 0.f}, cf2{1.f, 0.f}};
+    if constexpr (Ns > 1 && Ns < N) {
+        constexpr int tstride = N / (Ns * 16);
+        const int kt = (tid & (Ns - 1)) * tstride;
+        t.w1 = tw[kt]; t.w2 = tw[2 * kt]; t.w4 = tw[4 * kt]; t.w8 = tw[8 * kt];
+    }
+    return t;
+}
+
+template <int N, int Ns>
+__device__ __forceinline__ void r16_passes(cf2 *buf, const cf2 *tw, int tid, const Tw4 cur)
+{
+    if constexpr (Ns < N) {
+        constexpr int T = N / 16;
+        const int j = tid, k = j & (Ns - 1);
+        cf2 v[16];
+        const cf2 *src = buf + sw(j);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const int j = tid + i * T; v0[i] = buf[sw(j)]; v1[i] = buf[sw(j + nb)]; }
+        for (int r = 0; r < 16; ++r) v[r] = src[r * T + ((r * T) >> 5)];
+        if (Ns > 1) {
+            const cf2 w3 = cmulf(cur.w1, cur.w2), w5 = cmulf(cur.w4, cur.w1), w6 = cmulf(cur.w4, cur.w2), w7 = cmulf(cur.w4, w3);
+            v[1] = cmulf(v[1], cur.w1); v[2] = cmulf(v[2], cur.w2); v[3] = cmulf(v[3], w3); v[4] = cmulf(v[4], cur.w4);
+            v[5] = cmulf(v[5], w5); v[6] = cmulf(v[6], w6); v[7] = cmulf(v[7], w7); v[8] = cmulf(v[8], cur.w8);
+            v[9] = cmulf(v[9], cmulf(cur.w8, cur.w1)); v[10] = cmulf(v[10], cmulf(cur.w8, cur.w2));
+            v[11] = cmulf(v[11], cmulf(cur.w8, w3)); v[12] = cmulf(v[12], cmulf(cur.w8, cur.w4));
+            v[13] = cmulf(v[13], cmulf(cur.w8, w5)); v[14] = cmulf(v[14], cmulf(cur.w8, w6));
+            v[15] = cmulf(v[15], cmulf(cur.w8, w7));
+        }
+        dft16(v);
+        const Tw4 nxt = load_tw4<N, Ns * 16>(tw, tid);               // issued in front of the barriers
+        cf2 *dst = buf + sw((j - k) * 16 + k);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * Ns + ((r * Ns) >> 5)] = v[(r >> 2) + 4 * (r & 3)];
+        __syncthreads();
+        r16_passes<N, Ns * 16>(buf, tw, tid, nxt);
+    }
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int tid)
+{
+    constexpr int N = 1 << LOG2N, T = N / 16;
+    constexpr int Ns2 = (LOG2N & 1) ? 2 : 1;                          // after the radix-2 pass
+    constexpr int Ns4 = (LOG2N & 2) ? Ns2 * 4 : Ns2;                  // after the radix-4 pass
+    const Tw4 first = load_tw4<N, Ns4>(tw, tid);                      // of the first radix-16 pass: in flight under the passes in front
+    if constexpr ((LOG2N & 1) != 0) {                                 // radix-2, Ns = 1: no twiddles
+        constexpr int nb = N >> 1;                                    // 8 butterflies per thread
+        cf2 v0[8], v1[8];
+        const cf2 *src = buf + sw(tid);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v0[i] = src[i * T + ((i * T) >> 5)]; v1[i] = src[nb + (nb >> 5) + i * T + ((i * T) >> 5)]; }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -206,16 +265,15 @@ __device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int N, int lo
             buf[sw(2 * j + 1)] = cf2{v0[i].x - v1[i].x, v0[i].y - v1[i].y};
         }
         __syncthreads();
-        Ns = 2;
     }
-    if (log2n & 2) {                                                  // radix-4: 4 butterflies per thread
-        const int nb = N >> 2, tstride = N / (Ns * 4);
+    if constexpr ((LOG2N & 2) != 0) {                                 // radix-4: 4 butterflies per thread
+        constexpr int Ns = Ns2, nb = N >> 2, tstride = N / (Ns * 4);
         cf2 v[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = tid + i * T, k = j & (Ns - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i][r] = buf[sw(j + r * nb)];
+            for (int r = 0; r < 4; ++r) v[i][r] = buf[sw(j) + r * nb + ((r * nb) >> 5)];
             if (Ns > 1) {
 #pragma unroll
                 for (int r = 1; r < 4; ++r) v[i][r] = cmulf(v[i][r], tw[k * r * tstride]);
@@ -230,54 +288,44 @@ __device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int N, int lo
             for (int r = 0; r < 4; ++r) buf[sw(j0 + r * Ns)] = v[i][r];
         }
         __syncthreads();
-        Ns *= 4;
     }
-    while (Ns < N) {                                                  // radix-16, one butterfly per thread
-        const int j = tid, k = j & (Ns - 1), tstride = N / (Ns * 16);
-        cf2 v[16], w[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = buf[sw(j + r * T)];
-        if (Ns > 1) {
-#pragma unroll
-            for (int r = 1; r < 16; ++r) w[r] = tw[k * r * tstride];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) v[r] = cmulf(v[r], w[r]);
-        }
-        dft16(v);
-        const int j0 = (j - k) * 16 + k;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) buf[sw(j0 + r * Ns)] = v[(r >> 2) + 4 * (r & 3)];
-        __syncthreads();
-        Ns *= 16;
-    }
+    r16_passes<N, Ns4>(buf, tw, tid, first);
 }
 
-__global__ __launch_bounds__(1024) void k_fftconv16(const FftConvArgs a)
+template <int LOG2N>
+__global__ __launch_bounds__((1 << LOG2N) / 16) void k_fftconv16(const FftConvArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, T = blockDim.x;                     // T = N / 16
-    const int N = 1 << a.log2n, L1 = a.ntaps - 1, V = N - L1;
-    const int NP = N + (N >> 5) + 2;
+    constexpr int N = 1 << LOG2N, T = N / 16;                        // blockDim.x = T
+    const int tid = threadIdx.x;
+    const int L1 = a.ntaps - 1, V = N - L1;
+    constexpr int NP = N + (N >> 5) + 2;
     cf2 *X = (cf2 *)smem;
     cf2 *s_nco = X + NP;
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];
 
     const int64_t o0 = (int64_t)blockIdx.x * V;
-#pragma unroll 4
-    for (int p = tid; p < N; p += T) {
-        const int64_t fi = o0 + p;
-        X[sw(p)] = (fi < a.fbuf_len) ? a.fbuf[fi] : cf2{0.0f, 0.0f};
+    {
+        cf2 *dst = X + sw(tid);
+        const cf2 *srcg = a.fbuf + o0 + tid;
+        const int64_t room = a.fbuf_len - o0 - tid;                  // window samples this thread may read: p = tid + i T < room
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            dst[i * T + ((i * T) >> 5)] = ((int64_t)(i * T) < room) ? srcg[i * T] : cf2{0.0f, 0.0f};
     }
     __syncthreads();
-    fft16_lds(X, a.twiddle, N, a.log2n, tid, T);
-#pragma unroll 4
-    for (int p = tid; p < N; p += T) {
-        const cf2 z = cmulf(X[sw(p)], a.hfreq[p]);
-        X[sw(p)] = cf2{z.x, -z.y};
+    fft16_lds<LOG2N>(X, a.twiddle, tid);
+    {
+        cf2 *px = X + sw(tid);
+        const cf2 *ph = a.hfreq + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const cf2 z = cmulf(px[i * T + ((i * T) >> 5)], ph[i * T]);
+            px[i * T + ((i * T) >> 5)] = cf2{z.x, -z.y};
+        }
     }
     __syncthreads();
-    fft16_lds(X, a.twiddle, N, a.log2n, tid, T);
+    fft16_lds<LOG2N>(X, a.twiddle, tid);
     cf2 *Y = X;
     const int64_t left = a.n_emit - o0;
     const int nv = left < (int64_t)V ? (int)left : V;
@@ -291,6 +339,15 @@ __global__ __launch_bounds__(1024) void k_fftconv16(const FftConvArgs a)
     }
 }
 
+template <int LOG2N>
+static hipError_t launch_fftconv16(const FftConvArgs &a, unsigned nb, size_t lds, hipStream_t s)
+{
+    static LdsAttrCache cache16;
+    if (lds > 64 * 1024) { const hipError_t e = cache16.ensure((const void *)k_fftconv16<LOG2N>, lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k_fftconv16<LOG2N>, dim3(nb), dim3((1 << LOG2N) / 16), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
 {
     if (a.n_emit > 0 && a.log2n >= 10 && !getenv("IQGPU_FFT_NO_R16")) {
@@ -298,10 +355,14 @@ hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
         if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
         const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);
         const size_t lds = (size_t)(N + (N >> 5) + 2) * sizeof(cf2) + (a.pnco_mode != 0 ? 1024 * sizeof(cf2) : 0);
-        static LdsAttrCache cache16;
-        if (lds > 64 * 1024) { const hipError_t e = cache16.ensure((const void *)k_fftconv16, lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k_fftconv16, dim3(nb), dim3(N / 16), lds, s, a);
-        return hipGetLastError();
+        switch (a.log2n) {
+        case 10: return launch_fftconv16<10>(a, nb, lds, s);
+        case 11: return launch_fftconv16<11>(a, nb, lds, s);
+        case 12: return launch_fftconv16<12>(a, nb, lds, s);
+        case 13: return launch_fftconv16<13>(a, nb, lds, s);
+        case 14: return launch_fftconv16<14>(a, nb, lds, s);
+        default: return hipErrorInvalidValue;
+        }
     }
     if (a.n_emit <= 0) return hipSuccess;
     const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
