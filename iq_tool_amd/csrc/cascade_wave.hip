@@ -37,11 +37,12 @@ template <int M>
 __device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int lane, const float *taps_sgpr, v2f y[4])
 {
     constexpr int H = casc_hist_rows(M);
+    constexpr int PS = plane_stride(H + 64 + 1);      // two planes of 16-byte half rows (wave_common.hpp)
     v2f E[4 * (H + 1)];
-    const char *we = XE + lane * kRowB;
+    const char *we = XE + lane * 16;
 #pragma unroll
     for (int r = 0; r <= H; ++r) {
-        const float4 v0 = ld4(we + r * kRowB), v1 = ld4(we + r * kRowB + 16);
+        const float4 v0 = ld4(we + r * 16), v1 = ld4(we + r * 16 + PS);
         E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
         E[4 * r + 2] = v2f{v1.x, v1.y}; E[4 * r + 3] = v2f{v1.z, v1.w};
     }
@@ -50,11 +51,11 @@ __device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int l
     constexpr int r0 = c0 / 4;
     v2f O[8];
     {
-        const char *wo = XO + (lane + r0) * kRowB;
-        const float4 v0 = ld4(wo), v1 = ld4(wo + 16);
+        const char *wo = XO + (lane + r0) * 16;
+        const float4 v0 = ld4(wo), v1 = ld4(wo + PS);
         O[0] = v2f{v0.x, v0.y}; O[1] = v2f{v0.z, v0.w}; O[2] = v2f{v1.x, v1.y}; O[3] = v2f{v1.z, v1.w};
         if ((c0 & 3) != 0) {
-            const float4 u0 = ld4(wo + kRowB), u1 = ld4(wo + kRowB + 16);
+            const float4 u0 = ld4(wo + 16), u1 = ld4(wo + 16 + PS);
             O[4] = v2f{u0.x, u0.y}; O[5] = v2f{u0.z, u0.w}; O[6] = v2f{u1.x, u1.y}; O[7] = v2f{u1.z, u1.w};
         }
     }
@@ -145,7 +146,8 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
     const bool unit_gain = a.gain == 1.0f;
     char *XE0 = w.XE[0], *XO0 = w.XO[0];
     const int H0 = casc_hist_rows(a.m[0]);
-    const int woff = (H0 + (lane >> 1)) * kRowB + (lane & 1) * 16;     // this lane's write slot in stage 0
+    const int PS0 = plane_stride(H0 + 64 + 1);
+    const int woff = (H0 + (lane >> 1)) * 16 + (lane & 1) * PS0;       // this lane's write slot in stage 0 (plane lane & 1)
 
     RawChunk nxt[2];
     const bool nco_on = !EDGE && a.nco_mode != 0;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
         if (!EDGE) __builtin_amdgcn_s_setprio(1);       // feeding the LDS pipe goes ahead of FMA runs (as in k_front_s1)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int off = woff + 32 * c * kRowB;
+            const int off = woff + 32 * c * 16;
             *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
             *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
         }
@@ -290,10 +292,11 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 // slide this stage's history to the front of its buffers (one dword per lane)
                 float se = 0.f, so = 0.f;
                 if (k == 0) {
-                    const int Hk = casc_hist_rows(m);
-                    if (lane < 12 * Hk) { se = *(const float *)(w.XE[0] + 64 * kRowB + lane * 4); so = *(const float *)(w.XO[0] + 64 * kRowB + lane * 4); }
+                    const int Hk = casc_hist_rows(m);                  // Hk rows = 16 Hk bytes in each of the two planes
+                    const int so_ = (lane >= 4 * Hk ? PS0 - 16 * Hk : 0) + lane * 4;
+                    if (lane < 8 * Hk) { se = *(const float *)(w.XE[0] + 64 * 16 + so_); so = *(const float *)(w.XO[0] + 64 * 16 + so_); }
                     __builtin_amdgcn_wave_barrier();
-                    if (lane < 12 * Hk) { *(float *)(w.XE[0] + lane * 4) = se; *(float *)(w.XO[0] + lane * 4) = so; }
+                    if (lane < 8 * Hk) { *(float *)(w.XE[0] + so_) = se; *(float *)(w.XO[0] + so_) = so; }
                 } else {
                     const int hs = casc_lin_hs(m), ho = casc_lin_ho(m), pk_ = 256 >> k;     // samples per parity and tile
                     if (lane < 2 * hs) se = *(const float *)(w.XE[k] + pk_ * 8 + lane * 4);
@@ -346,7 +349,7 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
 // bytes of one stage's two buffers
 __host__ __device__ inline int casc_stage_bytes(int k, int m)
 {
-    if (k == 0) return 2 * (casc_hist_rows(m) + 64 + 1) * kRowB;
+    if (k == 0) return 4 * plane_stride(casc_hist_rows(m) + 64 + 1);
     const int pk_ = 256 >> k;
     return (((casc_lin_hs(m) + pk_) * 8 + 15) & ~15) + (((casc_lin_ho(m) + pk_) * 8 + 15) & ~15);
 }
@@ -359,7 +362,7 @@ size_t cascade_wave_lds(const FrontArgs &a)
 }
 
 template <int BPS>
-__global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
+__global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -375,8 +378,7 @@ __global__ __launch_bounds__(kWThreads) void k_cascade(const FrontArgs a)
             w.XE[k] = p; w.XO[k] = p;
             if (k < a.casc_K) {
                 if (k == 0) {
-                    const int rows = casc_hist_rows(a.m[0]) + 64 + 1;
-                    w.XE[0] = p; w.XO[0] = p + rows * kRowB;
+                    w.XE[0] = p; w.XO[0] = p + 2 * plane_stride(casc_hist_rows(a.m[0]) + 64 + 1);
                 } else {
                     w.XE[k] = p; w.XO[k] = p + (((casc_lin_hs(a.m[k]) + (256 >> k)) * 8 + 15) & ~15);
                 }
@@ -421,13 +423,16 @@ bool cascade_supported(const int *m_run_order, int S)
     return m_run_order[S - 1] == 10;
 }
 
-// wavefronts per workgroup (one workgroup per CU): as many as the LDS slices allow, in whole waves per SIMD,
-// at most 12 (16 was measured on config 3, K = 1: 0.254 ms against 0.232 ms with 12)
+// wavefronts per workgroup (one workgroup per CU): as many as the LDS slices allow, in whole waves per SIMD.
+// A cascade of two or more stages is a chain of LDS round trips per tile and gains from the fourth wave per SIMD
+// (config 4, K = 4: 0.787 ms with 12 waves, 0.699 ms with 16 -- which fit since stage 0's rows became planes);
+// a single stage does not (config 3, K = 1: 0.223 against 0.221 ms) and keeps 12.
 int cascade_waves(const FrontArgs &a)
 {
     int w = (int)((160 * 1024 - 1024 * 8) / (a.casc_wave_lds > 0 ? a.casc_wave_lds : 1));
     w &= ~3;
-    return w > kWaves ? kWaves : (w < 4 ? 4 : w);
+    const int cap = a.casc_K >= 2 ? kCascMaxWaves : kWaves;
+    return w > cap ? cap : (w < 4 ? 4 : w);
 }
 
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)

@@ -21,6 +21,7 @@ constexpr int kArbHist = 16;       // 13 needed, padded
 constexpr int kWTile = 512;        // input samples per wavefront tile (k_front_s1)
 constexpr int kWaves = 12;         // wavefronts per workgroup in k_cascade (3 per SIMD, 1 workgroup per CU)
 constexpr int kWThreads = kWaves * 64;
+constexpr int kCascMaxWaves = 16;  // k_cascade with two or more stages (latency-bound: 4 waves per SIMD when the LDS slices allow)
 #ifndef IQGPU_S1_WAVES
 #define IQGPU_S1_WAVES 16
 #endif

@@ -12,6 +12,18 @@ namespace iqgpu {
 
 constexpr int kRowB = 48;                                   // LDS row: 4 cf32 + 16 B pad (odd number of 16-byte slots)
 
+// k_cascade keeps stage 0's input (rows written by lane PAIRS: lane 2i holds samples 4i, 4i+1 and lane 2i+1
+// samples 4i+2, 4i+3 of a parity stream) as two planes of 16-byte half rows instead: plane h, row r = samples
+// 4r + 2h, 4r + 2h + 1 at byte 16 r of the plane, the planes 64 (mod 128) bytes apart.  A third less LDS than
+// the padded rows (which is what lets a 4-stage cascade run 16 waves per CU) and fewer write conflicts: the
+// four rows an 8-lane write group touches are 64 contiguous bytes in each plane.  A ds_read_b128 of "row
+// lane + c" is 16 contiguous bytes per lane.  (k_front_s1 keeps the padded rows: there the planes measured
+// 4 % slower, SQ_LDS_IDX_ACTIVE 290 -> 310 cycles per tile.)
+__host__ __device__ constexpr int plane_stride(int rows)
+{
+    return (rows * 16 + 63) / 128 * 128 + 64;               // smallest value >= 16 rows that is 64 (mod 128)
+}
+
 struct RawChunk { uint32_t w[8]; };
 
 template <int BPS>
