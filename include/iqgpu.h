@@ -59,7 +59,7 @@ enum {
     IQGPU_EFILTER = -7,     /* filter band beyond output Nyquist, fft size too small, too many stages (src/filter.c:80-84, 321-325) */
     IQGPU_ECAPACITY = -8,   /* out_capacity_bytes too small for this call */
     IQGPU_EHIP = -9,        /* a HIP runtime call failed */
-    IQGPU_EUNSUPPORTED = -10/* valid for the reference but not built: AGC profiles dx / local (liquid agc_crcf), see DESIGN.md */
+    IQGPU_EUNSUPPORTED = -10/* valid for the reference but not built (nothing on the path returns it since round 2) */
 };
 
 typedef struct iqgpu_chain iqgpu_chain; /* opaque, like resampler_t (include/resampler.h:25-26) */
@@ -92,7 +92,7 @@ typedef struct {
     size_t block_samples;               /* input samples per workgroup block, multiple of 2048; 0 = auto (one run per resident wave) */
     /* output AGC, between the post NCO and the pack (src/post_processor.c:55-57, src/agc.c) */
     int    agc_enable;                  /* config->output_agc.enable                                        */
-    int    agc_profile;                 /* IQGPU_AGC_*  (config->output_agc.profile); only DIGITAL is built  */
+    int    agc_profile;                 /* IQGPU_AGC_*  (config->output_agc.profile): DIGITAL, or liquid's agc_crcf as DX / LOCAL */
     float  agc_target;                  /* config->output_agc.target_level_arg (0 = AGC_DIGITAL_PEAK_TARGET) */
     int    agc_clock;                   /* IQGPU_AGC_CLOCK_*: what stands in for get_monotonic_time_sec()    */
     uint32_t agc_chunk_frames;          /* input frames per reference chunk, 0 = 16384 (PIPELINE_CHUNK_BASE_SAMPLES): */
@@ -109,8 +109,8 @@ enum { IQGPU_AGC_CLOCK_SAMPLES = 0, IQGPU_AGC_CLOCK_WALL = 1 };
 /* AppResources' AGC fields (include/app_context.h:227-231) */
 typedef struct {
     int      locked;
-    float    peak_memory;
-    float    current_gain;
+    float    peak_memory;               /* profiles dx / local: agc_crcf's y2_prime (smoothed output energy) */
+    float    current_gain;              /* profiles dx / local: agc_crcf's gain                              */
     int      reserved;
     double   last_strong_peak_time;
     uint64_t samples_seen;

@@ -282,4 +282,94 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// RMS profiles "dx" / "local": liquid's agc_crcf (src/agc.c:39-62, 92-100, 227-229) -- per sample
+//     y = x g;  y2 = |y|^2;  p = (1 - alpha) p + alpha y2  (double, stored as float);
+//     if (p > 1e-6) g *= exp(-0.5 alpha ln p);  g = min(g, 1e6);   out = y
+// a nonlinear recurrence with no closed form across samples.  What makes it parallel is that it FORGETS:
+// linearised around its fixed point the state error decays like (1 - alpha / 2)^n, so a lane that starts
+// `warm` = 40 / alpha samples early from ANY state arrives within 2e-9 of the true one.
+//   k_agc_rms_spec: one LANE per chunk of the call's output.  Chunks that begin within `warm` samples of the
+//       call's start run from the carried state at sample 0 (exact); the others from a guess `warm` samples
+//       ahead of their first output.  Each lane records the state it arrived with and the state it left.
+//   k_agc_rms_fix:  checks, in parallel, that every chunk arrived where its predecessor left (2e-6 relative
+//       in gain and energy); if one did not -- a silent stretch freezes the gain (p <= 1e-6) and with it the
+//       guess -- one lane re-runs the stream from there until the states meet again.  Then stores the
+//       stream state.
+// Unpinned like every liquid operator (DESIGN SPEC): parity with the oracle's restatement (glibc expf / logf) to 2e-5.
+// ---------------------------------------------------------------------------------------------
+struct RmsSt { float g, p; };
+
+__device__ __forceinline__ cf2 rms_step(cf2 v, RmsSt &st, float alpha, float half_alpha_neg)
+{
+    const float yr = v.x * st.g, yi = v.y * st.g;
+    const float y2 = yr * yr + yi * yi;
+    st.p = (float)((1.0 - (double)alpha) * (double)st.p + (double)alpha * (double)y2);
+    // logf / expf rounded the way glibc rounds them (correctly, but for rare near-ties): through double.  It matters:
+    // the update factor is 1 + O(alpha), so its float rounding is percent-level noise on the correction term, and a
+    // libm that rounds differently by 1e-7 per step moves the settled gain by 1e-7 / alpha (1e-3 for dx).
+    if (st.p > 1e-6f) st.g *= (float)exp((double)(half_alpha_neg * (float)log((double)st.p)));
+    st.g = fminf(st.g, 1e6f);
+    return cf2{yr, yi};
+}
+
+__global__ __launch_bounds__(64) void k_agc_rms_spec(const AgcRmsArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    const int64_t s = c * a.chunk, e = (s + a.chunk < a.n) ? s + a.chunk : a.n;
+    const float han = -0.5f * a.alpha;
+    RmsSt st{a.state->gain, a.state->peak_memory};
+    int64_t i = 0;
+    if (s > a.warm) { i = s - a.warm; st.p = 1.0f; }            // a guess: the call's first gain, unit energy
+    for (; i < s; ++i) (void)rms_step(a.x[i], st, a.alpha, han);
+    a.st[4 * c + 0] = st.g; a.st[4 * c + 1] = st.p;
+    for (; i < e; ++i) pack_store(a.out, i, a.out_fmt, rms_step(a.x[i], st, a.alpha, han));
+    a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
+}
+
+__device__ __forceinline__ bool rms_close(float a, float b) { return fabsf(a - b) <= 2e-6f * fmaxf(fabsf(a), fabsf(b)); }
+
+__global__ __launch_bounds__(1024) void k_agc_rms_fix(const AgcRmsArgs a)
+{
+    __shared__ int first_bad;
+    if (threadIdx.x == 0) first_bad = 0x7fffffff;
+    __syncthreads();
+    for (int c = 1 + (int)threadIdx.x; c < a.n_chunks; c += 1024)
+        if (!rms_close(a.st[4 * c], a.st[4 * c - 2]) || !rms_close(a.st[4 * c + 1], a.st[4 * c - 1])) atomicMin(&first_bad, c);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float han = -0.5f * a.alpha;
+    for (int64_t c = first_bad; c < a.n_chunks; ++c) {
+        RmsSt st{a.st[4 * c - 2], a.st[4 * c - 1]};                    // where the stream really is
+        if (rms_close(a.st[4 * c], st.g) && rms_close(a.st[4 * c + 1], st.p)) continue;
+        const int64_t s = c * a.chunk, e = (s + a.chunk < a.n) ? s + a.chunk : a.n;
+        for (int64_t i = s; i < e; ++i) pack_store(a.out, i, a.out_fmt, rms_step(a.x[i], st, a.alpha, han));
+        a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
+    }
+    if (a.n_chunks > 0) {
+        a.state->gain = a.st[4 * (int64_t)a.n_chunks - 2];
+        a.state->peak_memory = a.st[4 * (int64_t)a.n_chunks - 1];
+        a.state->seen += (uint64_t)a.n;
+    }
+}
+
+void agc_rms_geometry(float alpha, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks)
+{
+    int64_t w = (int64_t)(40.0 / (double)alpha + 0.5);         // e^-20 of the guess's error is left
+    w = (w + 1) & ~(int64_t)1;
+    int64_t ch = w / 16; if (ch < 2048) ch = 2048;
+    ch &= ~(int64_t)1;
+    *warm = w; *chunk = ch;
+    *n_chunks = (int32_t)((n + ch - 1) / ch);
+}
+
+hipError_t launch_agc_rms(const AgcRmsArgs &a, hipStream_t s)
+{
+    if (a.n <= 0 || a.n_chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_agc_rms_spec, dim3((unsigned)((a.n_chunks + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_agc_rms_fix, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
 } // namespace iqgpu

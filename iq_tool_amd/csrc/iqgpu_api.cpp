@@ -136,6 +136,7 @@ struct iqgpu_chain {
     // output AGC (digital profile)
     bool agc = false; float agc_target = 0.9f; int64_t agc_chunk = 16384;
     AgcState *d_agc_state = nullptr; AgcState agc_init{};
+    float agc_rms_alpha = 0.0f;     // > 0: profile dx / local (liquid agc_crcf), AgcState.gain = g, .peak_memory = y2_prime
     DevBuf abuf, agc_peak, agc_gain, agc_peak_b;
     // fused AGC of the locked phase (k_front_s1<.., AGC> + k_agc_verify): which chains qualify, the host's mirror of
     // "has the stream locked" (a closed form: the first chunk that starts after AGC_DIGITAL_LOCK_TIME of output), the
@@ -346,12 +347,15 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     }
     // ---- output AGC (src/agc.c:21-83, src/config.c:306-330) ----
     if (d->agc_enable) {
-        if (d->agc_profile != IQGPU_AGC_DIGITAL)
-            return fail(IQGPU_EUNSUPPORTED, "output AGC profile %d: only the 'digital' profile is built (dx / local are liquid agc_crcf, a per-sample nonlinear recurrence)", d->agc_profile);
+        if (d->agc_profile != IQGPU_AGC_DIGITAL && d->agc_profile != IQGPU_AGC_DX && d->agc_profile != IQGPU_AGC_LOCAL)
+            return fail(IQGPU_EINVAL, "Invalid AGC profile %d. Must be 'dx', 'local', or 'digital'.", d->agc_profile);   // src/config.c:318
         if (d->agc_target != 0.0f && (d->agc_target <= 0.0f || d->agc_target > 1.0f))
             return fail(IQGPU_EINVAL, "Invalid AGC target level %.2f. Must be between 0.0 and 1.0.", (double)d->agc_target);
         if (d->agc_clock != IQGPU_AGC_CLOCK_SAMPLES && d->agc_clock != IQGPU_AGC_CLOCK_WALL) return fail(IQGPU_EINVAL, "agc_clock must be IQGPU_AGC_CLOCK_SAMPLES or IQGPU_AGC_CLOCK_WALL");
         c->agc = true;
+        // dx / local: liquid agc_crcf with AGC_DX_BANDWIDTH / AGC_LOCAL_BANDWIDTH (src/agc.c:45-57, constants.h:169,175);
+        // the target level does not reach the loop (agc_crcf_set_gain(1.0f) behind set_signal_level, agc.c:56-59)
+        c->agc_rms_alpha = d->agc_profile == IQGPU_AGC_DX ? 1e-4f : d->agc_profile == IQGPU_AGC_LOCAL ? 1e-2f : 0.0f;
         c->agc_target = d->agc_target > 0.0f ? d->agc_target : 0.9f;      // AGC_DIGITAL_PEAK_TARGET
         c->agc_chunk = d->agc_chunk_frames ? (int64_t)d->agc_chunk_frames : 16384;   // PIPELINE_CHUNK_BASE_SAMPLES
         // k_agc_scan adds the output lengths of 64 chunks in 32 bits
@@ -455,7 +459,7 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         }
         if (c->agc) {
             CREATE_TRY(hipMalloc((void **)&c->d_agc_state, sizeof(AgcState)));
-            c->agc_init = AgcState{0, 0.05f, 1.0f, 0, c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0, 0};
+            c->agc_init = AgcState{0, c->agc_rms_alpha > 0.0f ? 1.0f : 0.05f, 1.0f, 0, c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0, 0};
             CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
             {   // [0] verdict of the verifier, [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk (agc.hip)
                 const int32_t init[4] = {0, 0, 0, -1};
@@ -468,7 +472,7 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
             fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk; fa.agc_shift = c->S;
             if (c->cascade) { fa.S = 1; fa.in_fmt = IQGPU_FMT_CF32; }      // k_cascade in front: the last stage sees cf32, one half-band
-            c->agc_fusable = c->decim && !c->late && !c->force_generic && !c->fp.enabled &&
+            c->agc_fusable = c->agc_rms_alpha == 0.0f && c->decim && !c->late && !c->force_generic && !c->fp.enabled &&
                              (c->cascade || c->S == 0 || (c->S == 1 && c->rp.stages[0].m == 10)) && front_s1_agc_fusable(fa);
         }
         if (c->fp.enabled) CREATE_RC(upload(&c->d_ftaps, (const cf2 *)c->fp.taps.data(), c->fp.taps.size()));
@@ -911,7 +915,11 @@ int Call::prepare_buffers()
         const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> casc_K;
         int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
     }
-    if (c->agc) {
+    if (c->agc && c->agc_rms_alpha > 0.0f) {
+        int64_t chunk, warm; int32_t n_chunks;
+        agc_rms_geometry(c->agc_rms_alpha, p.n_emit, &chunk, &warm, &n_chunks);
+        int rc = c->agc_gain.ensure((size_t)(n_chunks > 0 ? n_chunks : 1) * 4 * sizeof(float)); if (rc) return rc;
+    } else if (c->agc) {
         const AgcGeom g = agc_geom();
         if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
         int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
@@ -1106,6 +1114,17 @@ AgcArgs Call::agc_args() const
 
 int Call::stage_agc()
 {
+    if (c->agc_rms_alpha > 0.0f) {
+        AgcRmsArgs ra{};
+        ra.x = (const cf2 *)c->abuf.p; ra.n = p.n_emit; ra.alpha = c->agc_rms_alpha; ra.state = c->d_agc_state;
+        agc_rms_geometry(ra.alpha, ra.n, &ra.chunk, &ra.warm, &ra.n_chunks);
+        int rc = c->agc_gain.ensure((size_t)(ra.n_chunks > 0 ? ra.n_chunks : 1) * 4 * sizeof(float)); if (rc) return rc;
+        ra.st = (float *)c->agc_gain.p;
+        ra.out_fmt = c->desc.out_format; ra.out = d_out;
+        KernelTimer kt(c, IQGPU_K_AGC);
+        HIP_TRY(launch_agc_rms(ra, c->stream));
+        return IQGPU_OK;
+    }
     const AgcArgs ga = agc_args();
     KernelTimer kt(c, IQGPU_K_AGC);
     HIP_TRY(launch_agc(ga, c->stream));

@@ -349,7 +349,22 @@ struct AgcArgs {
     const int32_t *run_if;    // not NULL: the three kernels do nothing unless *run_if != 0
     int32_t   *verify_flag;   // k_agc_verify: set to 1 when the fused pass cannot stand (see agc.hip)
 };
-hipError_t launch_agc(const AgcArgs &a, hipStream_t s);   // peak, scan, apply
+hipError_t launch_agc(const AgcArgs &a, hipStream_t s);
+
+// RMS profiles dx / local (liquid agc_crcf): chunk-parallel with warm-up, then verified / repaired (agc.hip)
+struct AgcRmsArgs {
+    const cf2 *x;             // the call's output samples before the AGC (cf32)
+    int64_t    n;
+    float      alpha;         // loop bandwidth: AGC_DX_BANDWIDTH 1e-4, AGC_LOCAL_BANDWIDTH 1e-2
+    AgcState  *state;         // gain = g, peak_memory = y2_prime
+    int64_t    chunk, warm;   // outputs per lane; samples a speculative lane starts ahead
+    int32_t    n_chunks;
+    float     *st;            // [n_chunks][4]: {g, p} a chunk arrived with, {g, p} it left
+    int32_t    out_fmt;
+    void      *out;
+};
+void agc_rms_geometry(float alpha, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks);
+hipError_t launch_agc_rms(const AgcRmsArgs &a, hipStream_t s);   // peak, scan, apply
 // after a fused launch of the front kernel: all chunks healthy at the unchanged gain -> state advanced, *verify_flag = 0;
 // otherwise state untouched and *verify_flag = 1 (the caller has queued the unfused kernels behind it, run_if = verify_flag)
 hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s);

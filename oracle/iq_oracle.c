@@ -870,6 +870,8 @@ struct orc_agc {
     double rate;
     int    clock_mode;
     double wall;
+    int    profile;           /* ORC_AGC_PROFILE_* */
+    float  alpha, y2_prime;   /* agc_crcf: bandwidth, smoothed output energy (its gain lives in `gain`) */
     /* AppResources state, include/app_context.h:227-231 */
     int      locked;
     float    gain, peak_memory;
@@ -882,14 +884,21 @@ static double agc_now(const orc_agc *q)
     return q->clock_mode == ORC_AGC_CLOCK_WALL ? q->wall : (double)q->seen / q->rate;
 }
 
-orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode)
+orc_agc *orc_agc_create_profile(int profile, float target_level_arg, double sample_rate, int clock_mode)
 {
     orc_agc *q = (orc_agc *)calloc(1, sizeof(*q));
+    q->profile = profile ? profile : ORC_AGC_PROFILE_DIGITAL;
     q->target = (target_level_arg > 0) ? target_level_arg : ORC_AGC_PEAK_TARGET; /* ref: agc.c:111-113 */
     q->rate = sample_rate;      /* config->target_rate, agc.c:146 */
     q->clock_mode = clock_mode;
+    /* ref: agc.c:45-57: AGC_LOCAL_BANDWIDTH, or AGC_DX_BANDWIDTH for the dx profile (constants.h:169,175) */
+    q->alpha = (q->profile == ORC_AGC_PROFILE_DX) ? 1e-4f : 1e-2f;
     orc_agc_reset(q);
     return q;
+}
+orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode)
+{
+    return orc_agc_create_profile(ORC_AGC_PROFILE_DIGITAL, target_level_arg, sample_rate, clock_mode);
 }
 void orc_agc_destroy(orc_agc *q) { free(q); }
 void orc_agc_set_wall_time(orc_agc *q, double now_sec) { q->wall = now_sec; }
@@ -898,6 +907,7 @@ void orc_agc_reset(orc_agc *q) /* ref: agc.c:27-33, 75, 231-237 */
 {
     q->locked = 0; q->seen = 0; q->peak_memory = 0.05f; q->gain = 1.0f;
     q->last_strong = agc_now(q);
+    q->y2_prime = 1.0f;         /* agc_crcf_reset + agc_crcf_set_gain(1.0f), ref: agc.c:227-229 */
 }
 
 void orc_agc_apply(orc_agc *q, orc_cf32 *x, unsigned n)
@@ -905,6 +915,21 @@ void orc_agc_apply(orc_agc *q, orc_cf32 *x, unsigned n)
     unsigned i;
     float peak = 0.0f;
     if (n == 0) return;                                   /* ref: agc.c:86 */
+    if (q->profile != ORC_AGC_PROFILE_DIGITAL) {          /* ref: agc.c:92-100 -> agc_crcf_execute_block [liquid-mem] */
+        float g = q->gain, y2p = q->y2_prime;
+        const float alpha = q->alpha;
+        for (i = 0; i < n; i++) {
+            const float yr = x[i].re * g, yi = x[i].im * g;
+            const float y2 = yr * yr + yi * yi;
+            y2p = (float)((1.0 - (double)alpha) * (double)y2p + (double)alpha * (double)y2);
+            if (y2p > 1e-6f) g *= expf(-0.5f * alpha * logf(y2p));
+            if (g > 1e6f) g = 1e6f;
+            x[i].re = yr; x[i].im = yi;                   /* scale = 1 */
+        }
+        q->gain = g; q->y2_prime = y2p;
+        q->seen += n;
+        return;
+    }
     for (i = 0; i < n; i++) {                             /* ref: agc.c:120-124, 166-170 */
         float mag = hypotf(x[i].re, x[i].im);             /* cabsf */
         if (mag > peak) peak = mag;
@@ -941,6 +966,7 @@ void orc_agc_apply(orc_agc *q, orc_cf32 *x, unsigned n)
 int      orc_agc_is_locked(const orc_agc *q) { return q->locked; }
 float    orc_agc_gain(const orc_agc *q) { return q->gain; }
 float    orc_agc_peak_memory(const orc_agc *q) { return q->peak_memory; }
+float    orc_agc_y2_prime(const orc_agc *q) { return q->y2_prime; }
 uint64_t orc_agc_samples_seen(const orc_agc *q) { return q->seen; }
 
 struct orc_chain {
@@ -985,7 +1011,7 @@ orc_chain *orc_chain_create(const orc_chain_desc *d, int *err)
         c->filt = orc_filter_create(&d->filter, d->input_rate_hz, target, d->no_resample, err);
         if (!c->filt) { orc_chain_destroy(c); return NULL; }
     }
-    if (d->agc_enable) c->agc = orc_agc_create(d->agc_target, target, d->agc_clock); /* ref: pipeline.c:145 */
+    if (d->agc_enable) c->agc = orc_agc_create_profile(d->agc_profile, d->agc_target, target, d->agc_clock); /* ref: pipeline.c:145 */
     c->cap = orc_chain_max_out_frames(c, ORC_CHUNK);
     c->A = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));
     c->B = (orc_cf32 *)calloc(c->cap, sizeof(orc_cf32));

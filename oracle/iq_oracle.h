@@ -136,6 +136,7 @@ typedef struct {
     int    agc_enable;        /* config->output_agc.enable with profile "digital" (agc.c:105-222) */
     float  agc_target;        /* config->output_agc.target_level_arg; <= 0 -> AGC_DIGITAL_PEAK_TARGET */
     int    agc_clock;         /* ORC_AGC_CLOCK_* */
+    int    agc_profile;       /* ORC_AGC_PROFILE_*; 0 = digital (fixtures written before the RMS profiles existed) */
 } orc_chain_desc;
 /* ---- output AGC, "digital" profile (ref: src/agc.c:21-83 create, 85-222 apply, 224-238 reset) ----
  * The reference reads get_monotonic_time_sec() for the hang / creep logic of its locked phase
@@ -143,8 +144,19 @@ typedef struct {
  * (samples_seen / sample_rate, deterministic, equal to the wall clock when the reference runs
  * in real time), WALL = the value handed to orc_agc_set_wall_time(). */
 enum { ORC_AGC_CLOCK_SAMPLES = 0, ORC_AGC_CLOCK_WALL = 1 };
+/* AgcProfile, include/common_types.h:77-82.  DX / LOCAL are liquid's agc_crcf (ref: src/agc.c:39-62 create,
+ * 93-100 apply, 227-229 reset) with bandwidth AGC_DX_BANDWIDTH 1e-4 / AGC_LOCAL_BANDWIDTH 1e-2 (constants.h:169,175).
+ * [liquid-mem] agc_crcf_execute per sample, liquid-dsp >= 1.3.2 (src/agc/src/agc.proto.c):
+ *     y = x * g;  y2 = re(y)^2 + im(y)^2;  y2_prime = (1.0 - alpha) * y2_prime + alpha * y2   (in double, stored as float)
+ *     if (y2_prime > 1e-6f) g *= expf(-0.5f * alpha * logf(y2_prime));  if (g > 1e6f) g = 1e6f;  y *= scale (= 1)
+ * create / reset: g = 1, y2_prime = 1, alpha = bandwidth.  The reference calls agc_crcf_set_signal_level(target)
+ * -- which sets g = 1 / target and y2_prime = 1 -- and then agc_crcf_set_gain(1.0f), so the target level never
+ * reaches the loop: the output settles at unit mean power whatever --output-agc-target says (VERIFY). */
+enum { ORC_AGC_PROFILE_DX = 1, ORC_AGC_PROFILE_LOCAL = 2, ORC_AGC_PROFILE_DIGITAL = 3 };
 typedef struct orc_agc orc_agc;
-orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode);
+orc_agc *orc_agc_create(float target_level_arg, double sample_rate, int clock_mode);   /* digital */
+orc_agc *orc_agc_create_profile(int profile, float target_level_arg, double sample_rate, int clock_mode);
+float    orc_agc_y2_prime(const orc_agc *q);    /* RMS profiles: the smoothed output energy */
 void     orc_agc_destroy(orc_agc *q);
 void     orc_agc_reset(orc_agc *q);
 void     orc_agc_set_wall_time(orc_agc *q, double now_sec);

@@ -40,7 +40,7 @@ class ChainDesc(C.Structure):
                 ("no_resample", C.c_int),
                 ("filter", FilterCfg),
                 ("dc_f32_literal", C.c_int),
-                ("agc_enable", C.c_int), ("agc_target", C.c_float), ("agc_clock", C.c_int)]
+                ("agc_enable", C.c_int), ("agc_target", C.c_float), ("agc_clock", C.c_int), ("agc_profile", C.c_int)]
 
 
 def build(force=False):
@@ -104,6 +104,8 @@ def _proto(lib):
     P("orc_filter_taps", C.POINTER(C.c_float), [vp])
     P("orc_filter_apply", C.c_uint, [vp, vp, C.c_uint, vp])
     P("orc_agc_create", vp, [C.c_float, C.c_double, C.c_int])
+    P("orc_agc_create_profile", vp, [C.c_int, C.c_float, C.c_double, C.c_int])
+    P("orc_agc_y2_prime", C.c_float, [vp])
     P("orc_agc_destroy", None, [vp])
     P("orc_agc_reset", None, [vp])
     P("orc_agc_set_wall_time", None, [vp, C.c_double])
@@ -366,12 +368,14 @@ class Filter:
 
 
 class Agc:
-    """agc_create / agc_apply / agc_reset, "digital" profile (src/agc.c); apply() takes ONE chunk"""
+    """agc_create / agc_apply / agc_reset (src/agc.c); for the "digital" profile apply() takes ONE chunk,
+    the RMS profiles "dx" / "local" (liquid agc_crcf) are per-sample loops and do not care"""
+    PROFILES = {"dx": 1, "local": 2, "digital": 3}
 
-    def __init__(self, sample_rate, target=0.0, clock="samples", L=None, handle=None):
+    def __init__(self, sample_rate, target=0.0, clock="samples", L=None, handle=None, profile="digital"):
         self.L = L or lib()
         self.own = handle is None
-        self.q = handle or self.L.orc_agc_create(target, sample_rate, {"samples": 0, "wall": 1}[clock])
+        self.q = handle or self.L.orc_agc_create_profile(self.PROFILES[profile], target, sample_rate, {"samples": 0, "wall": 1}[clock])
 
     def __del__(self):
         if getattr(self, "q", None) and self.own:
@@ -394,6 +398,7 @@ class Agc:
     locked = property(lambda s: bool(s.L.orc_agc_is_locked(s.q)))
     gain = property(lambda s: s.L.orc_agc_gain(s.q))
     peak_memory = property(lambda s: s.L.orc_agc_peak_memory(s.q))
+    y2_prime = property(lambda s: s.L.orc_agc_y2_prime(s.q))
     samples_seen = property(lambda s: s.L.orc_agc_samples_seen(s.q))
 
 
@@ -402,11 +407,12 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
               iq_correct=False, iq_mag=0.0, iq_phase=0.0, no_resample=False,
               filters=(), transition_width_hz=0.0, attenuation_db=0.0, filter_taps=0,
               filter_impl="auto", fft_size=0, dc_f32_literal=False,
-              agc=False, agc_target=0.0, agc_clock="samples", agc_chunk_frames=0):
+              agc=False, agc_target=0.0, agc_clock="samples", agc_chunk_frames=0, agc_profile="digital"):
     assert agc_chunk_frames in (0, 16384), "the oracle chunks like the reference: 16384 frames"
     d = ChainDesc()
     d.agc_enable = int(bool(agc))
     d.agc_target = agc_target
+    d.agc_profile = Agc.PROFILES[agc_profile] if isinstance(agc_profile, str) else agc_profile
     d.agc_clock = {"samples": 0, "wall": 1}[agc_clock] if isinstance(agc_clock, str) else agc_clock
     d.in_format = fmt_id(in_format)
     d.out_format = fmt_id(out_format)

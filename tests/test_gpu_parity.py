@@ -589,12 +589,62 @@ def test_agc_with_fft_filter_and_interpolation_chunks(gpu, oracle):
     assert got.size == want.size and np.abs(got - want).max() <= TOL * 10
 
 
-def test_agc_unbuilt_profiles_and_bad_target(gpu):
+@pytest.mark.parametrize("profile", ["local", "dx"])
+def test_agc_rms_profiles_in_preset_chain(gpu, oracle, profile):
+    """--output-agc without a profile is liquid's agc_crcf ("local"; "dx" is the slow one), src/agc.c:39-62, 92-100:
+    a per-sample loop on the CPU, chunk-parallel with warm-up + verification on the GPU (agc.hip)"""
+    n = 3 * 1000 * 1000            # 930 k outputs: 455 chunks for local; 9 for dx, the last 4 of them speculative
+    raw = synth.raw_stream(n, 2.4e6, 41, "cs16")
+    for out_format in ("cf32", "cs16"):
+        kw = dict(NRSC5, out_format=out_format, agc=True, agc_profile=profile)
+        och = oracle.Chain(**kw)
+        want = och.process(raw)
+        ch = gpu.Chain(**kw)
+        cuts = [0, 100000, 100000 + 16384, 1500000, n]
+        got = np.concatenate([ch.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert got.size == want.size
+        if out_format == "cf32":
+            err = np.abs(cf(got) - cf(want))
+            assert err.max() <= 2e-5 * max(1.0, np.abs(cf(want)).max()), err.max()
+        else:
+            int_close(got, want, min_same=0.98)
+        st = ch.agc_state()
+        assert abs(st["gain"] - och.agc.gain) <= 1e-5 * och.agc.gain
+        assert abs(st["peak_memory"] - och.agc.y2_prime) <= 1e-5 * och.agc.y2_prime
+        assert st["samples_seen"] == och.agc.samples_seen
+
+
+def test_agc_rms_silence_freezes_the_gain_and_the_repair_pass_runs(gpu, oracle):
+    """a silent stretch drives y2_prime below 1e-6 and the gain stops moving: a lane that starts inside it from a
+    guess can never find the true state, the verifier must catch that and re-run the stream from there"""
+    rng = np.random.default_rng(42)
+    sig = lambda m, a: (a * (rng.standard_normal(m) + 1j * rng.standard_normal(m))).astype(np.complex64)
+    x = np.concatenate([sig(30000, 0.05), np.zeros(60000, np.complex64), sig(40000, 0.2), np.zeros(3000, np.complex64), sig(20000, 0.01)])
+    raw = x.view(np.float32)
+    for profile in ("local", "dx"):
+        kw = dict(in_format="cf32", out_format="cf32", input_rate_hz=1e6, target_rate_hz=1e6, no_resample=True,
+                  agc=True, agc_profile=profile)
+        och = oracle.Chain(**kw)
+        want = cf(och.process(raw))
+        ch = gpu.Chain(**kw)
+        got = cf(ch.process(raw))
+        assert got.size == want.size == x.size
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        assert abs(ch.agc_state()["gain"] - och.agc.gain) <= 1e-5 * och.agc.gain
+        # reset: g = 1, y2_prime = 1 (agc_crcf_reset + agc_crcf_set_gain(1), src/agc.c:227-229), then small ragged calls
+        ch.reset(); och.reset()
+        st = ch.agc_state()
+        assert st["gain"] == 1.0 and st["peak_memory"] == 1.0
+        got2 = np.concatenate([cf(ch.process(raw[2 * a:2 * b])) for a, b in ((0, 1), (1, 700), (700, 5000), (5000, 40000))])
+        want2 = cf(och.process(raw[:80000]))
+        assert np.abs(got2 - want2).max() <= 2e-5 * max(1.0, np.abs(want2).max())
+
+
+def test_agc_bad_profile_and_bad_target(gpu):
     from iq_tool_amd import IqgpuError
-    for prof in ("dx", "local"):
-        with pytest.raises(IqgpuError) as e:
-            gpu.Chain(agc=True, agc_profile=prof)
-        assert e.value.code == -10
+    with pytest.raises(IqgpuError) as e:
+        gpu.Chain(agc=True, agc_profile=7)
+    assert e.value.code == -1
     with pytest.raises(IqgpuError) as e:
         gpu.Chain(agc=True, agc_target=1.5)
     assert e.value.code == -1

@@ -423,6 +423,45 @@ def test_agc_digital_matches_numpy_restatement(oracle):
     assert not a.locked and a.gain == 1.0 and a.peak_memory == np.float32(0.05) and a.samples_seen == 0
 
 
+def _agc_crcf_python(x, alpha):
+    """liquid agc_crcf_execute [liquid-mem], one numpy float32 operation per C operation (math.exp / math.log in double
+    rounded to float stand in for glibc's correctly rounded expf / logf)"""
+    import math
+    f = np.float32
+    g, p, a = f(1.0), f(1.0), f(alpha)
+    out = np.empty(x.size, np.complex64)
+    for i, v in enumerate(x):
+        yr, yi = f(v.real) * g, f(v.imag) * g
+        y2 = f(yr * yr) + f(yi * yi)
+        p = f((1.0 - float(a)) * float(p) + float(a) * float(y2))
+        if p > f(1e-6):
+            g = g * f(math.exp(float(f(f(-0.5) * a) * f(math.log(float(p))))))
+        if g > f(1e6):
+            g = f(1e6)
+        out[i] = complex(yr, yi)
+    return out, g, p
+
+
+@pytest.mark.parametrize("profile,alpha", [("local", 1e-2), ("dx", 1e-4)])
+def test_agc_rms_profiles_match_python_restatement(oracle, profile, alpha):
+    rng = np.random.default_rng(33)
+    x = np.concatenate([0.05 * (rng.standard_normal(6000) + 1j * rng.standard_normal(6000)), np.zeros(3000),
+                        0.6 * (rng.standard_normal(4000) + 1j * rng.standard_normal(4000))]).astype(np.complex64)
+    want, g, p = _agc_crcf_python(x, alpha)
+    a = oracle.Agc(1e6, profile=profile)
+    got = np.concatenate([a.apply(x[:777]), a.apply(x[777:])])        # a per-sample loop: the call partition is invisible
+    # glibc's expf / logf are within 0.51 ulp, not always the nearest float: a step that rounds the other way leaves the
+    # two runs one ulp apart for ~1 / alpha samples
+    same = got.view(np.float32) == want.view(np.float32)
+    assert same.mean() > 0.9 and np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    assert abs(a.gain - g) <= 1e-6 * g and abs(a.y2_prime - p) <= 1e-6 * p and a.samples_seen == x.size
+    a.reset()
+    assert a.gain == 1.0 and a.y2_prime == 1.0
+    if profile == "local":      # a stationary input settles at unit output power whatever the target says (agc.c:56-59)
+        y = oracle.Agc(1e6, profile=profile, target=0.3).apply(x[:6000])
+        assert abs(np.mean(np.abs(y[-2000:]) ** 2) - 1.0) < 0.1
+
+
 def test_agc_in_chain_runs_between_post_nco_and_pack(oracle):
     """chain with the AGC == chain without it, cf32 out, then agc_apply per 16384-frame input chunk"""
     n = 200000
