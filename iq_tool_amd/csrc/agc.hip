@@ -300,17 +300,88 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------------------------
 struct RmsSt { float g, p; };
 
+// ln x for a float-range x > 0, in double to ~1e-13 relative (of ln x): x = 2^e m with m in [sqrt(1/2), sqrt(2)),
+// s = (m - 1) / (m + 1), ln m = 2 atanh s = 2 s (1 + s^2/3 + s^4/5 + ... + s^16/17), |s| <= 0.1716.
+// Written out (v_frexp, v_rcp_f64 + two Newton steps, Horner) because a lane runs ONE dependent chain: the
+// library log / exp are ~85 dependent instructions per sample together, these ~40.
+__device__ __forceinline__ double rms_ln(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);              // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m; e = lo ? e - 1 : e;
+    const double f = m - 1.0, d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    double sq = f * r;
+    sq = __builtin_fma(r, __builtin_fma(-sq, d, f), sq);    // s = f / d to the last bit or so
+    const double z = sq * sq;
+    double q = 1.0 / 17.0;
+    q = __builtin_fma(q, z, 1.0 / 15.0); q = __builtin_fma(q, z, 1.0 / 13.0); q = __builtin_fma(q, z, 1.0 / 11.0);
+    q = __builtin_fma(q, z, 1.0 / 9.0);  q = __builtin_fma(q, z, 1.0 / 7.0);  q = __builtin_fma(q, z, 1.0 / 5.0);
+    q = __builtin_fma(q, z, 1.0 / 3.0);
+    const double lnm = __builtin_fma(sq + sq, q * z, sq + sq);
+    return __builtin_fma((double)e, 0.69314718055994530942, lnm);
+}
+
+// e^t for |t| <= 0.14 (0.5 alpha |ln p| with p in (1e-6, 1e13), alpha <= 1e-2): Taylor to t^9 / 9!, < 1e-15
+__device__ __forceinline__ double rms_exp_small(double t)
+{
+    double q = 1.0 / 362880.0;
+    q = __builtin_fma(q, t, 1.0 / 40320.0); q = __builtin_fma(q, t, 1.0 / 5040.0); q = __builtin_fma(q, t, 1.0 / 720.0);
+    q = __builtin_fma(q, t, 1.0 / 120.0);   q = __builtin_fma(q, t, 1.0 / 24.0);   q = __builtin_fma(q, t, 1.0 / 6.0);
+    q = __builtin_fma(q, t, 0.5);           q = __builtin_fma(q, t, 1.0);
+    return __builtin_fma(q, t, 1.0);
+}
+
 __device__ __forceinline__ cf2 rms_step(cf2 v, RmsSt &st, float alpha, float half_alpha_neg)
 {
     const float yr = v.x * st.g, yi = v.y * st.g;
     const float y2 = yr * yr + yi * yi;
     st.p = (float)((1.0 - (double)alpha) * (double)st.p + (double)alpha * (double)y2);
-    // logf / expf rounded the way glibc rounds them (correctly, but for rare near-ties): through double.  It matters:
+    // logf / expf rounded the way glibc rounds them (to nearest, but for rare near-ties): through double.  It matters:
     // the update factor is 1 + O(alpha), so its float rounding is percent-level noise on the correction term, and a
     // libm that rounds differently by 1e-7 per step moves the settled gain by 1e-7 / alpha (1e-3 for dx).
-    if (st.p > 1e-6f) st.g *= (float)exp((double)(half_alpha_neg * (float)log((double)st.p)));
+    if (st.p > 1e-6f) st.g *= (float)rms_exp_small((double)(half_alpha_neg * (float)rms_ln((double)st.p)));
     st.g = fminf(st.g, 1e6f);
     return cf2{yr, yi};
+}
+
+// samples [i0, i1) of the stream through the loop; EMIT: pack and store them.  The loads run four samples ahead of
+// the chain (a lane's stream is contiguous, but every load of a wave touches 64 different cache lines: waited for
+// where it is used, its latency would be most of the step).
+template <bool EMIT>
+__device__ __forceinline__ void rms_run(const AgcRmsArgs &a, int64_t i0, int64_t i1, RmsSt &st, float han)
+{
+    int64_t i = i0;
+    if (i + 4 <= i1) {
+        cf2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = a.x[i + k];
+        for (; i + 8 <= i1; i += 4) {
+            cf2 nx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nx[k] = a.x[i + 4 + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const cf2 y = rms_step(v[k], st, a.alpha, han);
+                if (EMIT) pack_store(a.out, i + k, a.out_fmt, y);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = nx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const cf2 y = rms_step(v[k], st, a.alpha, han);
+            if (EMIT) pack_store(a.out, i + k, a.out_fmt, y);
+        }
+        i += 4;
+    }
+    for (; i < i1; ++i) {
+        const cf2 y = rms_step(a.x[i], st, a.alpha, han);
+        if (EMIT) pack_store(a.out, i, a.out_fmt, y);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_agc_rms_spec(const AgcRmsArgs a)
@@ -322,9 +393,9 @@ __global__ __launch_bounds__(64) void k_agc_rms_spec(const AgcRmsArgs a)
     RmsSt st{a.state->gain, a.state->peak_memory};
     int64_t i = 0;
     if (s > a.warm) { i = s - a.warm; st.p = 1.0f; }            // a guess: the call's first gain, unit energy
-    for (; i < s; ++i) (void)rms_step(a.x[i], st, a.alpha, han);
+    rms_run<false>(a, i, s, st, han);
     a.st[4 * c + 0] = st.g; a.st[4 * c + 1] = st.p;
-    for (; i < e; ++i) pack_store(a.out, i, a.out_fmt, rms_step(a.x[i], st, a.alpha, han));
+    rms_run<true>(a, s, e, st, han);
     a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
 }
 
@@ -344,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_agc_rms_fix(const AgcRmsArgs a)
         RmsSt st{a.st[4 * c - 2], a.st[4 * c - 1]};                    // where the stream really is
         if (rms_close(a.st[4 * c], st.g) && rms_close(a.st[4 * c + 1], st.p)) continue;
         const int64_t s = c * a.chunk, e = (s + a.chunk < a.n) ? s + a.chunk : a.n;
-        for (int64_t i = s; i < e; ++i) pack_store(a.out, i, a.out_fmt, rms_step(a.x[i], st, a.alpha, han));
+        rms_run<true>(a, s, e, st, han);
         a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
     }
     if (a.n_chunks > 0) {
