@@ -995,6 +995,41 @@ def test_submit_rules_tickets_and_mixing_with_process(gpu):
     assert np.array_equal(ch2.process(raw), want)
 
 
+def test_submit_defers_kernels_but_not_semantics(gpu, oracle):
+    """submit() only queues the batch's H2D copy; its kernels are launched by later submit / collect calls.  What a batch
+    computes must still be what it would have computed at submit time: I/Q factors as of its submit, output counts from
+    the stream position behind the tickets handed out, direct calls in stream order behind pending batches."""
+    from iq_tool_amd.chain import PinnedBuffer
+    kw = dict(in_format="cs16", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=-50e3,
+              iq_correct=True, iq_mag=0.0, iq_phase=0.0)
+    n, nb = 50001 * 2, 6                                 # ragged batches: the counts differ from batch to batch
+    raw = synth.raw_stream(n * (nb + 1), 2.4e6, 12, "cs16").view(np.uint8)
+    g, o = gpu.Chain(**kw), oracle.Chain(**kw)
+    ins = [PinnedBuffer(n * 4) for _ in range(nb)]
+    outs = [PinnedBuffer(g.max_out_frames(n) * 8) for _ in range(nb)]
+    steps = [(0.0, 0.0), (0.01, -0.005), (0.02, 0.0), (-0.02, 0.03), (0.0, 0.01), (0.005, 0.005)]
+    tickets, counts, want = [], [], []
+    for i in range(nb):
+        g.set_iq_factors(*steps[i]); o.set_iq_factors(*steps[i])
+        ins[i].array[:] = raw[i * n * 4:(i + 1) * n * 4]
+        assert g.next_out_frames(n) == g._lib.iqgpu_chain_next_out_frames(g._h, n)
+        expect = g.next_out_frames(n)                    # behind the pending tickets
+        got, t = g.submit(ins[i].ptr, n, outs[i].ptr, outs[i].nbytes)
+        assert got == expect
+        tickets.append(t); counts.append(got)
+        want.append(cf(o.process(raw[i * n * 4:(i + 1) * n * 4])))
+        assert got == want[-1].size
+    g.set_iq_factors(0.03, 0.03); o.set_iq_factors(0.03, 0.03)     # must not reach the batches already submitted
+    tail = cf(g.process(raw[nb * n * 4:]))               # a direct call: behind every pending batch, with the new factors
+    want_tail = cf(o.process(raw[nb * n * 4:]))
+    for i, t in enumerate(tickets):                       # collected late and out of order
+        g.collect(tickets[nb - 1 - i])
+    for i in range(nb):
+        got = outs[i].array[:counts[i] * 8].view(np.complex64)
+        assert np.abs(got - want[i]).max() <= TOL, i
+    assert tail.size == want_tail.size and np.abs(tail - want_tail).max() <= TOL
+
+
 def test_iq_factors_changed_between_calls(gpu, oracle):
     # what the optimiser thread does (src/iq_correct.c:141-152 reads the factors once per chunk)
     raw = synth.raw_stream(1 << 18, 2.4e6, 9, "cs16")
