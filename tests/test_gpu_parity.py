@@ -859,6 +859,8 @@ def _random_chain(rng):
         kw["agc"] = True
     if rng.random() < 0.3:
         kw["block_samples"] = int(rng.choice([2048, 16384, 1 << 20]))
+    if kw.get("agc") and rng.random() < 0.5:                        # (drawn last: the chains of earlier rounds keep their seeds)
+        kw["agc_profile"] = str(rng.choice(["local", "dx"]))          # liquid agc_crcf instead of the digital profile
     return kw
 
 
@@ -894,7 +896,19 @@ def test_random_chain_matches_oracle(gpu, oracle, seed):
     assert got.size == want.size, (kw, got.size, want.size)
     if want.size == 0:
         return
-    if kw["out_format"] == "cf32":
+    if kw.get("agc_profile") in ("local", "dx"):
+        # liquid's agc_crcf amplifies: while its input is still (nearly) silent -- filter and resampler start-up -- the
+        # gain runs up to its 1e6 clamp, and through the collapse that follows the two runs' 1e-6 differences in front
+        # of the AGC are no longer small.  Nearly all samples agree as usual; the rest stay within 2 % of full scale.
+        if kw["out_format"] == "cf32":
+            scale = max(1.0, float(np.abs(cf(want)).max()))
+            err = np.abs(cf(got) - cf(want))
+            assert (err <= 4 * TOL * scale).mean() >= 0.97 and err.max() <= 2e-2 * scale, kw
+        else:
+            d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+            full = float(np.iinfo(want.dtype).max - np.iinfo(want.dtype).min)
+            assert (d <= 1).mean() >= 0.97 and d.max() <= 2e-2 * full, (kw, d.max())
+    elif kw["out_format"] == "cf32":
         scale = max(1.0, float(np.abs(cf(want)).max()))
         assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL * scale, kw
     else:
