@@ -178,7 +178,10 @@ int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t f
  * the batches already submitted) and a ticket; the batch's kernels and its D2H copy are queued by the submit()
  * calls that follow (three and five batches later) or by collect(), which blocks until the batch's output
  * bytes are in `out`.  Up to iqgpu_chain_pipeline_depth() batches may be in flight; copies of one batch
- * overlap the kernels of its neighbours.  The pipeline makes progress inside submit() / collect() only.  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
+ * overlap the kernels of its neighbours.  The pipeline makes progress inside submit() / collect() only, and a
+ * failure of a batch's kernels (IQGPU_EHIP ...) is reported by the call that launches them -- a later submit()
+ * or the batch's collect() -- after which the handle is poisoned until iqgpu_chain_reset(), as with process().
+ * The I/Q factors a batch runs with are those in force at its submit().  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
  * pageable memory works but serialises -- and must stay untouched until the ticket is collected.  Batches are
  * processed in submit order: the stream is continuous across them exactly as across iqgpu_chain_process calls
  * (this is what replaces the reference's chunk hand-off between its three stage threads, src/pipeline.c:436-595). */

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs 
     cf2 *s_nco = (cf2 *)smem;
     CascLds w;
     w.nco = s_nco;
+    if (((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
     {
         char *p = (char *)smem + 1024 * 8 + wave * a.casc_wave_lds;
         char *p0 = p;

@@ -42,7 +42,7 @@ constexpr int kXRows = 5 + 64;                              // 20 history + 256 
 constexpr int kHRows = 4 + 64;                              // 16 history + 256 half-band outputs, aliased onto
 constexpr int kHBOff = 5;                                   //   XO rows kHBOff .. kHBOff + kHRows - 1
 constexpr int kWaveLds = (kXRows + kHBOff + kHRows) * kRowB; // 6816 B per wave
-constexpr int kTabLds = 1024 * 8 + 256 * 14 * 4;            // NCO {cos,sin} + polyphase taps [256][14]
+constexpr int kTabLds = 2 * 1024 * 8 + 256 * 14 * 4;        // NCO {cos,sin}, its half-scaled copy (FAST), polyphase taps [256][14]
 
 size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveLds; }   // the larger of the two shapes
 
@@ -117,7 +117,7 @@ __device__ __forceinline__ int out_bytes(int fmt)
 #define CLOCK_END(sinkbase) do { } while (0)
 #endif
 
-struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };
+struct WaveLds { char *XE, *XO, *HB; const cf2 *nco; const float *arb; unsigned arb_lds; };   // nco: two 8 KiB copies (FAST)
 
 // first output at or after the lane's first half-band sample (4*lane), for a tile whose first
 // output has phase delta0 (< step): n0 = its index within the tile, Pl = its phase relative to 4*lane
@@ -225,7 +225,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         for (int c = 0; c < NC; ++c) {
             uint32_t th = a.nco_theta0 + ((uint32_t)tile_first + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { cs_n[c][s] = nco_phasor2(w.nco, th); th += a.nco_dtheta; }
+            for (int s = 0; s < 4; ++s) {
+                // FAST: the odd stream only ever meets the half-band's centre tap 0.5 -- its samples are mixed with the
+                // half-scaled copy of the table and stored as 0.5 x (exactly: a power of two), which saves the 8 multiplies
+                cs_n[c][s] = nco_phasor2(w.nco, th, (FAST && (s & 1)) ? 1 : 0);
+                th += a.nco_dtheta;
+            }
         }
     };
     if (!EDGE) {
@@ -400,6 +405,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int off = woff + 32 * c * kRowB;
+                if (FAST && EDGE) {           // the scalar path mixes with the full table (and keeps its samples for hist_out)
+                    x[c][1].x *= 0.5f; x[c][1].y *= 0.5f; x[c][3].x *= 0.5f; x[c][3].y *= 0.5f;
+                }
                 *(float4 *)(XE + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
                 *(float4 *)(XO + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
             }
@@ -426,8 +434,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             }
             const char *wo = XO + lane * kRowB;
             const float4 o0 = ld4(wo + 2 * kRowB + 16), o1 = ld4(wo + 3 * kRowB);
-            v2f acc[4] = {v2f{0.5f * o0.x, 0.5f * o0.y}, v2f{0.5f * o0.z, 0.5f * o0.w},
-                          v2f{0.5f * o1.x, 0.5f * o1.y}, v2f{0.5f * o1.z, 0.5f * o1.w}};
+            const float hc = FAST ? 1.0f : 0.5f;          // FAST: the odd stream is stored as 0.5 x
+            v2f acc[4] = {v2f{hc * o0.x, hc * o0.y}, v2f{hc * o0.z, hc * o0.w},
+                          v2f{hc * o1.x, hc * o1.y}, v2f{hc * o1.z, hc * o1.w}};
             if (!EDGE) __builtin_amdgcn_s_setprio(0);
             const v2f *hbp = (const v2f *)a.hb0;          // 10 SGPR pairs {h[2i], h[2i+1]}
             // acc[r] += h[2 q2] E[20 + r - 2 q2] + h[2 q2 + 1] E[19 + r - 2 q2], q2 = 0 .. 9
@@ -603,13 +612,14 @@ __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThrea
     constexpr int kThr = k16 ? kS1Threads : kWThreads, kWv = k16 ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    cf2   *s_nco = (cf2 *)smem;
-    float *s_arb = (float *)(smem + 1024 * 8);
+    cf2   *s_nco = (cf2 *)smem, *s_nco_half = s_nco + 1024;
+    float *s_arb = (float *)(smem + 2 * 1024 * 8);
     WaveLds w;
     w.XE = (char *)smem + kTabLds + wave * kWaveLds;
     w.XO = w.XE + kXRows * kRowB;
     w.HB = w.XO + kHBOff * kRowB;
     w.nco = s_nco; w.arb = s_arb;
+    if (((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
     w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;   // LDS byte address
 
     if (a.nco_mode != 0 || a.pnco_mode != 0) {
@@ -617,7 +627,11 @@ __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThrea
         // FAST: the cs16 normaliser 2^-15 is folded into the table -- power-of-two scaling commutes with
         // every rounding of x * (c + j s), so the mixed samples are bit-identical
         const float scl = FAST ? 1.0f / 32768.0f : 1.0f;
-        for (int i = tid; i < 1024; i += kThr) { const cf2 v = a.nco_tab[i]; s_nco[i] = cf2{v.x * scl, sgn * v.y * scl}; }
+        for (int i = tid; i < 1024; i += kThr) {
+            const cf2 v = a.nco_tab[i];
+            s_nco[i] = cf2{v.x * scl, sgn * v.y * scl};
+            if (FAST) s_nco_half[i] = cf2{v.x * (0.5f * scl), sgn * v.y * (0.5f * scl)};
+        }
     }
     // polyphase taps: arm a lives in row a ^ (a >> 5).  The arms that the lanes of one gather touch
     // form an arithmetic progression (mod 256); with plain 56-byte rows that lands 3.3x the cycles of

@@ -172,9 +172,16 @@ __device__ __forceinline__ void pk_fma_pp12(v2f &ya, v2f &yb, const v2f *ta, con
         : [p0] "v"(ta[0]), [p1] "v"(ta[1]), [p2] "v"(ta[2]), [q0] "v"(tb[0]), [q1] "v"(tb[1]), [q2] "v"(tb[2]),
           [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]));
 }
-__device__ __forceinline__ v2f nco_phasor2(const cf2 *tab, uint32_t theta)
+// the table sits at an LDS address that is a multiple of its 8 KiB (the kernels put it first and check): index and
+// base meet in ONE v_and_or_b32 instead of an and and an add (eight lookups per tile)
+// (copy: which 8 KiB copy of the table behind `tab` -- a constant that lands in the instruction's offset field)
+__device__ __forceinline__ v2f nco_phasor2(const cf2 *tab, uint32_t theta, int copy = 0)
 {
-    return *(const v2f *)(tab + ((theta + (1u << 21)) >> 22));
+    typedef __attribute__((address_space(3))) const char lds_char;
+    typedef __attribute__((address_space(3))) const v2f lds_v2f;
+    const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)tab;
+    lds_char *p = (lds_char *)(size_t)((((theta + (1u << 21)) >> 19) & 0x1ff8u) | base);
+    return *(lds_v2f *)(p + copy * 8192);
 }
 
 // y = x * (c + j s); the sign of s for mix-down is folded into the LDS copy of the table
