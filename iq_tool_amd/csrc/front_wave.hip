@@ -395,12 +395,15 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         // wave priority: a wave that is about to feed the LDS pipe (the busiest of the three) goes ahead of waves
         // that are in their FMA runs (measured -3 % on the NRSC-5 chain)
         if (!EDGE) __builtin_amdgcn_s_setprio(1);
+        v2f own[4];                                 // the lane's own polyphase-input row (row lane + 4 of HB): kept, not re-read
         if (S0) {
             // no half-band stage: the lane's four samples ARE its polyphase-input row
             if (lane < 48) *(float *)(HB + lane * 4) = sl_hist;         // history rows of the polyphase input
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(x[0][0].x, x[0][0].y, x[0][1].x, x[0][1].y);
             *(float4 *)(ph + 16) = make_float4(x[0][2].x, x[0][2].y, x[0][3].x, x[0][3].y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) own[i] = v2f{x[0][i].x, x[0][i].y};
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -451,6 +454,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             char *ph = HB + (lane + 4) * kRowB;
             *(float4 *)ph = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
             *(float4 *)(ph + 16) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) own[i] = acc[i];
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 48) sl_hist = *(const float *)(HB + 64 * kRowB + lane * 4);
@@ -467,11 +472,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                     H[0] = v2f{v.x, v.y}; H[1] = v2f{v.z, v.w};
                 }
 #pragma unroll
-                for (int r = 1; r < 5; ++r) {
+                for (int r = 1; r < 4; ++r) {
                     const float4 v0 = ld4(wh + r * kRowB), v1 = ld4(wh + r * kRowB + 16);
                     H[4 * r - 2] = v2f{v0.x, v0.y}; H[4 * r - 1] = v2f{v0.z, v0.w};
                     H[4 * r + 0] = v2f{v1.x, v1.y}; H[4 * r + 1] = v2f{v1.z, v1.w};
                 }
+                H[14] = own[0]; H[15] = own[1]; H[16] = own[2]; H[17] = own[3];     // row lane + 4: what this lane wrote above
                 // (gathered right before use: values written by asm loads must not sit in registers
                 // that the register allocator may copy before the wait below)
                 uint32_t n0, Pl;
