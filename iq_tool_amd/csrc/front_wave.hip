@@ -431,8 +431,13 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             v2f E[24];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const float4 v0 = ld4(we + r * kRowB), v1 = ld4(we + r * kRowB + 16);
-                E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
+                const float4 v1 = ld4(we + r * kRowB + 16);
+                if (r == 0) {                  // E[0] is not a tap of any of the lane's four outputs: 8 bytes do
+                    E[0] = v2f{0.f, 0.f}; E[1] = *(const v2f *)(we + 8);
+                } else {
+                    const float4 v0 = ld4(we + r * kRowB);
+                    E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
+                }
                 E[4 * r + 2] = v2f{v1.x, v1.y}; E[4 * r + 3] = v2f{v1.z, v1.w};
             }
             const char *wo = XO + lane * kRowB;
@@ -467,10 +472,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             if (!EDGE || q_tile0 < a.n_groups) {
                 const char *wh = HB + lane * kRowB;
                 v2f H[18];
-                {
-                    const float4 v = ld4(wh + 16);
-                    H[0] = v2f{v.x, v.y}; H[1] = v2f{v.z, v.w};
-                }
+                H[0] = v2f{0.f, 0.f}; H[1] = *(const v2f *)(wh + 24);          // H[0] is not a tap of any slot: 8 bytes do
 #pragma unroll
                 for (int r = 1; r < 4; ++r) {
                     const float4 v0 = ld4(wh + r * kRowB), v1 = ld4(wh + r * kRowB + 16);
