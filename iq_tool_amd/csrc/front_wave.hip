@@ -134,7 +134,7 @@ __device__ __forceinline__ void tap_rows(const WaveLds &w, uint32_t Pl, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        hit[r] = (Pl >> 24) == (uint32_t)r;
+        hit[r] = Pl < ((uint32_t)(r + 1) << 24);       // Pl >= r << 24 here: the pending output never lies behind the slot
         const unsigned arm = (Pl >> 16) & 255u;
         row[r] = w.arb_lds + (arm ^ (arm >> 5)) * 56u;
         if (hit[r]) Pl += step;
