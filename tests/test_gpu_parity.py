@@ -1044,6 +1044,76 @@ def test_submit_defers_kernels_but_not_semantics(gpu, oracle):
     assert tail.size == want_tail.size and np.abs(tail - want_tail).max() <= TOL
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_submit_collect_random_schedules(gpu, seed):
+    """random batch sizes (empty ones included), collects at random distances, direct calls and resets in between:
+    the pipelined entry point is the same stream as a plain sequence of process() calls -- for chains whose counts
+    depend on the stream position in every way (decimation remainder, resampler phase, FFT-block quantisation)"""
+    from iq_tool_amd.chain import PinnedBuffer
+    rng = np.random.default_rng(7000 + seed)
+    kws = [dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3),
+           dict(in_format="cu8", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=250e3, shift_hz=-1e5, dc_block=True),
+           dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6,
+                filters=(("passband", 158.5e3, 113e3),), filter_taps=257, filter_impl="fft"),
+           dict(in_format="cs16", out_format="cf32", input_rate_hz=8e3, target_rate_hz=20e3)]
+    kw = kws[seed % len(kws)]
+    ch, ref = gpu.Chain(**kw), gpu.Chain(**kw)
+    depth = ch._lib.iqgpu_chain_pipeline_depth()
+    ibps, obps = ch.in_bytes, ch.out_bytes
+    nmax = 40000
+    raw = synth.raw_stream(nmax * 40, kw["input_rate_hz"], 70 + seed, kw["in_format"]).view(np.uint8)
+    ins = [PinnedBuffer(nmax * ibps) for _ in range(depth)]
+    outs = [PinnedBuffer(ch.max_out_frames(nmax) * obps) for _ in range(depth)]
+    flight, pos, got, want = [], 0, [], []
+
+    def collect_one():
+        slot, t, cnt = flight.pop(0)
+        ch.collect(t)
+        got.append(outs[slot].array[:cnt * obps].copy())
+
+    for step in range(30):
+        n = int(rng.choice([0, 1, 7, 4096, 16384, int(rng.integers(1, nmax))]))
+        if pos + n > nmax * 40:
+            break
+        chunk = raw[pos * ibps:(pos + n) * ibps]
+        pos += n
+        action = rng.random()
+        if action < 0.75:
+            if len(flight) == depth or (flight and rng.random() < 0.3):
+                collect_one()
+            slot = next(i for i in range(depth) if all(f[0] != i for f in flight))
+            ins[slot].array[:n * ibps] = chunk
+            cnt, t = ch.submit(ins[slot].ptr, n, outs[slot].ptr, outs[slot].nbytes)
+            flight.append((slot, t, cnt))
+            want.append(ref.process(chunk).view(np.uint8))
+            assert cnt * obps == want[-1].size, (step, n)
+        elif action < 0.92:
+            while flight:                                   # a direct call returns its bytes at once: everything older first
+                collect_one()
+            got.append(ch.process(chunk).view(np.uint8))
+            want.append(ref.process(chunk).view(np.uint8))
+        else:
+            while flight:
+                collect_one()
+            ch.reset(); ref.reset()
+    while flight:
+        collect_one()
+    g = np.concatenate(got) if got else np.zeros(0, np.uint8)
+    w = np.concatenate(want) if want else np.zeros(0, np.uint8)
+    assert g.size == w.size
+    if kw.get("dc_block") or kw.get("filters"):
+        a, b = g.view(_NPV[kw["out_format"]]), w.view(_NPV[kw["out_format"]])
+        if a.dtype == np.float32:
+            assert np.abs(a - b).max() <= 2e-6
+        else:
+            assert np.abs(a.astype(np.int64) - b.astype(np.int64)).max() <= 1
+    else:
+        assert np.array_equal(g, w)
+
+
+_NPV = {"cs16": np.int16, "cf32": np.float32, "cu8": np.uint8}
+
+
 def test_iq_factors_changed_between_calls(gpu, oracle):
     # what the optimiser thread does (src/iq_correct.c:141-152 reads the factors once per chunk)
     raw = synth.raw_stream(1 << 18, 2.4e6, 9, "cs16")
