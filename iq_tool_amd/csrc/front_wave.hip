@@ -492,7 +492,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 bool hit[4];
                 unsigned row[4];
                 tap_rows(w, Pl, step, hit, row);
-                v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+                v2f y[4];                                    // started by pk_fma_pp16's first products
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     v2f ta[7], tb[7];

@@ -153,12 +153,19 @@ __device__ __forceinline__ void pk_fma_hb40(v2f acc[4], const v2f *t, const v2f 
     "v_pk_fma_f32 %[yb], %[" TB "], %[" HC "], %[yb] op_sel_hi:[0,1,1]\n\t"              \
     "v_pk_fma_f32 %[ya], %[" TA "], %[" HA "], %[ya] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
     "v_pk_fma_f32 %[yb], %[" TB "], %[" HB_ "], %[yb] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-// tap pairs 0..3 of both slots against g[0..8]; pair i reads g[6 - 2i .. 8 - 2i]
+// the same with ya, yb STARTED by the first two products (no zero-initialised accumulators: 8 v_mov per tile;
+// a sum of products that are all -0 now ends as -0 instead of +0, nothing else changes)
+#define IQGPU_PP4_FIRST(TA, TB, HA, HB_, HC)                                            \
+    "v_pk_mul_f32 %[ya], %[" TA "], %[" HB_ "] op_sel_hi:[0,1]\n\t"                      \
+    "v_pk_mul_f32 %[yb], %[" TB "], %[" HC "] op_sel_hi:[0,1]\n\t"                       \
+    "v_pk_fma_f32 %[ya], %[" TA "], %[" HA "], %[ya] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 %[yb], %[" TB "], %[" HB_ "], %[yb] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+// tap pairs 0..3 of both slots against g[0..8]; pair i reads g[6 - 2i .. 8 - 2i]; ya, yb are outputs only
 __device__ __forceinline__ void pk_fma_pp16(v2f &ya, v2f &yb, const v2f *ta, const v2f *tb, const v2f *g)
 {
-    asm(IQGPU_PP4("p0", "q0", "g6", "g7", "g8") IQGPU_PP4("p1", "q1", "g4", "g5", "g6")
+    asm(IQGPU_PP4_FIRST("p0", "q0", "g6", "g7", "g8") IQGPU_PP4("p1", "q1", "g4", "g5", "g6")
         IQGPU_PP4("p2", "q2", "g2", "g3", "g4") IQGPU_PP4("p3", "q3", "g0", "g1", "g2")
-        : [ya] "+v"(ya), [yb] "+v"(yb)
+        : [ya] "=&v"(ya), [yb] "=&v"(yb)
         : [p0] "v"(ta[0]), [p1] "v"(ta[1]), [p2] "v"(ta[2]), [p3] "v"(ta[3]),
           [q0] "v"(tb[0]), [q1] "v"(tb[1]), [q2] "v"(tb[2]), [q3] "v"(tb[3]),
           [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]),
