@@ -526,7 +526,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
+                    if (FAST && !EDGE && !AGC) {
+                        // every lane packs every slot (a slot without an output holds junk that the compaction below
+                        // never picks): no EXEC games, no zero-initialised words
+                        pk[r] = pack_cs16(cf2{y[r].x, y[r].y});
+                    } else if (hit[r] && (!EDGE || (uint32_t)(4 * lane + r) < q_lim)) {
                         v2f yy = y[r];
                         if (!FAST && a.pnco_mode != 0) yy = pk_cmul(yy, nco_phasor2(w.nco, pth0 + kk * a.pnco_dtheta));
                         if (AGC) {
