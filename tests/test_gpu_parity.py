@@ -1044,7 +1044,7 @@ def test_submit_defers_kernels_but_not_semantics(gpu, oracle):
     assert tail.size == want_tail.size and np.abs(tail - want_tail).max() <= TOL
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(max(12, int(_os.environ.get("IQGPU_FUZZ_SEEDS", "0")) // 50)))
 def test_submit_collect_random_schedules(gpu, seed):
     """random batch sizes (empty ones included), collects at random distances, direct calls and resets in between:
     the pipelined entry point is the same stream as a plain sequence of process() calls -- for chains whose counts
