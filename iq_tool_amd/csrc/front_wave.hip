@@ -183,7 +183,7 @@ __device__ __forceinline__ double wave_max_d(double m)
     return m;
 }
 
-template <int BPS, bool EDGE, bool FAST, bool S0, bool AGC = false>
+template <int BPS, bool EDGE, bool FAST, bool S0, bool AGC = false, bool NONCO = false>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
                                           const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
@@ -218,7 +218,9 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     RawChunk nxt[2];
     // ... and of its eight NCO phasors: the table lookups depend on the stream position only, so they are
     // issued a tile ahead too and their LDS round trip never sits on the tile's critical path
-    const bool nco_on = !EDGE && (FAST || a.nco_mode != 0);
+    // NONCO (FAST only): the same preset shape without a shift -- no mixer at all; the samples stay unnormalised in LDS
+    // and the 2^-15 rides on the half-band taps (launch_front_s1 scales hb0; exact, a power of two)
+    const bool nco_on = !EDGE && ((FAST && !NONCO) || (!FAST && a.nco_mode != 0));
     v2f cs_n[2][4];
     auto nco_lookup = [&](int64_t tile_first) {
 #pragma unroll
@@ -383,7 +385,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                             v.x = re * a.iq_magp1;
                             v.y = fmaf(a.iq_phase, re, v.y);
                         }
-                        if (FAST || a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
+                        if (FAST && NONCO) { v.x *= 1.0f / 32768.0f; v.y *= 1.0f / 32768.0f; }      // what hist_out keeps: normalised
+                        else if (FAST || a.nco_mode != 0) v = cmul_tab(v, nco_phasor(w.nco, th));
                         const int64_t back = a.frames_in - (j0 + l4 + s);   // 1 .. hist_cap for kept frames
                         if (emit && back <= (int64_t)a.hist_cap) a.hist_out[(int64_t)a.hist_cap - back] = v;
                         x[c][s] = v;
@@ -408,7 +411,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int off = woff + 32 * c * kRowB;
-                if (FAST && EDGE) {           // the scalar path mixes with the full table (and keeps its samples for hist_out)
+                if (FAST && EDGE && NONCO) {  // history and new samples alike are normalised here: back to the LDS domain
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[c][q].x *= 32768.0f; x[c][q].y *= 32768.0f; }
+                } else if (FAST && EDGE) {    // the scalar path mixes with the full table (and keeps its samples for hist_out)
                     x[c][1].x *= 0.5f; x[c][1].y *= 0.5f; x[c][3].x *= 0.5f; x[c][3].y *= 0.5f;
                 }
                 *(float4 *)(XE + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
@@ -442,7 +448,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             }
             const char *wo = XO + lane * kRowB;
             const float4 o0 = ld4(wo + 2 * kRowB + 16), o1 = ld4(wo + 3 * kRowB);
-            const float hc = FAST ? 1.0f : 0.5f;          // FAST: the odd stream is stored as 0.5 x
+            const float hc = FAST ? (NONCO ? 0.5f / 32768.0f : 1.0f) : 0.5f;   // FAST: the odd stream is stored as 0.5 x (NONCO: as 2^15 x)
             v2f acc[4] = {v2f{hc * o0.x, hc * o0.y}, v2f{hc * o0.z, hc * o0.w},
                           v2f{hc * o1.x, hc * o1.y}, v2f{hc * o1.z, hc * o1.w}};
             if (!EDGE) __builtin_amdgcn_s_setprio(0);
@@ -615,7 +621,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 //      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
 //      AGC: output AGC fused (gain before the pack, exact per-chunk peaks); those of the run-time-switched kernels run 12 waves
-template <int BPS, bool FAST, bool S0 = false, bool AGC = false>
+template <int BPS, bool FAST, bool S0 = false, bool AGC = false, bool NONCO = false>
 __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
 {
     if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
@@ -673,21 +679,23 @@ __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThrea
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
         const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);   // DcGeom mode 1 order
-        run_tiles<BPS, true, FAST, S0, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        run_tiles<BPS, true, FAST, S0, AGC, NONCO>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
         const int seg = (int)(a.w_n_edge1 + r);
-        if (BPS != 0) run_tiles<BPS, false, FAST, S0, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        if (BPS != 0) run_tiles<BPS, false, FAST, S0, AGC, NONCO>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
+// the specialised instantiations: the cs16 NRSC-5 preset shape, with a pre-resample shift or with none at all
 static bool front_s1_fast_shape(const FrontArgs &a)
 {
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
-           !a.dc_enable && a.nco_mode != 0 && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
+           !a.dc_enable && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
 }
+static bool front_s1_fast_nonco(const FrontArgs &a) { return front_s1_fast_shape(a) && a.nco_mode == 0; }
 // the fused AGC exists for the 8- and 16-bit-input instantiations, with or without the half-band stage (the shipped
 // NRSC-5 presets: cs16 / cu8 in, cs16 or cu8 out, shift or none); chunks at least a tile long (one boundary per tile)
 bool front_s1_agc_fusable(const FrontArgs &a)
@@ -709,9 +717,15 @@ static bool front_s1_sixteen(const FrontArgs &a)
 }
 int front_s1_waves(const FrontArgs &a) { return front_s1_sixteen(a) ? kS1Waves : kWaves; }
 
-hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
+hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
 {
-    const bool fast = front_s1_fast_shape(a);
+    const bool fast = front_s1_fast_shape(a_in), nonco = front_s1_fast_nonco(a_in);
+    FrontArgs a_scaled;
+    if (nonco) {                      // the cs16 normaliser rides on the half-band taps (exact: a power of two)
+        a_scaled = a_in;
+        for (float &h : a_scaled.hb0) h *= 1.0f / 32768.0f;
+    }
+    const FrontArgs &a = nonco ? a_scaled : a_in;
     const int waves = front_s1_sixteen(a) ? kS1Waves : kWaves;
     const size_t lds = (size_t)kTabLds + (size_t)waves * kWaveLds;
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
@@ -724,12 +738,13 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_S1X(BPS, FAST, S0, AGC)                                                                          \
+#define IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, NONCO)                                                                   \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0, AGC>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC>), dim3(grid), dim3(waves * 64), lds, s, a);                \
+        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0, AGC, NONCO>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC, NONCO>), dim3(grid), dim3(waves * 64), lds, s, a);         \
     } while (0)
+#define IQGPU_LAUNCH_S1X(BPS, FAST, S0, AGC) IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, false)
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0) IQGPU_LAUNCH_S1X(BPS, FAST, S0, false)
     if (a.agc_fused && !(cls == 2 || cls == 4 || (cls == 8 && a.S == 1))) return hipErrorInvalidValue;     // (front_s1_agc_fusable)
     if (a.S == 0) {
@@ -742,6 +757,8 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     }
     else if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, false, true);
     else if (cls == 2) IQGPU_LAUNCH_S1(2, false, false);
+    else if (cls == 4 && nonco && a.agc_fused) IQGPU_LAUNCH_S1Y(4, true, false, true, true);
+    else if (cls == 4 && nonco) IQGPU_LAUNCH_S1Y(4, true, false, false, true);
     else if (cls == 4 && fast && a.agc_fused) IQGPU_LAUNCH_S1X(4, true, false, true);
     else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
@@ -751,6 +768,7 @@ hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s)
     else IQGPU_LAUNCH_S1(0, false, false);
 #undef IQGPU_LAUNCH_S1
 #undef IQGPU_LAUNCH_S1X
+#undef IQGPU_LAUNCH_S1Y
     return hipGetLastError();
 }
 

@@ -698,6 +698,39 @@ def test_fast_and_generic_front_kernels_agree(gpu, oracle, monkeypatch):
     assert np.abs(fast - want).max() <= TOL and np.abs(slow - want).max() <= TOL
 
 
+@pytest.mark.parametrize("agc", [False, True])
+def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, monkeypatch, agc):
+    """the shipped cs16-fm-nrsc5 preset carries no shift (iq_tool_presets.conf:216-222): k_front_s1<4, fast, .., nonco> has no
+    mixer at all, keeps the samples unnormalised in LDS and carries the 2^-15 on the half-band taps.  Power-of-two scaling
+    commutes with every rounding: the bytes must equal those of the run-time-switched kernel, call splits included."""
+    n = 16384 * 330 + 16384 // 2 + 6           # 2.25 s of output: the AGC scans, locks and runs fused
+    raw = synth.raw_stream(n, 2.4e6, 24, "cs16")
+    kw = dict(NRSC5, shift_hz=0.0, agc=agc)
+    cuts = [0, 16384 * 7, 16384 * 7 + 16384 * 260, 16384 * 300, n]
+    def run():
+        ch = gpu.Chain(**kw)
+        return np.concatenate([ch.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]), (ch.agc_state() if agc else None)
+    fast, st_fast = run()
+    monkeypatch.setenv("IQGPU_NO_FAST", "1")
+    slow, st_slow = run()
+    monkeypatch.delenv("IQGPU_NO_FAST")
+    assert np.array_equal(fast, slow)
+    if agc:
+        assert st_fast == st_slow and st_fast["locked"]
+    och = oracle.Chain(**kw)
+    want = np.concatenate([och.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    int_close(fast, want, min_same=0.95 if agc else 0.97)
+    # one frame, odd sizes, a reset in between: the edge tiles of the instantiation
+    ch, och = gpu.Chain(**kw), oracle.Chain(**kw)
+    for a, b in ((0, 1), (1, 3), (3, 1000), (1000, 70001)):
+        g, w = ch.process(raw[2 * a:2 * b]), och.process(raw[2 * a:2 * b])
+        assert g.size == w.size
+        if w.size:
+            int_close(g, w, min_same=0.9)
+    ch.reset(); och.reset()
+    int_close(ch.process(raw[:2 * 50000]), och.process(raw[:2 * 50000]), min_same=0.95)
+
+
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
 def test_one_stage_chain_all_input_formats(gpu, oracle, fmt):
     """the fast path's vector loaders (2, 4, 8 bytes per frame) and its scalar fallback"""
