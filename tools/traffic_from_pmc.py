@@ -30,7 +30,7 @@ def main():
     write, nw = avg(sys.argv[2], "WRITE_SIZE")
     log2_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 28
     traffic = (2.0 * fetch + write) * 1024.0
-    out = dict(kernel="k_front_s1<4, true, false, false>", kernel_sha=bench.kernel_sha(), log2_frames=log2_frames,
+    out = dict(kernel="k_front_s1<4, true, false, false, false>", kernel_sha=bench.kernel_sha(), log2_frames=log2_frames,
                fetch_size_KiB=fetch, write_size_KiB=write, dispatches=[nf, nw], traffic_bytes=traffic,
                rule="2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per launch, separate --pmc passes")
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
