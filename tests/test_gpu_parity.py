@@ -779,6 +779,23 @@ def test_golden_nrsc5_fixture(gpu):
 # --------------------------------------------------------------------------------------------
 # BASELINE.json full size (2^28 frames): size-independent properties
 # --------------------------------------------------------------------------------------------
+def test_full_size_output_bytes_unchanged_since_round_1(gpu):
+    """the round-1 review asked that kernel work leave the 2^28-frame cs16 output bit-identical: its sha256, taken with the
+    round-1 library (commit e84ecb7) and re-taken with every later kernel, on bench.py's input (tools/sha_out.py)"""
+    import hashlib
+    from iq_tool_amd.chain import DeviceBuffer
+    frames = 1 << 28
+    raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 1, "cs16"), frames >> 22)
+    ch = gpu.Chain(**NRSC5)
+    d_in = DeviceBuffer(raw.nbytes); d_in.upload(raw)
+    d_out = DeviceBuffer(ch.max_out_frames(frames) * 4)
+    got = ch.process_device(d_in.ptr, frames, d_out.ptr, d_out.nbytes)
+    ch.synchronize()
+    assert got == 83235963
+    assert hashlib.sha256(d_out.download(got * 4).tobytes()).hexdigest() == "340e6d09428159f216202869e76f728f157ff0aa816d77fa4443c3672ded2ab6"
+    d_in.free(); d_out.free()
+
+
 def test_full_size_count_law_split_invariance_and_spot_parity(gpu, oracle):
     """configs[1] at its real size, device-resident: (1) frames_out obeys the closed form,
     (2) one call == two calls of ragged sizes (checksum of the output bytes), (3) the first 2^25 frames'
