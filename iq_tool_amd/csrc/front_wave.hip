@@ -68,6 +68,12 @@ __device__ __forceinline__ uint32_t pack_cs16(cf2 v)
     const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)p, (int)q);
     return __builtin_bit_cast(uint32_t, pk);
 }
+// cu8 / cs8: one frame as 16 bits (src/sample_convert.c:40-73, the arithmetic of pack_store)
+__device__ __forceinline__ uint32_t pack_b8(cf2 v, bool is_unsigned)
+{
+    if (is_unsigned) return pk_unsigned(v.x, 127.0f, 127.5f, 255.0f) | (pk_unsigned(v.y, 127.0f, 127.5f, 255.0f) << 8);
+    return ((unsigned)pk_signed(v.x, 127.0f, -128.0f, 127.0f) & 0xffu) | (((unsigned)pk_signed(v.y, 127.0f, -128.0f, 127.0f) & 0xffu) << 8);
+}
 __device__ __forceinline__ void pack_store_at(char *base, uint32_t idx, int fmt, cf2 v)
 {
     if (fmt == IQGPU_FMT_CS16) {
@@ -245,14 +251,28 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     // cs16 output of the streaming variant: a tile's four packed dwords are held in registers and
     // stored at the top of the NEXT iteration, right after the wait for the prefetched frames, so
     // that this wait (vmcnt(0)) only ever covers loads and stores issued a whole tile earlier
-    const bool defer = !EDGE && (FAST || a.out_fmt == IQGPU_FMT_CS16);
+    // ... and the 2-byte formats (cu8 / cs8: the cu8-nrsc5 presets) likewise: one store per slot was a third of that shape's time
+    const bool out_b8 = !FAST && (a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8);
+    const bool defer = !EDGE && (FAST || a.out_fmt == IQGPU_FMT_CS16 || out_b8);
     // A lane's outputs of a tile are consecutive (2 to 4 of them: one per 1 .. 2 half-band samples), so
     // they are compacted and leave as one 8-byte store plus at most one more, instead of four predicated
     // dword stores -- the CU's vector-memory issue path is one of the three pipes this kernel loads.
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
     uint32_t pend_c[4] = {0, 0, 0, 0}, pend_n0 = 0, pend_cnt = 0;
     char *pend_base = (char *)a.out;
+    typedef uint32_t u32a2 __attribute__((aligned(2)));
     auto flush_pending = [&]() {
+        if (out_b8) {
+            // 2-byte frames: the lane's 2 .. 4 outputs as one or two dwords at a 2-byte-aligned address, an odd one as a short
+            if (pend_cnt != 0) {
+                char *b = pend_base + 2u * pend_n0;
+                if (pend_cnt & 1u) *(uint16_t *)(b + 2u * (pend_cnt - 1u)) = (uint16_t)pend_c[pend_cnt == 1u ? 0 : 2];
+                if (pend_cnt >= 2u) *(u32a2 *)b = pend_c[0] | (pend_c[1] << 16);
+                if (pend_cnt == 4u) *(u32a2 *)(b + 4) = pend_c[2] | (pend_c[3] << 16);
+                pend_cnt = 0;
+            }
+            return;
+        }
         if (pend_cnt != 0) {
             char *b = pend_base + 4u * pend_n0;
             if (pend_cnt == 1) *(uint32_t *)b = pend_c[0];
@@ -548,7 +568,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                             else agc_m1 = fmax(agc_m1, m2);
                             yy = v2f{yy.x * agc_g, yy.y * agc_g};
                         }
-                        if (defer) pk[r] = pack_cs16(cf2{yy.x, yy.y});
+                        if (defer) pk[r] = out_b8 ? pack_b8(cf2{yy.x, yy.y}, a.out_fmt == IQGPU_FMT_CU8) : pack_cs16(cf2{yy.x, yy.y});
                         else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
