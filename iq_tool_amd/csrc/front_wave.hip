@@ -641,12 +641,20 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 //      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
 //      AGC: output AGC fused (gain before the pack, exact per-chunk peaks); those of the run-time-switched kernels run 12 waves
-template <int BPS, bool FAST, bool S0 = false, bool AGC = false, bool NONCO = false>
-__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC)) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a)
+//      VAR: 0 = as the flags say; 1 = FAST without a mixer (NONCO); 2, 3 = the cu8-nrsc5 preset shapes (S0, no shift, unit gain,
+//      no dc blocker / iq correction, cu8 out) from cu8 resp. cs16 input with their run-time switches resolved at compile time
+template <int BPS, bool FAST, bool S0 = false, bool AGC = false, int VAR = 0>
+__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || VAR >= 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
 {
+    constexpr bool NONCO = VAR == 1;
+    FrontArgs a = a_in;
+    if (VAR >= 2) {        // constants instead of arguments: the compiler folds every switch they feed (128 -> 93 VGPRs, -17 % time)
+        a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.nco_mode = 0; a.pnco_mode = 0;
+        a.in_fmt = VAR == 2 ? (int)IQGPU_FMT_CU8 : (int)IQGPU_FMT_CS16; a.out_fmt = IQGPU_FMT_CU8;
+    }
     if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool k16 = FAST || (BPS == 2 && !AGC);
+    constexpr bool k16 = FAST || (BPS == 2 && !AGC) || VAR >= 2;
     constexpr int kThr = k16 ? kS1Threads : kWThreads, kWv = k16 ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -727,9 +735,17 @@ bool front_s1_agc_fusable(const FrontArgs &a)
     return (a.S == 0 || a.S == 1) && (in8 || in16 || mid) && a.agc_chunk_frames >= ((int64_t)256 << a.agc_shift) && !getenv("IQGPU_AGC_NOFUSE");
 }
 
+// the cu8-nrsc5 preset shapes (iq_tool_presets.conf:190-214): 0.5 <= r < 1, nothing but unpack -> polyphase -> pack cu8
+static int front_s1_plain_var(const FrontArgs &a)
+{
+    if (a.S != 0 || a.out_fmt != IQGPU_FMT_CU8 || a.gain != 1.0f || a.iq_enable || a.dc_enable || a.nco_mode != 0 || a.pnco_mode != 0 ||
+        getenv("IQGPU_NO_FAST")) return 0;
+    return a.in_fmt == IQGPU_FMT_CU8 ? 2 : a.in_fmt == IQGPU_FMT_CS16 ? 3 : 0;
+}
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
 {
+    if (front_s1_plain_var(a) != 0) return true;
     // 4 waves per SIMD where the instantiation fits 128 VGPRs (nearly) without scratch: the specialised one,
     // and the 8-bit-input ones (2 - 4 spilled dwords; measured -8 % on the cu8-nrsc5 shape, -4 % on cu8 -> cs16).
     // The cs16 / cf32-input run-time-switched ones spill 7 - 21 dwords there and are faster with 12 waves.
@@ -758,16 +774,21 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, NONCO)                                                                   \
+#define IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, VAR)                                                                     \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0, AGC, NONCO>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC, NONCO>), dim3(grid), dim3(waves * 64), lds, s, a);         \
+        { const hipError_t e = cache.ensure((const void *)k_front_s1<BPS, FAST, S0, AGC, VAR>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_s1<BPS, FAST, S0, AGC, VAR>), dim3(grid), dim3(waves * 64), lds, s, a);         \
     } while (0)
-#define IQGPU_LAUNCH_S1X(BPS, FAST, S0, AGC) IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, false)
+#define IQGPU_LAUNCH_S1X(BPS, FAST, S0, AGC) IQGPU_LAUNCH_S1Y(BPS, FAST, S0, AGC, 0)
 #define IQGPU_LAUNCH_S1(BPS, FAST, S0) IQGPU_LAUNCH_S1X(BPS, FAST, S0, false)
     if (a.agc_fused && !(cls == 2 || cls == 4 || (cls == 8 && a.S == 1))) return hipErrorInvalidValue;     // (front_s1_agc_fusable)
-    if (a.S == 0) {
+    const int pvar = front_s1_plain_var(a);
+    if (pvar == 2 && a.agc_fused) IQGPU_LAUNCH_S1Y(2, false, true, true, 2);
+    else if (pvar == 2) IQGPU_LAUNCH_S1Y(2, false, true, false, 2);
+    else if (pvar == 3 && a.agc_fused) IQGPU_LAUNCH_S1Y(4, false, true, true, 3);
+    else if (pvar == 3) IQGPU_LAUNCH_S1Y(4, false, true, false, 3);
+    else if (a.S == 0) {
         if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, true, true);
         else if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);
         else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, true, true);
@@ -777,8 +798,8 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
     }
     else if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, false, true);
     else if (cls == 2) IQGPU_LAUNCH_S1(2, false, false);
-    else if (cls == 4 && nonco && a.agc_fused) IQGPU_LAUNCH_S1Y(4, true, false, true, true);
-    else if (cls == 4 && nonco) IQGPU_LAUNCH_S1Y(4, true, false, false, true);
+    else if (cls == 4 && nonco && a.agc_fused) IQGPU_LAUNCH_S1Y(4, true, false, true, 1);
+    else if (cls == 4 && nonco) IQGPU_LAUNCH_S1Y(4, true, false, false, 1);
     else if (cls == 4 && fast && a.agc_fused) IQGPU_LAUNCH_S1X(4, true, false, true);
     else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);

@@ -698,6 +698,36 @@ def test_fast_and_generic_front_kernels_agree(gpu, oracle, monkeypatch):
     assert np.abs(fast - want).max() <= TOL and np.abs(slow - want).max() <= TOL
 
 
+@pytest.mark.parametrize("in_format", ["cu8", "cs16"])
+@pytest.mark.parametrize("agc", [False, True])
+def test_cu8_preset_shapes_have_their_own_instantiations(gpu, oracle, monkeypatch, in_format, agc):
+    """cu8-nrsc5 (iq_tool_presets.conf:190-196): any 2.4 MS/s source -> cu8 at 1 488 375 Hz, no shift.  k_front_s1<.., VAR = 2 / 3>
+    are the run-time-switched S0 kernels with their arguments replaced by constants: same arithmetic, same bytes."""
+    n = 16384 * 330 + 16384 // 2 + 6           # 2.25 s of input = 2.25 s of output: the AGC scans, locks and runs fused
+    raw = synth.raw_stream(n, 2.4e6, 25, in_format)
+    kw = dict(in_format=in_format, out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, agc=agc)
+    cuts = [0, 16384 * 7, 16384 * 7 + 16384 * 160, 16384 * 300, n]
+    def run():
+        ch = gpu.Chain(**kw)
+        return np.concatenate([ch.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]), (ch.agc_state() if agc else None)
+    fast, st_fast = run()
+    monkeypatch.setenv("IQGPU_NO_FAST", "1")
+    slow, st_slow = run()
+    monkeypatch.delenv("IQGPU_NO_FAST")
+    assert np.array_equal(fast, slow)
+    if agc:
+        assert st_fast == st_slow and st_fast["locked"]
+    och = oracle.Chain(**kw)
+    want = np.concatenate([och.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    int_close(fast, want, min_same=0.95 if agc else 0.97)
+    ch, och = gpu.Chain(**kw), oracle.Chain(**kw)
+    for a, b in ((0, 1), (1, 3), (3, 1000), (1000, 70001)):
+        g, w = ch.process(raw[2 * a:2 * b]), och.process(raw[2 * a:2 * b])
+        assert g.size == w.size
+        if w.size:
+            int_close(g, w, min_same=0.9)
+
+
 @pytest.mark.parametrize("agc", [False, True])
 def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, monkeypatch, agc):
     """the shipped cs16-fm-nrsc5 preset carries no shift (iq_tool_presets.conf:216-222): k_front_s1<4, fast, .., nonco> has no

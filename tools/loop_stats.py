@@ -19,7 +19,7 @@ def main():
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                         "-S", "--cuda-device-only", "-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
-    name = "_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0ELb0EEEvNS_9FrontArgsE:"
+    name = "_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0ELi0EEEvNS_9FrontArgsE:"
     i0 = next(i for i, l in enumerate(lines) if l.startswith(name))
     i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith(".Lfunc_end"))
     loops = collections.defaultdict(list)      # header label -> instructions
