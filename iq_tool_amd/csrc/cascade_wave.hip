@@ -19,6 +19,7 @@
 // 64 >> k lanes: 112 packed FMAs and 344 LDS cycles per tile at K = 4 against 52 and about 200 now.
 // Semi-lengths 3 and 5 (what liquid designs for every stage but the last at 60 dB) are compiled in;
 // anything else stays on k_front.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -128,9 +129,62 @@ __device__ __forceinline__ void casc_stage_lin(const char *E, const char *O, int
     }
 }
 
+// ---- stage 0 on RAW frames (RAW0: 8-bit input, unit gain, no dc blocker / iq correction / mixer in front -- BASELINE
+// configs[3]).  The streaming waves keep the tile's frames in LDS as they came (2 bytes a frame: 1 KiB per tile instead of
+// 4 KiB of cf32, one 16-byte read per 8 frames instead of four) and a lane unpacks the 4M + 5 frames its four outputs need
+// in registers: the unpacked values are the ones unpack_chunk produces (cu8: (u - 127.5) / 128 as ONE fused multiply-add --
+// product and sum are exact, so the rounding of the two-step form never happens), the taps meet them in the order of
+// casc_stage, and the bits are the same.  Layout: byte 64 + 2 f holds frame f of the tile, bytes 0 .. 63 the last 32 frames
+// of the tile before.  Edge waves keep the cf32 rows (their history comes as processed samples).
+constexpr int kRawHist = 64;
+template <int M>
+__device__ __forceinline__ void casc_stage_raw8(const char *RB, int lane, int in_fmt, const float *taps_sgpr, v2f y[4])
+{
+    // even sample n / odd sample n of the lane (frames 8 lane + 2n, + 2n + 1), n = -(2M-1) .. 3: dword n of the lane's blocks
+    constexpr int NB = (2 * M - 1 + 3) / 4 + 1;            // 16-byte blocks: the lane's own and the NB - 1 before it
+    uint32_t W[4 * NB];
+    const char *wb = RB + kRawHist + (lane - (NB - 1)) * 16;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint4 v = *(const uint4 *)(wb + b * 16);
+        W[4 * b + 0] = v.x; W[4 * b + 1] = v.y; W[4 * b + 2] = v.z; W[4 * b + 3] = v.w;
+    }
+    const bool uns = in_fmt == IQGPU_FMT_CU8;
+    auto unpack = [&](uint32_t h) {                         // h: one frame in the low 16 bits
+        v2f x;
+        if (uns) {
+            x.x = __builtin_fmaf((float)(h & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f);
+            x.y = __builtin_fmaf((float)((h >> 8) & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f);
+        } else {
+            x.x = (float)(signed char)(h & 0xffu) * (1.0f / 128.0f);
+            x.y = (float)(signed char)((h >> 8) & 0xffu) * (1.0f / 128.0f);
+        }
+        return x;
+    };
+    constexpr int Z = 4 * (NB - 1);                         // dword index of n = 0
+    v2f E[2 * M + 3];                                       // E[k] = even sample n = k - (2M - 1)
+#pragma unroll
+    for (int k = 0; k < 2 * M + 3; ++k) E[k] = unpack(W[Z + k - (2 * M - 1)] & 0xffffu);
+    __builtin_amdgcn_s_setprio(0);
+    const v2f *hbp = (const v2f *)taps_sgpr;                // M SGPR pairs {h[2i], h[2i+1]}
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v2f o = unpack(W[Z + i - M] >> 16);           // O[j - M], j = 4 lane + i
+        y[i] = v2f{0.5f * o.x, 0.5f * o.y};
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < M; ++q2) {
+        const v2f tp = hbp[q2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, E[2 * M - 1 + i - 2 * q2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[2 * M - 1 + i - 2 * q2 - 1]);
+    }
+}
+
 struct CascLds { char *XE[kCascMaxK], *XO[kCascMaxK]; const cf2 *nco; };
 
-template <int BPS, bool EDGE>
+template <int BPS, bool EDGE, bool RAW0 = false>
 __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w, const int lane,
                                            const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
@@ -174,7 +228,15 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
 
         // ------------------------------------------------------------ pointwise -> stage 0 rows
         cf2 x[2][4];
-        if (!EDGE) {
+        if (RAW0 && !EDGE) {
+            // the frames go to LDS as they are; nothing stands between the unpack and stage 0 (launch_cascade checks)
+            __builtin_amdgcn_s_setprio(1);
+            *(uint2 *)(XE0 + kRawHist + 8 * lane) = make_uint2(nxt[0].w[0], nxt[0].w[1]);
+            *(uint2 *)(XE0 + kRawHist + 512 + 8 * lane) = make_uint2(nxt[1].w[0], nxt[1].w[1]);
+            const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
+            load_chunk<VB>(src, nxt[0]);
+            load_chunk<VB>(src + 256 * VB, nxt[1]);
+        } else if (!EDGE) {
             unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
             unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             {
@@ -264,11 +326,13 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
             }
         }
         if (!EDGE) __builtin_amdgcn_s_setprio(1);       // feeding the LDS pipe goes ahead of FMA runs (as in k_front_s1)
+        if (!(RAW0 && !EDGE)) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int off = woff + 32 * c * 16;
             *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
             *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+        }
         }
         __builtin_amdgcn_wave_barrier();
         if (nco_on) nco_lookup(i0 + kWTile);
@@ -282,7 +346,10 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 const int g_out = k == 0 ? 4 : casc_lin_g(k);     // outputs per lane of this stage
                 const int n_act = k == 0 ? 64 : casc_lin_lanes(k);
                 v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-                if (k == 0) {
+                if (k == 0 && RAW0 && !EDGE) {
+                    if (m == 3) casc_stage_raw8<3>(w.XE[0], lane, a.in_fmt, a.casc_taps[0], y);
+                    else        casc_stage_raw8<5>(w.XE[0], lane, a.in_fmt, a.casc_taps[0], y);
+                } else if (k == 0) {
                     if (m == 3) casc_stage<3>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
                     else        casc_stage<5>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
                 } else if (lane < n_act) {
@@ -291,7 +358,13 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 }
                 // slide this stage's history to the front of its buffers (one dword per lane)
                 float se = 0.f, so = 0.f;
-                if (k == 0) {
+                if (k == 0 && RAW0 && !EDGE) {
+                    // the last 32 frames of the tile become the history in front of the next one
+                    uint32_t hv = 0;
+                    if (lane < kRawHist / 4) hv = *(const uint32_t *)(w.XE[0] + 1024 + lane * 4);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < kRawHist / 4) *(uint32_t *)(w.XE[0] + lane * 4) = hv;
+                } else if (k == 0) {
                     const int Hk = casc_hist_rows(m);                  // Hk rows = 16 Hk bytes in each of the two planes
                     const int so_ = (lane >= 4 * Hk ? PS0 - 16 * Hk : 0) + lane * 4;
                     if (lane < 8 * Hk) { se = *(const float *)(w.XE[0] + 64 * 16 + so_); so = *(const float *)(w.XO[0] + 64 * 16 + so_); }
@@ -361,7 +434,7 @@ size_t cascade_wave_lds(const FrontArgs &a)
     return b;
 }
 
-template <int BPS>
+template <int BPS, bool RAW0 = false>
 __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -412,7 +485,7 @@ __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs 
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
         const int seg = (int)(a.w_n_edge1 + r);
-        if (BPS != 0) casc_tiles<BPS, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        if (BPS != 0) casc_tiles<BPS, false, RAW0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -450,13 +523,16 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 0; break;
     }
-#define IQGPU_LAUNCH_CASC(BPS)                                                                                         \
+#define IQGPU_LAUNCH_CASC(...)                                                                                         \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_cascade<BPS>, lds); if (e != hipSuccess) return e; }     \
-        hipLaunchKernelGGL(k_cascade<BPS>, dim3(grid), dim3(waves * 64), lds, s, a);                                   \
+        { const hipError_t e = cache.ensure((const void *)k_cascade<__VA_ARGS__>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_cascade<__VA_ARGS__>), dim3(grid), dim3(waves * 64), lds, s, a);                        \
     } while (0)
-    if (cls == 2) IQGPU_LAUNCH_CASC(2);
+    // 8-bit frames with nothing between the unpack and stage 0: the streaming waves keep them raw in LDS (casc_stage_raw8)
+    const bool raw0 = cls == 2 && a.gain == 1.0f && !a.dc_enable && !a.iq_enable && a.nco_mode == 0 && !getenv("IQGPU_NO_RAW0");
+    if (raw0) IQGPU_LAUNCH_CASC(2, true);
+    else if (cls == 2) IQGPU_LAUNCH_CASC(2);
     else if (cls == 4) IQGPU_LAUNCH_CASC(4);
     else if (cls == 8) IQGPU_LAUNCH_CASC(8);
     else IQGPU_LAUNCH_CASC(0);
