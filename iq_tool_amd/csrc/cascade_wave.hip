@@ -34,47 +34,56 @@ __host__ __device__ constexpr int casc_hist_rows(int m) { return (2 * m - 1 + 3)
 // One stage: 4 outputs per lane for lanes < n_act.
 //   out j = 0.5 O[j - M] + sum_q h[q] E[j - q], q < 2M   (E[i] = x[2i], O[i] = x[2i+1]; h pre-scaled by 0.5)
 // XE / XO: the stage's input rows; row (H + l) holds samples 4l .. 4l+3 of the tile, rows 0 .. H-1 the history.
+template <int M> struct CascWin0 { v2f E[4 * (casc_hist_rows(M) + 1)]; v2f O[8]; };
 template <int M>
-__device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int lane, const float *taps_sgpr, v2f y[4])
+__device__ __forceinline__ void casc_stage_load(const char *XE, const char *XO, int lane, CascWin0<M> &wn)
 {
     constexpr int H = casc_hist_rows(M);
     constexpr int PS = plane_stride(H + 64 + 1);      // two planes of 16-byte half rows (wave_common.hpp)
-    v2f E[4 * (H + 1)];
     const char *we = XE + lane * 16;
 #pragma unroll
     for (int r = 0; r <= H; ++r) {
         const float4 v0 = ld4(we + r * 16), v1 = ld4(we + r * 16 + PS);
-        E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
-        E[4 * r + 2] = v2f{v1.x, v1.y}; E[4 * r + 3] = v2f{v1.z, v1.w};
+        wn.E[4 * r + 0] = v2f{v0.x, v0.y}; wn.E[4 * r + 1] = v2f{v0.z, v0.w};
+        wn.E[4 * r + 2] = v2f{v1.x, v1.y}; wn.E[4 * r + 3] = v2f{v1.z, v1.w};
     }
     // centre taps: O[4l + i - M] = window index 4H + i - M  ->  rows r0, r0 + 1
     constexpr int c0 = 4 * H - M;                     // window index of i = 0
     constexpr int r0 = c0 / 4;
-    v2f O[8];
-    {
-        const char *wo = XO + (lane + r0) * 16;
-        const float4 v0 = ld4(wo), v1 = ld4(wo + PS);
-        O[0] = v2f{v0.x, v0.y}; O[1] = v2f{v0.z, v0.w}; O[2] = v2f{v1.x, v1.y}; O[3] = v2f{v1.z, v1.w};
-        if ((c0 & 3) != 0) {
-            const float4 u0 = ld4(wo + 16), u1 = ld4(wo + 16 + PS);
-            O[4] = v2f{u0.x, u0.y}; O[5] = v2f{u0.z, u0.w}; O[6] = v2f{u1.x, u1.y}; O[7] = v2f{u1.z, u1.w};
-        }
+    const char *wo = XO + (lane + r0) * 16;
+    const float4 v0 = ld4(wo), v1 = ld4(wo + PS);
+    wn.O[0] = v2f{v0.x, v0.y}; wn.O[1] = v2f{v0.z, v0.w}; wn.O[2] = v2f{v1.x, v1.y}; wn.O[3] = v2f{v1.z, v1.w};
+    if ((c0 & 3) != 0) {
+        const float4 u0 = ld4(wo + 16), u1 = ld4(wo + 16 + PS);
+        wn.O[4] = v2f{u0.x, u0.y}; wn.O[5] = v2f{u0.z, u0.w}; wn.O[6] = v2f{u1.x, u1.y}; wn.O[7] = v2f{u1.z, u1.w};
     }
-    __builtin_amdgcn_s_setprio(0);
+}
+template <int M>
+__device__ __forceinline__ void casc_stage_fma(const CascWin0<M> &wn, const float *taps_sgpr, v2f y[4])
+{
+    constexpr int H = casc_hist_rows(M);
+    constexpr int c0 = 4 * H - M;
     const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const v2f o = O[(c0 & 3) + i];
+        const v2f o = wn.O[(c0 & 3) + i];
         y[i] = v2f{0.5f * o.x, 0.5f * o.y};
     }
 #pragma unroll
     for (int q2 = 0; q2 < M; ++q2) {
         const v2f tp = hbp[q2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, E[4 * H + i - 2 * q2]);
+        for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, wn.E[4 * H + i - 2 * q2]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[4 * H + i - 2 * q2 - 1]);
+        for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, wn.E[4 * H + i - 2 * q2 - 1]);
     }
+}
+template <int M>
+__device__ __forceinline__ void casc_stage(const char *XE, const char *XO, int lane, const float *taps_sgpr, v2f y[4])
+{
+    CascWin0<M> wn;
+    casc_stage_load<M>(XE, XO, lane, wn);
+    casc_stage_fma<M>(wn, taps_sgpr, y);
 }
 
 // ---- stages k >= 1: linear even / odd arrays.  E[hs + i] / O[ho + i] hold samples 2i / 2i+1 of the tile, the hs / ho
@@ -86,47 +95,59 @@ __host__ __device__ constexpr int casc_lin_lanes(int k) { return (256 >> k) / ca
 
 __device__ __forceinline__ v2f ld2(const char *p) { const float2 v = *(const float2 *)p; return v2f{v.x, v.y}; }
 
+template <int M, int G> struct CascWinLin { v2f W[G == 2 ? 2 * M + 2 : 2 * M]; v2f o[2]; };
 template <int M, int G>
-__device__ __forceinline__ void casc_stage_lin(const char *E, const char *O, int lane, const float *taps_sgpr, v2f y[2])
+__device__ __forceinline__ void casc_stage_lin_load(const char *E, const char *O, int lane, CascWinLin<M, G> &wn)
 {
     constexpr int HS = casc_lin_hs(M), HO = casc_lin_ho(M);
-    const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
     if (G == 2) {
         // outputs 2l, 2l+1: E[HS + 2l - (2M-1) .. HS + 2l + 1] = array entries 2l + 1 .. 2l + 2M + 1 -> 16-byte reads from entry 2l
-        v2f W[2 * M + 2];
         const char *we = E + lane * 16;
 #pragma unroll
         for (int r = 0; r <= M; ++r) {
             const float4 v = ld4(we + r * 16);
-            W[2 * r] = v2f{v.x, v.y}; W[2 * r + 1] = v2f{v.z, v.w};
+            wn.W[2 * r] = v2f{v.x, v.y}; wn.W[2 * r + 1] = v2f{v.z, v.w};
         }
+        wn.o[0] = ld2(O + (HO + 2 * lane - M) * 8); wn.o[1] = ld2(O + (HO + 2 * lane + 1 - M) * 8);
+    } else {
+        // output l: E[l - (2M-1) .. l] = array entries l + 1 .. l + 2M (8-byte reads, consecutive lanes consecutive words)
+        const char *we = E + (lane + HS - (2 * M - 1)) * 8;
+#pragma unroll
+        for (int i = 0; i < 2 * M; ++i) wn.W[i] = ld2(we + i * 8);
+        wn.o[0] = ld2(O + (HO + lane - M) * 8);
+    }
+}
+template <int M, int G>
+__device__ __forceinline__ void casc_stage_lin_fma(const CascWinLin<M, G> &wn, const float *taps_sgpr, v2f y[2])
+{
+    constexpr int HS = casc_lin_hs(M);
+    const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
+    if (G == 2) {
         // W[i] = array entry 2l + i = E index 2l + i - HS; output j = 2l + g uses E[j - q] = W[HS + g - q]
-        const v2f o0 = ld2(O + (HO + 2 * lane - M) * 8), o1 = ld2(O + (HO + 2 * lane + 1 - M) * 8);
-        __builtin_amdgcn_s_setprio(0);
-        y[0] = v2f{0.5f * o0.x, 0.5f * o0.y}; y[1] = v2f{0.5f * o1.x, 0.5f * o1.y};
+        y[0] = v2f{0.5f * wn.o[0].x, 0.5f * wn.o[0].y}; y[1] = v2f{0.5f * wn.o[1].x, 0.5f * wn.o[1].y};
 #pragma unroll
         for (int q2 = 0; q2 < M; ++q2) {
             const v2f tp = hbp[q2];
-            pk_fma_lo_s(y[0], tp, W[HS - 2 * q2]);     pk_fma_lo_s(y[1], tp, W[HS + 1 - 2 * q2]);
-            pk_fma_hi_s(y[0], tp, W[HS - 2 * q2 - 1]); pk_fma_hi_s(y[1], tp, W[HS - 2 * q2]);
+            pk_fma_lo_s(y[0], tp, wn.W[HS - 2 * q2]);     pk_fma_lo_s(y[1], tp, wn.W[HS + 1 - 2 * q2]);
+            pk_fma_hi_s(y[0], tp, wn.W[HS - 2 * q2 - 1]); pk_fma_hi_s(y[1], tp, wn.W[HS - 2 * q2]);
         }
     } else {
-        // output l: E[l - (2M-1) .. l] = array entries l + 1 .. l + 2M (8-byte reads, consecutive lanes consecutive words)
-        v2f W[2 * M];
-        const char *we = E + (lane + HS - (2 * M - 1)) * 8;
-#pragma unroll
-        for (int i = 0; i < 2 * M; ++i) W[i] = ld2(we + i * 8);
-        const v2f o = ld2(O + (HO + lane - M) * 8);
-        __builtin_amdgcn_s_setprio(0);
-        y[0] = v2f{0.5f * o.x, 0.5f * o.y};
+        y[0] = v2f{0.5f * wn.o[0].x, 0.5f * wn.o[0].y};
         // W[i] = E[l - (2M-1) + i]; tap q multiplies E[l - q] = W[2M - 1 - q]
 #pragma unroll
         for (int q2 = 0; q2 < M; ++q2) {
             const v2f tp = hbp[q2];
-            pk_fma_lo_s(y[0], tp, W[2 * M - 1 - 2 * q2]);
-            pk_fma_hi_s(y[0], tp, W[2 * M - 2 - 2 * q2]);
+            pk_fma_lo_s(y[0], tp, wn.W[2 * M - 1 - 2 * q2]);
+            pk_fma_hi_s(y[0], tp, wn.W[2 * M - 2 - 2 * q2]);
         }
     }
+}
+template <int M, int G>
+__device__ __forceinline__ void casc_stage_lin(const char *E, const char *O, int lane, const float *taps_sgpr, v2f y[2])
+{
+    CascWinLin<M, G> wn;
+    casc_stage_lin_load<M, G>(E, O, lane, wn);
+    casc_stage_lin_fma<M, G>(wn, taps_sgpr, y);
 }
 
 // ---- stage 0 on RAW frames (RAW0: 8-bit input, unit gain, no dc blocker / iq correction / mixer in front -- BASELINE
@@ -137,22 +158,27 @@ __device__ __forceinline__ void casc_stage_lin(const char *E, const char *O, int
 // casc_stage, and the bits are the same.  Layout: byte 64 + 2 f holds frame f of the tile, bytes 0 .. 63 the last 32 frames
 // of the tile before.  Edge waves keep the cf32 rows (their history comes as processed samples).
 constexpr int kRawHist = 64;
+__host__ __device__ constexpr int casc_raw_nb(int m) { return (2 * m - 1 + 3) / 4 + 1; }   // 16-byte blocks: the lane's own and the ones before it
+template <int M> struct CascWinRaw { uint32_t W[4 * casc_raw_nb(M)]; };
 template <int M>
-__device__ __forceinline__ void casc_stage_raw8(const char *RB, int lane, int in_fmt, const float *taps_sgpr, v2f y[4])
+__device__ __forceinline__ void casc_stage_raw8_load(const char *RB, int lane, CascWinRaw<M> &wn)
 {
-    // even sample n / odd sample n of the lane (frames 8 lane + 2n, + 2n + 1), n = -(2M-1) .. 3: dword n of the lane's blocks
-    constexpr int NB = (2 * M - 1 + 3) / 4 + 1;            // 16-byte blocks: the lane's own and the NB - 1 before it
-    uint32_t W[4 * NB];
+    constexpr int NB = casc_raw_nb(M);
     const char *wb = RB + kRawHist + (lane - (NB - 1)) * 16;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const uint4 v = *(const uint4 *)(wb + b * 16);
-        W[4 * b + 0] = v.x; W[4 * b + 1] = v.y; W[4 * b + 2] = v.z; W[4 * b + 3] = v.w;
+        wn.W[4 * b + 0] = v.x; wn.W[4 * b + 1] = v.y; wn.W[4 * b + 2] = v.z; wn.W[4 * b + 3] = v.w;
     }
-    const bool uns = in_fmt == IQGPU_FMT_CU8;
+}
+template <int M, bool UNS>
+__device__ __forceinline__ void casc_stage_raw8_fma(const CascWinRaw<M> &wn, const float *taps_sgpr, v2f y[4])
+{
+    // even sample n / odd sample n of the lane (frames 8 lane + 2n, + 2n + 1), n = -(2M-1) .. 3: dword n of the lane's blocks
+    constexpr int NB = casc_raw_nb(M);
     auto unpack = [&](uint32_t h) {                         // h: one frame in the low 16 bits
         v2f x;
-        if (uns) {
+        if (UNS) {
             x.x = __builtin_fmaf((float)(h & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f);
             x.y = __builtin_fmaf((float)((h >> 8) & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f);
         } else {
@@ -164,12 +190,11 @@ __device__ __forceinline__ void casc_stage_raw8(const char *RB, int lane, int in
     constexpr int Z = 4 * (NB - 1);                         // dword index of n = 0
     v2f E[2 * M + 3];                                       // E[k] = even sample n = k - (2M - 1)
 #pragma unroll
-    for (int k = 0; k < 2 * M + 3; ++k) E[k] = unpack(W[Z + k - (2 * M - 1)] & 0xffffu);
-    __builtin_amdgcn_s_setprio(0);
+    for (int k = 0; k < 2 * M + 3; ++k) E[k] = unpack(wn.W[Z + k - (2 * M - 1)] & 0xffffu);
     const v2f *hbp = (const v2f *)taps_sgpr;                // M SGPR pairs {h[2i], h[2i+1]}
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const v2f o = unpack(W[Z + i - M] >> 16);           // O[j - M], j = 4 lane + i
+        const v2f o = unpack(wn.W[Z + i - M] >> 16);        // O[j - M], j = 4 lane + i
         y[i] = v2f{0.5f * o.x, 0.5f * o.y};
     }
 #pragma unroll
@@ -181,15 +206,26 @@ __device__ __forceinline__ void casc_stage_raw8(const char *RB, int lane, int in
         for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[2 * M - 1 + i - 2 * q2 - 1]);
     }
 }
+template <int M, bool UNS>
+__device__ __forceinline__ void casc_stage_raw8(const char *RB, int lane, const float *taps_sgpr, v2f y[4])
+{
+    CascWinRaw<M> wn;
+    casc_stage_raw8_load<M>(RB, lane, wn);
+    casc_stage_raw8_fma<M, UNS>(wn, taps_sgpr, y);
+}
 
 struct CascLds { char *XE[kCascMaxK], *XO[kCascMaxK]; const cf2 *nco; };
 
-template <int BPS, bool EDGE, bool RAW0 = false>
+// KT: 0 = stage count and semi-lengths from the arguments; 1 .. 4 = that many stages with liquid's 60 dB semi-lengths
+// (3 everywhere, 5 in the last one) resolved at compile time, so that the whole tile is straight-line code and the
+// window reads of all stages are issued together
+template <int BPS, bool EDGE, bool RAW0 = false, int KT = 0>
 __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w, const int lane,
                                            const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
 {
     constexpr int VB = BPS ? BPS : 4;
-    const int K = a.casc_K;
+    const int K = KT ? KT : a.casc_K;
+    auto stage_m = [&](int k) { return KT ? (k == KT - 1 ? 5 : 3) : a.m[k]; };
     // dc blocker (SPEC B.5): v[n] = x[n] + c v[n-1], y[n] = x[n] - (1 - c) v[n-1]; v carried as a wave-uniform pair
     float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
     bool dc_started = false;
@@ -199,7 +235,7 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
     }
     const bool unit_gain = a.gain == 1.0f;
     char *XE0 = w.XE[0], *XO0 = w.XO[0];
-    const int H0 = casc_hist_rows(a.m[0]);
+    const int H0 = casc_hist_rows(stage_m(0));
     const int PS0 = plane_stride(H0 + 64 + 1);
     const int woff = (H0 + (lane >> 1)) * 16 + (lane & 1) * PS0;       // this lane's write slot in stage 0 (plane lane & 1)
 
@@ -221,25 +257,32 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
         if (nco_on) nco_lookup(t_begin * kWTile);
     }
 
-    for (int64_t t = t_begin; t < t_emit1; ++t) {
+    // The stages run SKEWED by one tile each: what iteration t hands to LDS (the pointwise samples of tile t, stage k's
+    // outputs) is read at the top of iteration t + 1, so that an iteration is ONE LDS round trip -- every stage's window
+    // reads are issued together, then the FMAs, then all writes -- instead of a chain of K + 1.  Stage k works on tile
+    // t - 1 - k, the last stage's outputs of tile t - K go to memory; K more iterations drain the pipe (their pointwise
+    // input is never used by an emitted output: every stage is causal).
+    for (int64_t t = t_begin; t < t_emit1 + K; ++t) {
         const int64_t i0 = t * kWTile;
         const int64_t j0 = i0 - a.rem0;
-        const bool emit = t >= t_emit0;
+        const bool fresh = t < t_emit1;                   // tile t is part of this run (else: drain)
+        const bool emit = t >= t_emit0 && fresh;          // pointwise side effects (hist_out)
 
         // ------------------------------------------------------------ pointwise -> stage 0 rows
         cf2 x[2][4];
+        uint32_t rw[4] = {0u, 0u, 0u, 0u};
         if (RAW0 && !EDGE) {
             // the frames go to LDS as they are; nothing stands between the unpack and stage 0 (launch_cascade checks)
-            __builtin_amdgcn_s_setprio(1);
-            *(uint2 *)(XE0 + kRawHist + 8 * lane) = make_uint2(nxt[0].w[0], nxt[0].w[1]);
-            *(uint2 *)(XE0 + kRawHist + 512 + 8 * lane) = make_uint2(nxt[1].w[0], nxt[1].w[1]);
-            const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
-            load_chunk<VB>(src, nxt[0]);
-            load_chunk<VB>(src + 256 * VB, nxt[1]);
+            rw[0] = nxt[0].w[0]; rw[1] = nxt[0].w[1]; rw[2] = nxt[1].w[0]; rw[3] = nxt[1].w[1];
+            if (fresh) {
+                const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
+                load_chunk<VB>(src, nxt[0]);
+                load_chunk<VB>(src + 256 * VB, nxt[1]);
+            }
         } else if (!EDGE) {
             unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
             unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
-            {
+            if (fresh) {
                 const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
                 load_chunk<VB>(src, nxt[0]);
                 load_chunk<VB>(src + 256 * VB, nxt[1]);
@@ -325,63 +368,115 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 }
             }
         }
+        // ------------------------------------------------------------ the stages: reads and FMAs (tile t - 1 - k in stage k)
         if (!EDGE) __builtin_amdgcn_s_setprio(1);       // feeding the LDS pipe goes ahead of FMA runs (as in k_front_s1)
-        if (!(RAW0 && !EDGE)) {
+        if (nco_on && fresh) nco_lookup(i0 + kWTile);
+        v2f ys[kCascMaxK][4];
+        float se[kCascMaxK], so[kCascMaxK];
+        uint32_t hv = 0;
+        if constexpr (KT > 0) {
+            // compile-time stage list: every window (and every history tail) is read first, then all the FMAs run
+            constexpr int M0 = KT == 1 ? 5 : 3, M1 = KT == 2 ? 5 : 3, M2 = KT == 3 ? 5 : 3, M3 = 5;
+            CascWinRaw<M0> r0; CascWin0<M0> f0; CascWinLin<M1, 2> l1; CascWinLin<M2, 1> l2; CascWinLin<M3, 1> l3;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int off = woff + 32 * c * 16;
-            *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
-            *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+            for (int k = 0; k < kCascMaxK; ++k) {
+                se[k] = 0.f; so[k] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ys[k][i] = v2f{0.f, 0.f};
+            }
+            if (RAW0 && !EDGE) {
+                casc_stage_raw8_load<M0>(w.XE[0], lane, r0);
+                hv = *(const uint32_t *)(w.XE[0] + 1024 + (lane & (kRawHist / 4 - 1)) * 4);
+            } else {
+                casc_stage_load<M0>(w.XE[0], w.XO[0], lane, f0);
+                constexpr int Hk = casc_hist_rows(M0);
+                const int ls = lane < 8 * Hk ? lane : 8 * Hk - 1;
+                const int so_ = (ls >= 4 * Hk ? PS0 - 16 * Hk : 0) + ls * 4;
+                se[0] = *(const float *)(w.XE[0] + 64 * 16 + so_); so[0] = *(const float *)(w.XO[0] + 64 * 16 + so_);
+            }
+            auto tails = [&](int k, int m) {
+                const int hs = casc_lin_hs(m), ho = casc_lin_ho(m), pk_ = 256 >> k;
+                se[k] = *(const float *)(w.XE[k] + pk_ * 8 + (lane < 2 * hs ? lane : 2 * hs - 1) * 4);
+                so[k] = *(const float *)(w.XO[k] + pk_ * 8 + (lane < 2 * ho ? lane : 2 * ho - 1) * 4);
+            };
+            if (KT > 1) { casc_stage_lin_load<M1, 2>(w.XE[1], w.XO[1], lane, l1); tails(1, M1); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!EDGE) __builtin_amdgcn_s_setprio(0);
+            if (RAW0 && !EDGE) casc_stage_raw8_fma<M0, true>(r0, a.casc_taps[0], ys[0]);
+            else casc_stage_fma<M0>(f0, a.casc_taps[0], ys[0]);
+            if (KT > 1) casc_stage_lin_fma<M1, 2>(l1, a.casc_taps[1], ys[1]);
+            // (all four windows at once do not fit 128 registers: the late stages form a second group)
+            if (KT > 2) { casc_stage_lin_load<M2, 1>(w.XE[2], w.XO[2], lane, l2); tails(2, M2); }
+            if (KT > 3) { const int lc = lane < 32 ? lane : 31; casc_stage_lin_load<M3, 1>(w.XE[3], w.XO[3], lc, l3); tails(3, M3); }
+            if (KT > 2) casc_stage_lin_fma<M2, 1>(l2, a.casc_taps[2], ys[2]);
+            if (KT > 3) casc_stage_lin_fma<M3, 1>(l3, a.casc_taps[3], ys[3]);
+        } else {
+#pragma unroll
+        for (int k = 0; k < kCascMaxK; ++k) {
+            se[k] = 0.f; so[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ys[k][i] = v2f{0.f, 0.f};
+            if (k < K) {
+                const int m = stage_m(k);
+                const int n_act = k == 0 ? 64 : casc_lin_lanes(k);
+                const int lc = lane < n_act ? lane : n_act - 1;       // idle lanes read what the last active one reads
+                if (k == 0 && RAW0 && !EDGE) {
+                    if (BPS == 2) {          // RAW0 stands for "cu8" here, RAW0 with BPS 0 for "cs8" (launch_cascade)
+                        if (m == 3) casc_stage_raw8<3, true>(w.XE[0], lane, a.casc_taps[0], ys[0]);
+                        else        casc_stage_raw8<5, true>(w.XE[0], lane, a.casc_taps[0], ys[0]);
+                    }
+                    hv = *(const uint32_t *)(w.XE[0] + 1024 + (lane & (kRawHist / 4 - 1)) * 4);   // the last 32 frames: next tile's history (unconditional reads: straight-line code)
+                } else if (k == 0) {
+                    if (m == 3) casc_stage<3>(w.XE[0], w.XO[0], lane, a.casc_taps[0], ys[0]);
+                    else        casc_stage<5>(w.XE[0], w.XO[0], lane, a.casc_taps[0], ys[0]);
+                    const int Hk = casc_hist_rows(m);                  // Hk rows = 16 Hk bytes in each of the two planes
+                    const int ls = lane < 8 * Hk ? lane : 8 * Hk - 1;
+                    const int so_ = (ls >= 4 * Hk ? PS0 - 16 * Hk : 0) + ls * 4;
+                    se[0] = *(const float *)(w.XE[0] + 64 * 16 + so_); so[0] = *(const float *)(w.XO[0] + 64 * 16 + so_);
+                } else {
+                    if (k == 1) { if (m == 3) casc_stage_lin<3, 2>(w.XE[k], w.XO[k], lc, a.casc_taps[k], ys[k]); else casc_stage_lin<5, 2>(w.XE[k], w.XO[k], lc, a.casc_taps[k], ys[k]); }
+                    else        { if (m == 3) casc_stage_lin<3, 1>(w.XE[k], w.XO[k], lc, a.casc_taps[k], ys[k]); else casc_stage_lin<5, 1>(w.XE[k], w.XO[k], lc, a.casc_taps[k], ys[k]); }
+                    const int hs = casc_lin_hs(m), ho = casc_lin_ho(m), pk_ = 256 >> k;     // samples per parity and tile
+                    se[k] = *(const float *)(w.XE[k] + pk_ * 8 + (lane < 2 * hs ? lane : 2 * hs - 1) * 4);
+                    so[k] = *(const float *)(w.XO[k] + pk_ * 8 + (lane < 2 * ho ? lane : 2 * ho - 1) * 4);
+                }
+            }
         }
         }
         __builtin_amdgcn_wave_barrier();
-        if (nco_on) nco_lookup(i0 + kWTile);
-        __builtin_amdgcn_sched_barrier(0);
 
-        // ------------------------------------------------------------ the stages
+        // ------------------------------------------------------------ the writes: histories slide, every stage hands its tile on
+        if (!EDGE) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int k = 0; k < kCascMaxK; ++k) {
             if (k < K) {
-                const int m = a.m[k];
+                const int m = stage_m(k);
                 const int g_out = k == 0 ? 4 : casc_lin_g(k);     // outputs per lane of this stage
                 const int n_act = k == 0 ? 64 : casc_lin_lanes(k);
-                v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+                const v2f *y = ys[k];
+                // slide this stage's history to the front of its buffers (one dword per lane), then its new input behind it
                 if (k == 0 && RAW0 && !EDGE) {
-                    if (m == 3) casc_stage_raw8<3>(w.XE[0], lane, a.in_fmt, a.casc_taps[0], y);
-                    else        casc_stage_raw8<5>(w.XE[0], lane, a.in_fmt, a.casc_taps[0], y);
-                } else if (k == 0) {
-                    if (m == 3) casc_stage<3>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
-                    else        casc_stage<5>(w.XE[0], w.XO[0], lane, a.casc_taps[0], y);
-                } else if (lane < n_act) {
-                    if (k == 1) { if (m == 3) casc_stage_lin<3, 2>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); else casc_stage_lin<5, 2>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); }
-                    else        { if (m == 3) casc_stage_lin<3, 1>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); else casc_stage_lin<5, 1>(w.XE[k], w.XO[k], lane, a.casc_taps[k], y); }
-                }
-                // slide this stage's history to the front of its buffers (one dword per lane)
-                float se = 0.f, so = 0.f;
-                if (k == 0 && RAW0 && !EDGE) {
-                    // the last 32 frames of the tile become the history in front of the next one
-                    uint32_t hv = 0;
-                    if (lane < kRawHist / 4) hv = *(const uint32_t *)(w.XE[0] + 1024 + lane * 4);
-                    __builtin_amdgcn_wave_barrier();
                     if (lane < kRawHist / 4) *(uint32_t *)(w.XE[0] + lane * 4) = hv;
+                    *(uint2 *)(XE0 + kRawHist + 8 * lane) = make_uint2(rw[0], rw[1]);
+                    *(uint2 *)(XE0 + kRawHist + 512 + 8 * lane) = make_uint2(rw[2], rw[3]);
                 } else if (k == 0) {
-                    const int Hk = casc_hist_rows(m);                  // Hk rows = 16 Hk bytes in each of the two planes
+                    const int Hk = casc_hist_rows(m);
                     const int so_ = (lane >= 4 * Hk ? PS0 - 16 * Hk : 0) + lane * 4;
-                    if (lane < 8 * Hk) { se = *(const float *)(w.XE[0] + 64 * 16 + so_); so = *(const float *)(w.XO[0] + 64 * 16 + so_); }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 8 * Hk) { *(float *)(w.XE[0] + so_) = se; *(float *)(w.XO[0] + so_) = so; }
+                    if (lane < 8 * Hk) { *(float *)(w.XE[0] + so_) = se[0]; *(float *)(w.XO[0] + so_) = so[0]; }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int off = woff + 32 * c * 16;
+                        *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
+                        *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+                    }
                 } else {
-                    const int hs = casc_lin_hs(m), ho = casc_lin_ho(m), pk_ = 256 >> k;     // samples per parity and tile
-                    if (lane < 2 * hs) se = *(const float *)(w.XE[k] + pk_ * 8 + lane * 4);
-                    if (lane < 2 * ho) so = *(const float *)(w.XO[k] + pk_ * 8 + lane * 4);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 2 * hs) *(float *)(w.XE[k] + lane * 4) = se;
-                    if (lane < 2 * ho) *(float *)(w.XO[k] + lane * 4) = so;
+                    const int hs = casc_lin_hs(m), ho = casc_lin_ho(m);
+                    if (lane < 2 * hs) *(float *)(w.XE[k] + lane * 4) = se[k];
+                    if (lane < 2 * ho) *(float *)(w.XO[k] + lane * 4) = so[k];
                 }
-                if (!EDGE) __builtin_amdgcn_s_setprio(1);
                 if (k + 1 < K) {
                     // this stage's outputs -> the even / odd arrays of the next one (output j: even -> E[hs + j/2], odd -> O[ho + j/2])
-                    const int hn = casc_lin_hs(a.m[k + 1]), on = casc_lin_ho(a.m[k + 1]);
+                    const int hn = casc_lin_hs(stage_m(k + 1)), on = casc_lin_ho(stage_m(k + 1));
                     if (lane < n_act) {
                         if (g_out == 4) {
                             *(float4 *)(w.XE[k + 1] + (hn + 2 * lane) * 8) = make_float4(y[0].x, y[0].y, y[2].x, y[2].y);
@@ -394,9 +489,9 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                             *(float2 *)dst = make_float2(y[0].x, y[0].y);
                         }
                     }
-                } else if (emit && lane < n_act) {
-                    // the last stage's outputs go to memory: g_out contiguous cf32 per lane
-                    const int64_t o = (i0 >> K) + (int64_t)g_out * lane;
+                } else if (t - K >= t_emit0 && lane < n_act) {
+                    // the last stage's outputs (tile t - K) go to memory: g_out contiguous cf32 per lane
+                    const int64_t o = ((i0 - (int64_t)K * kWTile) >> K) + (int64_t)g_out * lane;
                     if (g_out == 4) {
                         if (!EDGE || o + 4 <= a.casc_n_out) {
                             float4 *dst = (float4 *)(a.casc_out + o);
@@ -413,9 +508,10 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                         if (!EDGE || o < a.casc_n_out) a.casc_out[o] = cf2{y[0].x, y[0].y};
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (!EDGE) __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -434,7 +530,7 @@ size_t cascade_wave_lds(const FrontArgs &a)
     return b;
 }
 
-template <int BPS, bool RAW0 = false>
+template <int BPS, bool RAW0 = false, int KT = 0>
 __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -479,13 +575,13 @@ __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs 
         // position of this run among the dc-carry segments: edge runs of the first region, streaming runs,
         // edge runs of the second region (kernels.hpp, DcGeom mode 1)
         const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);
-        casc_tiles<BPS, true>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        casc_tiles<BPS, true, false, KT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
         const int seg = (int)(a.w_n_edge1 + r);
-        if (BPS != 0) casc_tiles<BPS, false, RAW0>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        if (BPS != 0) casc_tiles<BPS, false, RAW0, KT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     }
 }
 
@@ -529,13 +625,24 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
         { const hipError_t e = cache.ensure((const void *)k_cascade<__VA_ARGS__>, lds); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL((k_cascade<__VA_ARGS__>), dim3(grid), dim3(waves * 64), lds, s, a);                        \
     } while (0)
-    // 8-bit frames with nothing between the unpack and stage 0: the streaming waves keep them raw in LDS (casc_stage_raw8)
-    const bool raw0 = cls == 2 && a.gain == 1.0f && !a.dc_enable && !a.iq_enable && a.nco_mode == 0 && !getenv("IQGPU_NO_RAW0");
-    if (raw0) IQGPU_LAUNCH_CASC(2, true);
-    else if (cls == 2) IQGPU_LAUNCH_CASC(2);
-    else if (cls == 4) IQGPU_LAUNCH_CASC(4);
-    else if (cls == 8) IQGPU_LAUNCH_CASC(8);
+    // cu8 frames with nothing between the unpack and stage 0: the streaming waves keep them raw in LDS (casc_stage_raw8)
+    const bool raw0 = a.in_fmt == IQGPU_FMT_CU8 && a.gain == 1.0f && !a.dc_enable && !a.iq_enable && a.nco_mode == 0 && !getenv("IQGPU_NO_RAW0");
+    // liquid's 60 dB semi-lengths (3 .. 3 5): stage count and lengths resolved at compile time (casc_tiles, KT)
+    int kt = a.casc_K;
+    for (int k = 0; k < a.casc_K; ++k) if (a.m[k] != (k == a.casc_K - 1 ? 5 : 3)) kt = 0;
+    if (getenv("IQGPU_NO_KT")) kt = 0;
+#define IQGPU_LAUNCH_CASC_KT(BPS, RAW)                                                                                \
+    do {                                                                                                              \
+        if (kt == 1) IQGPU_LAUNCH_CASC(BPS, RAW, 1); else if (kt == 2) IQGPU_LAUNCH_CASC(BPS, RAW, 2);               \
+        else if (kt == 3) IQGPU_LAUNCH_CASC(BPS, RAW, 3); else if (kt == 4) IQGPU_LAUNCH_CASC(BPS, RAW, 4);          \
+        else IQGPU_LAUNCH_CASC(BPS, RAW, 0);                                                                          \
+    } while (0)
+    if (raw0) IQGPU_LAUNCH_CASC_KT(2, true);
+    else if (cls == 2) IQGPU_LAUNCH_CASC_KT(2, false);
+    else if (cls == 4) IQGPU_LAUNCH_CASC_KT(4, false);
+    else if (cls == 8) IQGPU_LAUNCH_CASC_KT(8, false);
     else IQGPU_LAUNCH_CASC(0);
+#undef IQGPU_LAUNCH_CASC_KT
 #undef IQGPU_LAUNCH_CASC
     return hipGetLastError();
 }
