@@ -641,14 +641,18 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 //      256-frame tiles, the mixed samples go straight to the polyphase rows
 //      The FAST instantiation (121 VGPRs) and the 8-bit-input ones run 16 waves per workgroup, the others 12.
 //      AGC: output AGC fused (gain before the pack, exact per-chunk peaks); those of the run-time-switched kernels run 12 waves
-//      VAR: 0 = as the flags say; 1 = FAST without a mixer (NONCO); 2, 3 = the cu8-nrsc5 preset shapes (S0, no shift, unit gain,
+//      VAR: 0 = as the flags say; 1 = FAST without a mixer (NONCO); 4 = the last stage of a multi-stage chain (cf32 from k_cascade,
+//      nothing pointwise, cs16 / cu8 / cf32 out: 16 waves instead of 12); 2, 3 = the cu8-nrsc5 preset shapes (S0, no shift, unit gain,
 //      no dc blocker / iq correction, cu8 out) from cu8 resp. cs16 input with their run-time switches resolved at compile time
 template <int BPS, bool FAST, bool S0 = false, bool AGC = false, int VAR = 0>
 __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || VAR >= 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
 {
     constexpr bool NONCO = VAR == 1;
     FrontArgs a = a_in;
-    if (VAR >= 2) {        // constants instead of arguments: the compiler folds every switch they feed (128 -> 93 VGPRs, -17 % time)
+    if (VAR == 4) {        // the last stage behind k_cascade: cf32 in, nothing pointwise; cs16 or cu8 out, or cf32 for a filter behind it (VAR 4 with S0 = false only)
+        a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.nco_mode = 0; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CF32;
+        if (a.out_fmt != IQGPU_FMT_CU8 && a.out_fmt != IQGPU_FMT_CF32) a.out_fmt = IQGPU_FMT_CS16;
+    } else if (VAR >= 2) {        // constants instead of arguments: the compiler folds every switch they feed (128 -> 93 VGPRs, -17 % time)
         a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.nco_mode = 0; a.pnco_mode = 0;
         a.in_fmt = VAR == 2 ? (int)IQGPU_FMT_CU8 : (int)IQGPU_FMT_CS16; a.out_fmt = IQGPU_FMT_CU8;
     }
@@ -742,10 +746,16 @@ static int front_s1_plain_var(const FrontArgs &a)
         getenv("IQGPU_NO_FAST")) return 0;
     return a.in_fmt == IQGPU_FMT_CU8 ? 2 : a.in_fmt == IQGPU_FMT_CS16 ? 3 : 0;
 }
+// the last stage behind k_cascade (or any cf32 stream) with nothing pointwise in it and 16- or 8-bit frames out: VAR 4
+static bool front_s1_mid_var(const FrontArgs &a)
+{
+    return a.S == 1 && a.in_fmt == IQGPU_FMT_CF32 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable && a.nco_mode == 0 && a.pnco_mode == 0 &&
+           (a.out_fmt == IQGPU_FMT_CS16 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CF32) && !getenv("IQGPU_NO_FAST");
+}
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
 {
-    if (front_s1_plain_var(a) != 0) return true;
+    if (front_s1_plain_var(a) != 0 || front_s1_mid_var(a)) return true;
     // 4 waves per SIMD where the instantiation fits 128 VGPRs (nearly) without scratch: the specialised one,
     // and the 8-bit-input ones (2 - 4 spilled dwords; measured -8 % on the cu8-nrsc5 shape, -4 % on cu8 -> cs16).
     // The cs16 / cf32-input run-time-switched ones spill 7 - 21 dwords there and are faster with 12 waves.
@@ -804,6 +814,8 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
     else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);
+    else if (cls == 8 && front_s1_mid_var(a) && a.agc_fused) IQGPU_LAUNCH_S1Y(8, false, false, true, 4);
+    else if (cls == 8 && front_s1_mid_var(a)) IQGPU_LAUNCH_S1Y(8, false, false, false, 4);
     else if (cls == 8 && a.agc_fused) IQGPU_LAUNCH_S1X(8, false, false, true);
     else if (cls == 8) IQGPU_LAUNCH_S1(8, false, false);
     else IQGPU_LAUNCH_S1(0, false, false);
