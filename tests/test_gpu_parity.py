@@ -761,6 +761,43 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
     int_close(ch.process(raw[:2 * 50000]), och.process(raw[:2 * 50000]), min_same=0.95)
 
 
+@pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,shift", [
+    ("cu8", 61.44e6, 1488375.0, "cu8", 0.0),        # BASELINE configs[3] without its filter: raw stage 0, K = 4
+    ("cu8", 20e6, 744187.5, "cs16", 0.0),           # raw stage 0, K = 3
+    ("cu8", 10e6, 1488375.0, "cu8", 0.0),           # raw stage 0, K = 1 (semi-length 5 in stage 0)
+    ("cu8", 61.44e6, 1488375.0, "cu8", 1.0e6),      # a mixer in front: cf32 rows, compile-time stage list
+    ("cs16", 20e6, 744187.5, "cs16", 0.0),
+    ("cs8", 10e6, 744187.5, "cs16", 0.0),
+])
+def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatch, in_format, in_rate, out_rate, out_format, shift):
+    """k_cascade<BPS, raw, KT> (cu8 frames kept raw in LDS for stage 0; stage count and semi-lengths as template parameters) and
+    k_front_s1<8, .., VAR = 4> (the last stage with its switches folded) against the run-time-switched kernels: same arithmetic in
+    the same order, so the bytes must be equal -- call splits, one-frame calls and a reset included -- and close to the oracle."""
+    n = 16384 * 90 + 16384 // 2 + 6
+    raw = synth.raw_stream(n, in_rate, 31, in_format)
+    bps = 2 if in_format in ("cu8", "cs8") else 4
+    per = raw.size // n                                  # array elements per frame
+    assert per * raw.itemsize == bps
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=in_rate, target_rate_hz=out_rate, shift_hz=shift)
+    cuts = [0, 1, 16384 * 3 + 5, 16384 * 3 + 5 + 16384 * 40, 16384 * 80, n]
+    def run():
+        ch = gpu.Chain(**kw)
+        parts = [ch.process(raw[per * a:per * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        ch.reset()
+        parts.append(ch.process(raw[:per * 70001]))
+        return np.concatenate(parts)
+    fast = run()
+    for k in ("IQGPU_NO_RAW0", "IQGPU_NO_KT", "IQGPU_NO_FAST"):
+        monkeypatch.setenv(k, "1")
+    slow = run()
+    for k in ("IQGPU_NO_RAW0", "IQGPU_NO_KT", "IQGPU_NO_FAST"):
+        monkeypatch.delenv(k)
+    assert np.array_equal(fast, slow)
+    och = oracle.Chain(**kw)
+    want = np.concatenate([och.process(raw[per * a:per * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    int_close(fast[:want.size], want, min_same=0.9 if out_format == "cu8" else 0.97)
+
+
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
 def test_one_stage_chain_all_input_formats(gpu, oracle, fmt):
     """the fast path's vector loaders (2, 4, 8 bytes per frame) and its scalar fallback"""
