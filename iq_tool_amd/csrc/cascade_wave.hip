@@ -29,6 +29,15 @@
 
 namespace iqgpu {
 
+// 16-byte LDS accesses of this file: every slice, row and array starts on a 16-byte boundary, but the wave's slice sits at a
+// run-time multiple of casc_wave_lds, which hides that from the compiler -- without the hint it emits ds_read2_b64 /
+// ds_write2_b64 pairs (two 8-byte accesses at a 16-byte lane stride: two-way bank conflicts) instead of b128
+__device__ __forceinline__ float4 ld4a(const char *p) { return *(const float4 *)__builtin_assume_aligned(p, 16); }
+// ... and every component of a window load counts as used: left alone, the compiler trims a 16-byte load to the dwords the
+// taps touch and re-chunks the rest into ds_read2_b32 / unaligned ds_read2_b64 (slow, and conflict-prone at a 16-byte lane stride)
+template <typename T> __device__ __forceinline__ void keep(const T &v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void st4a(char *p, float4 v) { *(float4 *)__builtin_assume_aligned(p, 16) = v; }
+
 __host__ __device__ constexpr int casc_hist_rows(int m) { return (2 * m - 1 + 3) / 4; }   // older rows a lane reads
 
 // One stage: 4 outputs per lane for lanes < n_act.
@@ -43,7 +52,7 @@ __device__ __forceinline__ void casc_stage_load(const char *XE, const char *XO, 
     const char *we = XE + lane * 16;
 #pragma unroll
     for (int r = 0; r <= H; ++r) {
-        const float4 v0 = ld4(we + r * 16), v1 = ld4(we + r * 16 + PS);
+        const float4 v0 = ld4a(we + r * 16), v1 = ld4a(we + r * 16 + PS);
         wn.E[4 * r + 0] = v2f{v0.x, v0.y}; wn.E[4 * r + 1] = v2f{v0.z, v0.w};
         wn.E[4 * r + 2] = v2f{v1.x, v1.y}; wn.E[4 * r + 3] = v2f{v1.z, v1.w};
     }
@@ -51,10 +60,10 @@ __device__ __forceinline__ void casc_stage_load(const char *XE, const char *XO, 
     constexpr int c0 = 4 * H - M;                     // window index of i = 0
     constexpr int r0 = c0 / 4;
     const char *wo = XO + (lane + r0) * 16;
-    const float4 v0 = ld4(wo), v1 = ld4(wo + PS);
+    const float4 v0 = ld4a(wo), v1 = ld4a(wo + PS);
     wn.O[0] = v2f{v0.x, v0.y}; wn.O[1] = v2f{v0.z, v0.w}; wn.O[2] = v2f{v1.x, v1.y}; wn.O[3] = v2f{v1.z, v1.w};
     if ((c0 & 3) != 0) {
-        const float4 u0 = ld4(wo + 16), u1 = ld4(wo + 16 + PS);
+        const float4 u0 = ld4a(wo + 16), u1 = ld4a(wo + 16 + PS);
         wn.O[4] = v2f{u0.x, u0.y}; wn.O[5] = v2f{u0.z, u0.w}; wn.O[6] = v2f{u1.x, u1.y}; wn.O[7] = v2f{u1.z, u1.w};
     }
 }
@@ -105,7 +114,7 @@ __device__ __forceinline__ void casc_stage_lin_load(const char *E, const char *O
         const char *we = E + lane * 16;
 #pragma unroll
         for (int r = 0; r <= M; ++r) {
-            const float4 v = ld4(we + r * 16);
+            const float4 v = ld4a(we + r * 16);
             wn.W[2 * r] = v2f{v.x, v.y}; wn.W[2 * r + 1] = v2f{v.z, v.w};
         }
         wn.o[0] = ld2(O + (HO + 2 * lane - M) * 8); wn.o[1] = ld2(O + (HO + 2 * lane + 1 - M) * 8);
@@ -123,6 +132,8 @@ __device__ __forceinline__ void casc_stage_lin_fma(const CascWinLin<M, G> &wn, c
     constexpr int HS = casc_lin_hs(M);
     const v2f *hbp = (const v2f *)taps_sgpr;          // M SGPR pairs {h[2i], h[2i+1]}
     if (G == 2) {
+#pragma unroll
+        for (int i = 0; i < 2 * M + 2; ++i) keep(wn.W[i]);
         // W[i] = array entry 2l + i = E index 2l + i - HS; output j = 2l + g uses E[j - q] = W[HS + g - q]
         y[0] = v2f{0.5f * wn.o[0].x, 0.5f * wn.o[0].y}; y[1] = v2f{0.5f * wn.o[1].x, 0.5f * wn.o[1].y};
 #pragma unroll
@@ -167,7 +178,7 @@ __device__ __forceinline__ void casc_stage_raw8_load(const char *RB, int lane, C
     const char *wb = RB + kRawHist + (lane - (NB - 1)) * 16;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const uint4 v = *(const uint4 *)(wb + b * 16);
+        const uint4 v = *(const uint4 *)__builtin_assume_aligned(wb + b * 16, 16);
         wn.W[4 * b + 0] = v.x; wn.W[4 * b + 1] = v.y; wn.W[4 * b + 2] = v.z; wn.W[4 * b + 3] = v.w;
     }
 }
@@ -188,6 +199,8 @@ __device__ __forceinline__ void casc_stage_raw8_fma(const CascWinRaw<M> &wn, con
         return x;
     };
     constexpr int Z = 4 * (NB - 1);                         // dword index of n = 0
+#pragma unroll
+    for (int i = 0; i < 4 * NB; ++i) keep(wn.W[i]);
     v2f E[2 * M + 3];                                       // E[k] = even sample n = k - (2M - 1)
 #pragma unroll
     for (int k = 0; k < 2 * M + 3; ++k) E[k] = unpack(wn.W[Z + k - (2 * M - 1)] & 0xffffu);
@@ -399,16 +412,20 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                 se[k] = *(const float *)(w.XE[k] + pk_ * 8 + (lane < 2 * hs ? lane : 2 * hs - 1) * 4);
                 so[k] = *(const float *)(w.XO[k] + pk_ * 8 + (lane < 2 * ho ? lane : 2 * ho - 1) * 4);
             };
-            if (KT > 1) { casc_stage_lin_load<M1, 2>(w.XE[1], w.XO[1], lane, l1); tails(1, M1); }
+            // stage groups whose windows are read together: {0, 1} {2, 3} on raw frames (all four at once do not fit 128
+            // registers); with the cf32 rows (48 registers for stage 0's window alone) every stage reads for itself
+            constexpr bool G01 = RAW0 && !EDGE;
+            if (G01 && KT > 1) { casc_stage_lin_load<M1, 2>(w.XE[1], w.XO[1], lane, l1); tails(1, M1); }
             __builtin_amdgcn_sched_barrier(0);
             if (!EDGE) __builtin_amdgcn_s_setprio(0);
             if (RAW0 && !EDGE) casc_stage_raw8_fma<M0, true>(r0, a.casc_taps[0], ys[0]);
             else casc_stage_fma<M0>(f0, a.casc_taps[0], ys[0]);
+            if (!G01 && KT > 1) { casc_stage_lin_load<M1, 2>(w.XE[1], w.XO[1], lane, l1); tails(1, M1); }
             if (KT > 1) casc_stage_lin_fma<M1, 2>(l1, a.casc_taps[1], ys[1]);
-            // (all four windows at once do not fit 128 registers: the late stages form a second group)
             if (KT > 2) { casc_stage_lin_load<M2, 1>(w.XE[2], w.XO[2], lane, l2); tails(2, M2); }
-            if (KT > 3) { const int lc = lane < 32 ? lane : 31; casc_stage_lin_load<M3, 1>(w.XE[3], w.XO[3], lc, l3); tails(3, M3); }
+            if (G01 && KT > 3) { const int lc = lane < 32 ? lane : 31; casc_stage_lin_load<M3, 1>(w.XE[3], w.XO[3], lc, l3); tails(3, M3); }
             if (KT > 2) casc_stage_lin_fma<M2, 1>(l2, a.casc_taps[2], ys[2]);
+            if (!G01 && KT > 3) { const int lc = lane < 32 ? lane : 31; casc_stage_lin_load<M3, 1>(w.XE[3], w.XO[3], lc, l3); tails(3, M3); }
             if (KT > 3) casc_stage_lin_fma<M3, 1>(l3, a.casc_taps[3], ys[3]);
         } else {
 #pragma unroll
@@ -466,8 +483,8 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const int off = woff + 32 * c * 16;
-                        *(float4 *)(XE0 + off) = make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y);
-                        *(float4 *)(XO0 + off) = make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y);
+                        st4a(XE0 + off, make_float4(x[c][0].x, x[c][0].y, x[c][2].x, x[c][2].y));
+                        st4a(XO0 + off, make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y));
                     }
                 } else {
                     const int hs = casc_lin_hs(m), ho = casc_lin_ho(m);
@@ -479,8 +496,8 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
                     const int hn = casc_lin_hs(stage_m(k + 1)), on = casc_lin_ho(stage_m(k + 1));
                     if (lane < n_act) {
                         if (g_out == 4) {
-                            *(float4 *)(w.XE[k + 1] + (hn + 2 * lane) * 8) = make_float4(y[0].x, y[0].y, y[2].x, y[2].y);
-                            *(float4 *)(w.XO[k + 1] + (on + 2 * lane) * 8) = make_float4(y[1].x, y[1].y, y[3].x, y[3].y);
+                            st4a(w.XE[k + 1] + (hn + 2 * lane) * 8, make_float4(y[0].x, y[0].y, y[2].x, y[2].y));
+                            st4a(w.XO[k + 1] + (on + 2 * lane) * 8, make_float4(y[1].x, y[1].y, y[3].x, y[3].y));
                         } else if (g_out == 2) {
                             *(float2 *)(w.XE[k + 1] + (hn + lane) * 8) = make_float2(y[0].x, y[0].y);
                             *(float2 *)(w.XO[k + 1] + (on + lane) * 8) = make_float2(y[1].x, y[1].y);
