@@ -36,6 +36,7 @@ __device__ __forceinline__ float4 ld4a(const char *p) { return *(const float4 *)
 // ... and every component of a window load counts as used: left alone, the compiler trims a 16-byte load to the dwords the
 // taps touch and re-chunks the rest into ds_read2_b32 / unaligned ds_read2_b64 (slow, and conflict-prone at a 16-byte lane stride)
 template <typename T> __device__ __forceinline__ void keep(const T &v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ v2f ld2(const char *p) { const float2 v = *(const float2 *)p; return v2f{v.x, v.y}; }
 __device__ __forceinline__ void st4a(char *p, float4 v) { *(float4 *)__builtin_assume_aligned(p, 16) = v; }
 
 __host__ __device__ constexpr int casc_hist_rows(int m) { return (2 * m - 1 + 3) / 4; }   // older rows a lane reads
@@ -47,24 +48,37 @@ template <int M> struct CascWin0 { v2f E[4 * (casc_hist_rows(M) + 1)]; v2f O[8];
 template <int M>
 __device__ __forceinline__ void casc_stage_load(const char *XE, const char *XO, int lane, CascWin0<M> &wn)
 {
+    // Every load below is used in full (the taps touch E[4H - 2M + 1 .. 4H + 3] and four consecutive O's): a load with unused
+    // components is trimmed by the compiler and re-chunked into ds_read2_b32 / unaligned ds_read2_b64, which conflict
     constexpr int H = casc_hist_rows(M);
     constexpr int PS = plane_stride(H + 64 + 1);      // two planes of 16-byte half rows (wave_common.hpp)
+    constexpr int lo = 4 * H - 2 * M + 1;             // first window entry a tap touches (3 for M = 3 and M = 5)
     const char *we = XE + lane * 16;
 #pragma unroll
     for (int r = 0; r <= H; ++r) {
-        const float4 v0 = ld4a(we + r * 16), v1 = ld4a(we + r * 16 + PS);
-        wn.E[4 * r + 0] = v2f{v0.x, v0.y}; wn.E[4 * r + 1] = v2f{v0.z, v0.w};
-        wn.E[4 * r + 2] = v2f{v1.x, v1.y}; wn.E[4 * r + 3] = v2f{v1.z, v1.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                 // half row h: entries 4r + 2h, 4r + 2h + 1
+            const int e0 = 4 * r + 2 * h;
+            const char *q = we + r * 16 + h * PS;
+            // (a half row with one used entry is read whole and the other entry declared used: an 8-byte read in front of
+            //  aligned 16-byte ones makes the vectoriser re-chunk the whole run at the 8-byte phase)
+            if (e0 + 1 >= lo) { const float4 v = ld4a(q); wn.E[e0] = v2f{v.x, v.y}; wn.E[e0 + 1] = v2f{v.z, v.w}; if (e0 < lo) keep(wn.E[e0]); }
+        }
     }
-    // centre taps: O[4l + i - M] = window index 4H + i - M  ->  rows r0, r0 + 1
+    // centre taps: O[4l + i - M] = window index 4H + i - M  ->  rows r0, r0 + 1; entries (c0 & 3) .. (c0 & 3) + 3 of O[0 .. 7]
     constexpr int c0 = 4 * H - M;                     // window index of i = 0
     constexpr int r0 = c0 / 4;
+    constexpr int u0 = c0 & 3, u1 = u0 + 3;           // used entries u0 .. u1
     const char *wo = XO + (lane + r0) * 16;
-    const float4 v0 = ld4a(wo), v1 = ld4a(wo + PS);
-    wn.O[0] = v2f{v0.x, v0.y}; wn.O[1] = v2f{v0.z, v0.w}; wn.O[2] = v2f{v1.x, v1.y}; wn.O[3] = v2f{v1.z, v1.w};
-    if ((c0 & 3) != 0) {
-        const float4 u0 = ld4a(wo + 16), u1 = ld4a(wo + 16 + PS);
-        wn.O[4] = v2f{u0.x, u0.y}; wn.O[5] = v2f{u0.z, u0.w}; wn.O[6] = v2f{u1.x, u1.y}; wn.O[7] = v2f{u1.z, u1.w};
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {                  // pair pr: entries 2 pr, 2 pr + 1 = row r0 + pr / 2, plane pr & 1
+        const char *q = wo + (pr >> 1) * 16 + (pr & 1) * PS;
+        const bool a0 = 2 * pr >= u0 && 2 * pr <= u1, a1 = 2 * pr + 1 >= u0 && 2 * pr + 1 <= u1;
+        if (a0 || a1) {
+            const float4 v = ld4a(q); wn.O[2 * pr] = v2f{v.x, v.y}; wn.O[2 * pr + 1] = v2f{v.z, v.w};
+            if (!a0) keep(wn.O[2 * pr]);
+            if (!a1) keep(wn.O[2 * pr + 1]);
+        }
     }
 }
 template <int M>
@@ -102,7 +116,6 @@ __host__ __device__ constexpr int casc_lin_ho(int m) { return (m + 1) & ~1; }   
 __host__ __device__ constexpr int casc_lin_g(int k) { return k == 1 ? 2 : 1; }         // outputs per lane
 __host__ __device__ constexpr int casc_lin_lanes(int k) { return (256 >> k) / casc_lin_g(k); }
 
-__device__ __forceinline__ v2f ld2(const char *p) { const float2 v = *(const float2 *)p; return v2f{v.x, v.y}; }
 
 template <int M, int G> struct CascWinLin { v2f W[G == 2 ? 2 * M + 2 : 2 * M]; v2f o[2]; };
 template <int M, int G>
