@@ -459,7 +459,12 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             for (int r = 0; r < 6; ++r) {
                 const float4 v1 = ld4(we + r * kRowB + 16);
                 if (r == 0) {                  // E[0] is not a tap of any of the lane's four outputs: 8 bytes do
-                    E[0] = v2f{0.f, 0.f}; E[1] = *(const v2f *)(we + 8);
+                    // (through a pointer the compiler cannot see through: next to the 16-byte read at + 16 the vectoriser would
+                    //  re-chunk the 24 bytes as 16 at + 8 -- a misaligned ds_read2_b64 -- and 8 at + 24)
+                    typedef __attribute__((address_space(3))) const v2f lds_v2f_t;
+                    unsigned we8 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)(we + 8);
+                    asm("" : "+v"(we8));
+                    E[0] = v2f{0.f, 0.f}; E[1] = *(lds_v2f_t *)(size_t)we8;
                 } else {
                     const float4 v0 = ld4(we + r * kRowB);
                     E[4 * r + 0] = v2f{v0.x, v0.y}; E[4 * r + 1] = v2f{v0.z, v0.w};
