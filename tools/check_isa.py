@@ -7,7 +7,10 @@ script compiles front_wave.hip to gfx950 ISA and verifies for every instantiatio
   (1) each asm block that reads LDS holds the 14 reads of one slot pair and ENDS with
       s_waitcnt lgkmcnt(0) (nothing of the compiler's can then see a register that is still filling),
   (2) there are two such blocks per polyphase section,
-  (3) no asm global_load / buffer_load is left in the file (loads are compiler-managed).
+  (3) no asm global_load / buffer_load is left in the file (loads are compiler-managed),
+  (4) neither k_front_s1 nor k_cascade (cascade_wave.hip) holds a ds_read2_b32: that is what hipcc's load vectoriser makes of
+      a window load it has trimmed to the dwords in use -- two 4-byte accesses per lane at a 16-byte lane stride, which
+      conflict (SQ_LDS_BANK_CONFLICT 94 -> 12 cycles per tile when the cascade's window loads were made whole).
 Exit code 0 = ok.  Run by __graft_entry__.build() and tests/test_host_logic.py."""
 import os
 import re
@@ -17,13 +20,15 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_wave.hip")
+SRC_CASC = os.path.join(HERE, "..", "iq_tool_amd", "csrc", "cascade_wave.hip")
 
 
-def compile_isa():
+def compile_isa(src=None):
+    src = src or SRC
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "fw.s")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-               "--cuda-device-only", "-S", SRC, "-o", out]
+               "--cuda-device-only", "-S", src, "-o", out]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         return open(out).read().split("\n")
 
@@ -87,8 +92,25 @@ def check(lines):
     return errors, n_gathers
 
 
+def check_no_read2_b32(lines, what):
+    errors, cur = [], None
+    for l in lines:
+        m = re.match(r"(_ZN5iqgpu\d+k_(?:front_s1|cascade)I\w+):", l)
+        if m:
+            cur = m.group(1)
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur and re.match(r"\s*ds_read2(st64)?_b32", l):
+            errors.append("%s: %s holds a ds_read2_b32 (a trimmed, re-chunked window load?)" % (what, cur))
+            cur = None
+    return errors
+
+
 def main():
-    errors, n = check(compile_isa())
+    lines = compile_isa()
+    errors, n = check(lines)
+    errors += check_no_read2_b32(lines, "front_wave.hip")
+    errors += check_no_read2_b32(compile_isa(SRC_CASC), "cascade_wave.hip")
     for e in errors:
         print("FAIL", e)
     print("check_isa: %d tap gathers checked: %s" % (n, "ok" if not errors and n > 0 else "FAILED"))
