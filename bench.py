@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=2.0,
                     help="untimed back-to-back steps before the W warm-up steps, so that the K timed steps see the clock the chip HOLDS under this load and not the first milliseconds after idle (measured: launches 1-3 0.48 ms, 4-12 up to 0.68 ms, steady state 0.49 ms)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host_end_to_end leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` legs (BASELINE configs[2], configs[3], the preset with its AGC)")
+    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--secondary-settle", type=float, default=0.7, help="seconds of untimed steps in front of each secondary leg")
     ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
     ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
     a = ap.parse_args()
@@ -110,23 +113,54 @@ def cpu_model():
 
 
 def spawn_workers(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes.  The parent
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  The parent
     never imports torch or touches HIP (a process that has initialised the GPU must not be replaced or
-    forked on this pool); it only relays rank 0's line and the worst exit code."""
+    forked on this pool); it relays rank 0's line and watches ALL children: the first one that exits
+    non-zero (no GPU for its local rank, an import error, a kernel fault) ends the others at once --
+    they would otherwise sit in the gloo barrier until its timeout -- and its code is returned."""
+    import tempfile
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()                   # a file, not a pipe: nobody has to drain it while we poll
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode("utf-8", "replace"))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + float(os.environ.get("IQGPU_BENCH_TIMEOUT_S", "1500"))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+        if rc == 0 and time.monotonic() > deadline:
+            sys.stderr.write("bench.py: ranks still running after the watchdog period, ending them\n")
+            rc = 124
+        if rc != 0 and live:
+            sys.stderr.write("bench.py: a rank failed (exit %d): ending the other %d\n" % (rc, len(live)))
+            for p in live:
+                p.terminate()                         # exact children of this process, never a pattern
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            live = []
+        elif live:
+            time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode("utf-8", "replace"))
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    out0.close()
+    return rc
 
 
 def shard_plan(world_size, rank, frames_per_gpu):
@@ -219,6 +253,135 @@ def step_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
     return f + executed, f + direct
 
 
+def run_case(args, dist, dev, local_rank, world, rank, config, preset, steps, warmup, settle_s, log2_frames):
+    """One timed leg: build the chain of `config` (2, 3, 4; preset = config 2 with the output AGC), put its batch into
+    HBM, settle, warm up, time `steps` steps between barriers.  Returns the raw figures; the caller formats them."""
+    import torch
+    import iq_tool_amd
+    from iq_tool_amd import synth
+    chain_kw, rate, fmt, in_bps, workload = (dict(CHAIN, agc=True) if preset else CHAIN), 2.4e6, "cs16", 4, None
+    if config != 2:
+        o = OTHER[config]
+        chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
+        if log2_frames == 28:
+            log2_frames = o["log2_frames"]
+    frames = 1 << log2_frames
+    plan = shard_plan(world, rank, frames)
+    seg_frames = min(frames, 1 << SEGMENT_LOG2)
+    seg = synth.raw_stream(seg_frames, rate, plan["seed"], fmt)               # interleaved I,Q integers
+    d_seg = torch.from_numpy(seg).to(dev)
+    d_in = d_seg.repeat(frames // seg_frames).contiguous()                     # resident in HBM
+    del d_seg
+
+    chain = iq_tool_amd.Chain(device=local_rank, block_samples=BLOCK_SAMPLES, **chain_kw)
+    chain.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    cap_frames = chain.max_out_frames(frames)
+    d_out = torch.empty(cap_frames * chain.out_bytes, dtype=torch.uint8, device=dev)
+    out_frames = []
+
+    def step():
+        out_frames.append(chain.process_device(d_in.data_ptr(), frames, d_out.data_ptr(), d_out.numel()))
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < settle_s:                # sustained-load clock, see --settle-seconds
+        for _ in range(50):
+            step()
+        sync()
+        out_frames.clear()
+    for _ in range(warmup):
+        step()
+    sync()
+    out_frames.clear()
+    chain.set_profiling(True)
+    chain.profile()                                   # clear
+    dt = timed_region(dist, sync, step, steps)
+    prof = chain.profile()
+    chain.set_profiling(False)
+
+    front = prof["front"]
+    k_ms = front["ms"] / max(front["launches"], 1)
+    if config != 2 or preset:
+        # these run several kernels per step (cascade, last stage, dc carries, filter, AGC verdict):
+        # price the whole step's device time, not one of them
+        k_ms = sum(v["ms"] for v in prof.values()) / max(steps, 1)
+    n_out_avg = float(np.mean(out_frames)) if out_frames else 0.0
+    alg_bytes = frames * in_bps + n_out_avg * chain.out_bytes   # SURVEY 8(d): in_bytes + r * out_bytes per input frame
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    del d_in, d_out
+    return dict(chain=chain, seg=seg, frames=frames, log2_frames=log2_frames, dt=dt, k_ms=k_ms, prof=prof, front=front, n_out_avg=n_out_avg,
+                alg_bytes=alg_bytes, achieved=achieved, chain_kw=chain_kw, in_bps=in_bps, workload=workload, steps=steps)
+
+
+def fp32_roofline(case):
+    """configs 3 / 4 are ALU-bound: executed flops of the step against the FP32 vector peak, HBM fraction beside it"""
+    chain, frames, k_ms, prof = case["chain"], case["frames"], case["k_ms"], case["prof"]
+    info = chain.info()
+    n_res = float(-(-((frames >> info.num_halfband_stages) << 24) // info.arb_step))
+    flops, flops_direct = step_flops(info, frames, n_res, case["n_out_avg"], case["chain_kw"], int(info.filter_ntaps), info.filter_impl in (2, 4))
+    tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    return {"bound": "fp32", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+            "traffic": None, "kernel": "all kernels of the step", "kernel_ms": round(k_ms, 4), "launches": case["front"]["launches"],
+            "executed_flops_per_step": int(flops), "direct_form_flops_per_step": int(flops_direct),
+            "direct_form_TFLOPs": round(flops_direct / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
+            "algorithmic_bytes_per_step": int(case["alg_bytes"]),
+            "hbm_GBs": round(case["achieved"], 1), "hbm_frac": round(case["achieved"] / HBM_PEAK_GBS, 4),
+            "note": "per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])}
+
+
+def secondary_traffic(name):
+    """counter-traffic ratio (HBM bytes by PMC / algorithmic bytes) of a secondary config, when profiles/traffic.json holds
+    a figure measured on this very build of the kernels (same source hash); otherwise null"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        sec = t.get("secondary", {}).get(name)
+        if sec and t.get("all_sources_sha") == all_sources_sha():
+            return float(sec["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def all_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "iq_tool_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def secondary_cases(args, dist, dev, local_rank, world, rank):
+    """BASELINE configs[2], configs[3] and the shipped preset (configs[1] + output AGC), each a short timed leg of its own
+    AFTER the main timed region: they never touch `value`; they are in the line so that the driver's run carries them."""
+    out = {}
+    for name, cfg, preset in (("config3", 3, False), ("config4", 4, False), ("preset", 2, True)):
+        c = run_case(args, dist, dev, local_rank, world, rank, cfg, preset, args.secondary_steps, 2, args.secondary_settle, 28)
+        e = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "steps": c["steps"], "frames_per_step": c["frames"],
+             "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1)}
+        if preset:
+            e["workload"] = "cs16-fm-nrsc5 preset: BASELINE configs[1] + digital output AGC fused past the lock"
+            e["roofline"] = {"bound": "hbm", "achieved": round(c["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(c["achieved"] / HBM_PEAK_GBS, 4), "kernel": "all kernels of the step", "kernel_ms": round(c["k_ms"], 4),
+                             "note": "per-kernel ms per step: " + ", ".join("%s %.3f" % (k, v["ms"] / max(c["steps"], 1)) for k, v in c["prof"].items() if v["launches"])}
+        else:
+            e["workload"] = c["workload"]
+            e["roofline"] = fp32_roofline(c)
+        tb = secondary_traffic(name)
+        e["traffic"] = tb
+        e["traffic_over_algorithmic"] = round(tb / c["alg_bytes"], 3) if tb else None
+        out[name] = e
+        c["chain"].close()
+        del c
+        import torch
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(frames_log2):
     """The oracle (float accumulators, -O3 -march=native) on a bounded sample of the same workload:
     one thread, and the reference's own arrangement -- three concurrent stage threads handing over
@@ -259,6 +422,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
+    if os.environ.get("IQGPU_BENCH_STUB") == "1" and os.environ.get("IQGPU_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                            # launcher test: a rank that dies before the rendezvous
+
     import torch
 
     dist = None
@@ -269,7 +435,9 @@ def main():
         keep = os.dup(1)
         os.dup2(2, 1)                                  # gloo announces its mesh on stdout: rank 0's stdout is ONE JSON line
         try:
-            dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)   # barrier + MAX only
+            import datetime
+            dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world,      # barrier + MAX only
+                                        timeout=datetime.timedelta(seconds=float(os.environ.get("IQGPU_BENCH_RDZV_S", "300"))))
             dist_mod.barrier()
         finally:
             os.dup2(keep, 1)
@@ -291,59 +459,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    chain_kw, rate, fmt, in_bps, workload = (dict(CHAIN, agc=True) if args.preset else CHAIN), 2.4e6, "cs16", 4, None
-    if args.config != 2:
-        o = OTHER[args.config]
-        chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
-        if args.log2_frames == 28:
-            args.log2_frames = o["log2_frames"]
-    frames = 1 << args.log2_frames
-    plan = shard_plan(world, rank, frames)
-    seg_frames = min(frames, 1 << SEGMENT_LOG2)
-    seg = synth.raw_stream(seg_frames, rate, plan["seed"], fmt)               # interleaved I,Q integers
-    d_seg = torch.from_numpy(seg).to(dev)
-    d_in = d_seg.repeat(frames // seg_frames).contiguous()                     # resident in HBM
-    del d_seg
-
-    chain = iq_tool_amd.Chain(device=local_rank, block_samples=BLOCK_SAMPLES, **chain_kw)
-    chain.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    cap_frames = chain.max_out_frames(frames)
-    d_out = torch.empty(cap_frames * chain.out_bytes, dtype=torch.uint8, device=dev)
-    out_frames = []
-
-    def step():
-        out_frames.append(chain.process_device(d_in.data_ptr(), frames, d_out.data_ptr(), d_out.numel()))
-
-    def sync():
-        torch.cuda.synchronize(dev)
-
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_seconds:     # sustained-load clock, see --settle-seconds
-        for _ in range(50):
-            step()
-        sync()
-        out_frames.clear()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    out_frames.clear()
-    chain.set_profiling(True)
-    chain.profile()                                   # clear
-    dt = timed_region(dist, sync, step, args.steps)
-    prof = chain.profile()
-    chain.set_profiling(False)
-
-    total_frames = world * args.steps * frames
-    value = total_frames / dt / 1e6
-    front = prof["front"]
-    k_ms = front["ms"] / max(front["launches"], 1)
-    if args.config != 2:
-        # secondary configs run several kernels per step (cascade, last stage, dc carries, filter):
-        # price the whole step's device time, not one of them
-        k_ms = sum(v["ms"] for v in prof.values()) / max(args.steps, 1)
-    n_out_avg = float(np.mean(out_frames)) if out_frames else 0.0
-    alg_bytes = frames * in_bps + n_out_avg * chain.out_bytes   # in_bytes + r * out_bytes per input frame
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    case = run_case(args, dist, dev, local_rank, world, rank, args.config, args.preset, args.steps, args.warmup, args.settle_seconds, args.log2_frames)
+    chain, seg, frames, dt, k_ms, prof, front, n_out_avg, alg_bytes, achieved, chain_kw, in_bps, workload = (
+        case[k] for k in ("chain", "seg", "frames", "dt", "k_ms", "prof", "front", "n_out_avg", "alg_bytes", "achieved", "chain_kw", "in_bps", "workload"))
+    value = world * args.steps * frames / dt / 1e6
 
     # ---- second leg: the same chain fed from pinned host memory (PCIe-inclusive; never `value`) ----
     host = None
@@ -363,32 +482,21 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "settle_s": args.settle_seconds,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(seg_frames)), args.log2_frames),
+            "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(min(frames, 1 << SEGMENT_LOG2))), case["log2_frames"]),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES,
                        "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"
                                    + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.log2_frames) if args.config == 2 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(case["log2_frames"]) if args.config == 2 else None,
                          "kernel": "k_front_s1<4, true>" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
             "host_end_to_end": host,
         }
         if args.config != 2:
-            # configs 3 / 4 are ALU-bound: price them against the FP32 vector peak, HBM fraction kept beside it
-            info = chain.info()
-            n_res = float(-(-((frames >> info.num_halfband_stages) << 24) // info.arb_step))
-            flops, flops_direct = step_flops(info, frames, n_res, n_out_avg, chain_kw, int(info.filter_ntaps), info.filter_impl in (2, 4))
-            tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             line["config"]["workload"] = workload
-            line["roofline"] = {"bound": "fp32", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                                "traffic": None, "kernel": "all kernels of the step", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
-                                "executed_flops_per_step": int(flops), "direct_form_flops_per_step": int(flops_direct),
-                                "direct_form_TFLOPs": round(flops_direct / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
-                                "algorithmic_bytes_per_step": int(alg_bytes),
-                                "hbm_GBs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-                                "note": "per-kernel ms: " + ", ".join("%s %.3f" % (k, v["ms"] / max(v["launches"], 1)) for k, v in prof.items() if v["launches"])}
+            line["roofline"] = fp32_roofline(case)
         if args.preset:
             line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
                                           "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "
@@ -399,6 +507,14 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
         else:
             line["cpu_baseline"] = None
+    # ---- the other single-GPU BASELINE configs and the shipped preset: short legs of their own, after everything that feeds `value`
+    sec = None
+    if args.config == 2 and not args.preset and not args.no_secondary:
+        case = chain = None
+        torch.cuda.empty_cache()
+        sec = secondary_cases(args, dist, dev, local_rank, world, rank)
+    if rank == 0:
+        line["secondary"] = sec
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -656,11 +656,11 @@ hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
         hipLaunchKernelGGL((k_cascade<__VA_ARGS__>), dim3(grid), dim3(waves * 64), lds, s, a);                        \
     } while (0)
     // cu8 frames with nothing between the unpack and stage 0: the streaming waves keep them raw in LDS (casc_stage_raw8)
-    const bool raw0 = a.in_fmt == IQGPU_FMT_CU8 && a.gain == 1.0f && !a.dc_enable && !a.iq_enable && a.nco_mode == 0 && !getenv("IQGPU_NO_RAW0");
+    const bool raw0 = a.in_fmt == IQGPU_FMT_CU8 && a.gain == 1.0f && !a.dc_enable && !a.iq_enable && a.nco_mode == 0 && !(a.dbg & kDbgNoRaw0);
     // liquid's 60 dB semi-lengths (3 .. 3 5): stage count and lengths resolved at compile time (casc_tiles, KT)
     int kt = a.casc_K;
     for (int k = 0; k < a.casc_K; ++k) if (a.m[k] != (k == a.casc_K - 1 ? 5 : 3)) kt = 0;
-    if (getenv("IQGPU_NO_KT")) kt = 0;
+    if (a.dbg & kDbgNoKT) kt = 0;
 #define IQGPU_LAUNCH_CASC_KT(BPS, RAW)                                                                                \
     do {                                                                                                              \
         if (kt == 1) IQGPU_LAUNCH_CASC(BPS, RAW, 1); else if (kt == 2) IQGPU_LAUNCH_CASC(BPS, RAW, 2);               \

@@ -350,7 +350,7 @@ static hipError_t launch_fftconv16(const FftConvArgs &a, unsigned nb, size_t lds
 
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
 {
-    if (a.n_emit > 0 && a.log2n >= 10 && !getenv("IQGPU_FFT_NO_R16")) {
+    if (a.n_emit > 0 && a.log2n >= 10 && !(a.dbg & kDbgFftNoR16)) {
         const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
         if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;
         const unsigned nb = (unsigned)((a.n_emit + V - 1) / V);

@@ -28,7 +28,6 @@
 // are handled by a scalar-load instantiation of the same tile routine; the host gives those tiles
 // to a few extra waves (a handful of tiles each) so that the streaming waves run a loop with no
 // special cases in it.
-#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -730,7 +729,7 @@ __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || VAR >= 2) ? kS1Threa
 static bool front_s1_fast_shape(const FrontArgs &a)
 {
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable &&
-           !a.dc_enable && a.pnco_mode == 0 && !getenv("IQGPU_NO_FAST");
+           !a.dc_enable && a.pnco_mode == 0 && !(a.dbg & kDbgNoFast);
 }
 static bool front_s1_fast_nonco(const FrontArgs &a) { return front_s1_fast_shape(a) && a.nco_mode == 0; }
 // the fused AGC exists for the 8- and 16-bit-input instantiations, with or without the half-band stage (the shipped
@@ -741,21 +740,21 @@ bool front_s1_agc_fusable(const FrontArgs &a)
     const bool in16 = a.in_fmt == IQGPU_FMT_CS16 || a.in_fmt == IQGPU_FMT_CU16 || a.in_fmt == IQGPU_FMT_SC16Q11;
     // (cf32 input: the last stage behind k_cascade, whose chunks are counted in the chain's input frames)
     const bool mid = a.in_fmt == IQGPU_FMT_CF32 && a.S == 1 && a.agc_shift >= 2;
-    return (a.S == 0 || a.S == 1) && (in8 || in16 || mid) && a.agc_chunk_frames >= ((int64_t)256 << a.agc_shift) && !getenv("IQGPU_AGC_NOFUSE");
+    return (a.S == 0 || a.S == 1) && (in8 || in16 || mid) && a.agc_chunk_frames >= ((int64_t)256 << a.agc_shift) && !(a.dbg & kDbgAgcNoFuse);
 }
 
 // the cu8-nrsc5 preset shapes (iq_tool_presets.conf:190-214): 0.5 <= r < 1, nothing but unpack -> polyphase -> pack cu8
 static int front_s1_plain_var(const FrontArgs &a)
 {
     if (a.S != 0 || a.out_fmt != IQGPU_FMT_CU8 || a.gain != 1.0f || a.iq_enable || a.dc_enable || a.nco_mode != 0 || a.pnco_mode != 0 ||
-        getenv("IQGPU_NO_FAST")) return 0;
+        (a.dbg & kDbgNoFast)) return 0;
     return a.in_fmt == IQGPU_FMT_CU8 ? 2 : a.in_fmt == IQGPU_FMT_CS16 ? 3 : 0;
 }
 // the last stage behind k_cascade (or any cf32 stream) with nothing pointwise in it and 16- or 8-bit frames out: VAR 4
 static bool front_s1_mid_var(const FrontArgs &a)
 {
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CF32 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable && a.nco_mode == 0 && a.pnco_mode == 0 &&
-           (a.out_fmt == IQGPU_FMT_CS16 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CF32) && !getenv("IQGPU_NO_FAST");
+           (a.out_fmt == IQGPU_FMT_CS16 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CF32) && !(a.dbg & kDbgNoFast);
 }
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)

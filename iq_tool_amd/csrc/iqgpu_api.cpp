@@ -175,6 +175,7 @@ struct iqgpu_chain {
     cf2 probe_last[1024];
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
+    uint32_t dbg = 0;             // kDbg* diagnostic switches, read from the environment once at create
     // profiling
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
@@ -279,7 +280,12 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
         return fail(IQGPU_EINVAL, "input_rate_hz must be positive");
     c->desc = *d;
     c->device = d->device_ordinal;
-    { const char *fg = getenv("IQGPU_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1'; }
+    {   // every IQGPU_* switch is read HERE, once per chain: process() and the launch functions never touch the environment
+        const char *fg = getenv("IQGPU_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1';
+        c->dbg = (getenv("IQGPU_NO_FAST") ? kDbgNoFast : 0u) | (getenv("IQGPU_AGC_NOFUSE") ? kDbgAgcNoFuse : 0u) |
+                 (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
+                 (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u);
+    }
 
     // ---- ratio (src/setup.c:91-122) ----
     const double in_rate = d->input_rate_hz > 0.0 ? d->input_rate_hz : 1.0;
@@ -334,7 +340,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     c->S = c->decim ? c->rp.S : 0;
     c->D = 1 << c->S;
     c->TG = kTile >> c->S;
-    if (c->decim && c->S >= 2 && !getenv("IQGPU_FORCE_GENERIC")) {
+    if (c->decim && c->S >= 2 && !c->force_generic) {
         int mm[kMaxS];
         for (int i = 0; i < c->S; ++i) mm[i] = c->rp.stages[(size_t)i].m;
         c->cascade = cascade_supported(mm, c->S);
@@ -468,6 +474,7 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             }
             // the fused path exists for the specialised front kernel: the shipped cs16 NRSC-5 preset shape
             FrontArgs fa{};
+            fa.dbg = c->dbg;
             fa.S = c->S; fa.in_fmt = c->desc.in_format; fa.out_fmt = c->desc.out_format; fa.gain = c->desc.gain;
             fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
             fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk; fa.agc_shift = c->S;
@@ -831,6 +838,7 @@ void Call::plan_geometry()
     casc_K = c->S - 1;
     rem_k = casc ? (c->rem & ((1 << casc_K) - 1)) : c->rem;
     cplan = FrontArgs{};
+    cplan.dbg = c->dbg;
     if (casc || fast_s1) {
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
@@ -935,6 +943,7 @@ int Call::prepare_buffers()
 int Call::stage_front()
 {
     FrontArgs a{};
+    a.dbg = c->dbg;
     a.raw = d_raw_in;
     a.hist_in = c->d_hist[c->hist_cur]; a.hist_out = c->d_hist[c->hist_cur ^ 1];
     a.frames_in = (int64_t)frames_in; a.hist_cap = c->hist_cap; a.rem0 = c->rem;
@@ -992,6 +1001,7 @@ int Call::stage_front()
         // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
         if (n_mid > 0) {
             FrontArgs a2{};
+            a2.dbg = c->dbg;
             a2.raw = c->mid.p; a2.hist_in = c->d_hist2[c->hist2_cur]; a2.hist_out = c->d_hist2[c->hist2_cur ^ 1];
             a2.frames_in = n_mid; a2.hist_cap = c->hist2_cap; a2.rem0 = rem_1;
             a2.in_fmt = IQGPU_FMT_CF32; a2.gain = 1.0f; a2.raw_aligned = 1;
@@ -1045,6 +1055,7 @@ int Call::stage_filter()
     else         { fa.out_fmt = fin_fmt; fa.out = fin_out; }
     if (c->d_hfreq) {
         FftConvArgs ca{};
+        ca.dbg = c->dbg;
         ca.fbuf = fcur; ca.fbuf_len = (int64_t)(L1 + (size_t)c->fpending + (size_t)p.n_res);
         ca.hfreq = c->d_hfreq; ca.twiddle = c->d_twiddle; ca.ntaps = fa.ntaps;
         ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = n_filt;
@@ -1407,10 +1418,24 @@ extern "C" int iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t fra
     if (ps.busy) return fail(IQGPU_EINVAL, "iqgpu_chain_submit: %d batches are in flight; collect ticket %llu first",
                              iqgpu_chain::kPipeSlots, (unsigned long long)ps.ticket);
     const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
-    // this batch's copy first (it needs nothing but the slot), so that the copy stream never idles while the host
-    // queues the previous batch's kernels
+    // Everything that can refuse the batch comes first and touches nothing: the exact output count (a closed form of the
+    // stream position behind the tickets already handed out -- pipe_advance below never moves that position), the capacity
+    // check, and both device buffers.  Only then is anything queued, and the look-ahead position moves together with the
+    // ticket at the very end: a refused submit leaves the handle exactly as it was.
+    StreamPos at;
+    if (c->pipe_launched == c->pipe_seq) { at.rem = c->rem; at.phi = c->phi; at.fpending = c->fpending; }
+    else { at.rem = c->pipe_rem; at.phi = c->pipe_phi; at.fpending = c->pipe_fpending; }
+    const CallPlan plan = plan_call_at(c, at, frames_in);
+    const size_t n_emit = (size_t)plan.n_emit;
+    if (n_emit * obps > out_capacity_bytes)
+        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
     if (frames_in) {
         rc = ps.d_in.ensure(frames_in * ibps); if (rc) return rc;
+        rc = ps.d_out.ensure(n_emit * obps + 16); if (rc) return rc;
+    }
+    // this batch's copy next (it needs nothing but the slot), so that the copy stream never idles while the host
+    // queues the previous batch's kernels
+    if (frames_in) {
         hipStream_t h2d = c->pipe_h2d[frames_in * ibps <= kSmallCopy ? c->pipe_seq % (uint64_t)iqgpu_chain::kCopyStreams : 0];
         HIP_TRY(hipMemcpyAsync(ps.d_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, h2d));
         HIP_TRY(hipEventRecord(ps.in_done, h2d));
@@ -1423,17 +1448,8 @@ extern "C" int iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t fra
     static_assert(kLagK + kLagD < (uint64_t)iqgpu_chain::kPipeSlots, "a batch must leave the pipeline before its slot comes round again");
     if (t > kLagK) { rc = pipe_advance(c, t - kLagK); if (rc) return rc; }
     if (t > kLagK + kLagD) { rc = pipe_drain(c, t - kLagK - kLagD); if (rc) return rc; }
-    // the exact output count is a closed form of the stream position behind the tickets already handed out
-    StreamPos at;
-    if (c->pipe_launched == c->pipe_seq) { at.rem = c->rem; at.phi = c->phi; at.fpending = c->fpending; }
-    else { at.rem = c->pipe_rem; at.phi = c->pipe_phi; at.fpending = c->pipe_fpending; }
-    const CallPlan plan = plan_call_at(c, at, frames_in);
-    const size_t n_emit = (size_t)plan.n_emit;
-    if (n_emit * obps > out_capacity_bytes)
-        return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", n_emit * obps, out_capacity_bytes);
     if (frames_in) { c->pipe_rem = plan.rem_next; c->pipe_phi = plan.phi_next; c->pipe_fpending = c->fp.enabled ? plan.fpending_next : at.fpending; }
     else { c->pipe_rem = at.rem; c->pipe_phi = at.phi; c->pipe_fpending = at.fpending; }
-    if (frames_in) { rc = ps.d_out.ensure(n_emit * obps + 16); if (rc) return rc; }
     ps.frames_in = frames_in; ps.n_emit = n_emit; ps.out = out;
     { std::lock_guard<std::mutex> g(c->aux_mu); ps.iq_mag = c->iq_mag; ps.iq_phase = c->iq_phase; }
     ps.ticket = ++c->pipe_seq; ps.busy = true;
@@ -1463,12 +1479,23 @@ extern "C" int iqgpu_chain_enable_iq_probe(iqgpu_chain *c, int enable)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
-    if (enable && !c->d_probe) {
-        if (hipMalloc((void **)&c->d_probe, 1024 * sizeof(cf2)) != hipSuccess) return fail(IQGPU_ENOMEM, "hipMalloc failed");
-        if (hipHostMalloc((void **)&c->h_probe, 1024 * sizeof(cf2), hipHostMallocDefault) != hipSuccess) return fail(IQGPU_ENOMEM, "hipHostMalloc failed");
-        HIP_TRY(hipEventCreateWithFlags(&c->probe_done, hipEventDisableTiming));
+    if (enable && !(c->d_probe && c->h_probe && c->probe_done)) {
+        // all three resources or none: a partial failure leaves nothing behind, so that a second enable() starts over
+        cf2 *dp = nullptr, *hp = nullptr; hipEvent_t ev = nullptr;
+        const bool ok = hipMalloc((void **)&dp, 1024 * sizeof(cf2)) == hipSuccess &&
+                        hipHostMalloc((void **)&hp, 1024 * sizeof(cf2), hipHostMallocDefault) == hipSuccess &&
+                        hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            if (ev) (void)hipEventDestroy(ev);
+            if (hp) (void)hipHostFree(hp);
+            if (dp) (void)hipFree(dp);
+            (void)hipGetLastError();
+            return fail(IQGPU_ENOMEM, "iqgpu_chain_enable_iq_probe: could not allocate the probe buffers");
+        }
+        std::lock_guard<std::mutex> g(c->aux_mu);
+        c->d_probe = dp; c->h_probe = hp; c->probe_done = ev;
     }
-    c->probe_on = enable != 0;
+    { std::lock_guard<std::mutex> g(c->aux_mu); c->probe_on = enable != 0; }     // process_one reads it under the same lock
     return IQGPU_OK;
 }
 

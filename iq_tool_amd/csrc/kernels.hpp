@@ -60,7 +60,12 @@ struct cd2 { double x, y; };
 // k_front: raw -> [unpack, gain] -> [dc block] -> [iq correct] -> [pre NCO] -> [half-band cascade ->
 //          arbitrary polyphase] -> [post NCO] -> [pack] -> out
 // ---------------------------------------------------------------------------------------------
+// diagnostic switches (IQGPU_NO_FAST, IQGPU_AGC_NOFUSE, IQGPU_NO_RAW0, IQGPU_NO_KT, IQGPU_FFT_NO_R16): read from the
+// environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
+enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u };
+
 struct FrontArgs {
+    uint32_t    dbg;          // kDbg* switches of the chain
     // input
     const void *raw;          // frames_in new samples, in_fmt
     const cf2  *hist_in;      // hist_cap processed samples that precede this call
@@ -239,6 +244,7 @@ constexpr int kMaxFftN = 16384;    // k_fftconv16 transforms in place: N cf32 = 
 constexpr int kMaxFftN4 = 8192;    // the radix-4 ping-pong kernel (only used below N = 1024)
 constexpr int kFftMaxThreads = 1024;
 struct FftConvArgs {
+    uint32_t   dbg;           // kDbg* switches of the chain
     const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]
     int64_t    fbuf_len;      // valid cf32 entries in fbuf
     const cf2 *hfreq;         // FFT_N(taps) / N

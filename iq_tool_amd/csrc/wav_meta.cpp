@@ -250,6 +250,9 @@ extern "C" int iqgpu_wav_probe(const char *path, iqgpu_wav_info *md)
     if (!f) return IQGPU_EINVAL;
     unsigned char hdr[12];
     int rc = IQGPU_EINVAL;
+    uint64_t file_size = 0;
+    if (fseeko(f, 0, SEEK_END) == 0) { const off_t e = ftello(f); if (e > 0) file_size = (uint64_t)e; }
+    rewind(f);
     uint64_t ds64_data = 0; bool rf64 = false, have_fmt = false, have_data = false;
     std::vector<unsigned char> auxi;
     if (fread(hdr, 1, 12, f) == 12 && (memcmp(hdr, "RIFF", 4) == 0 || memcmp(hdr, "RF64", 4) == 0) && memcmp(hdr + 8, "WAVE", 4) == 0) {
@@ -277,6 +280,11 @@ extern "C" int iqgpu_wav_probe(const char *path, iqgpu_wav_info *md)
                 if (fread(auxi.data(), 1, (size_t)size, f) != (size_t)size) auxi.clear();
             } else if (memcmp(ch, "data", 4) == 0) {
                 if (rf64 && size == 0xFFFFFFFFu) size = ds64_data;
+                // a capture whose recorder was killed leaves 0 or 0xFFFFFFFF (or any size beyond the file) in the data header:
+                // libsndfile -- what the reference opens the file with (src/input_wav.c:556) -- then takes the data to run to
+                // the end of the file ("wasn't closed properly"; datalength clamped to filelength - dataoffset)
+                const uint64_t avail = file_size > body ? file_size - body : 0;
+                if ((!rf64 && (size == 0 || size == 0xFFFFFFFFu)) || size > avail) size = avail;
                 md->data_offset = body; md->data_bytes = size; have_data = true;
             }
             pos = body + size + (size & 1);

@@ -55,6 +55,9 @@ def main():
     wav("mono.wav", [fmt(1, 48000, 16), chunk(b"data", pcm16)])
     wav("pcm24.wav", [fmt(2, 2400000, 24), chunk(b"data", pcm16 + pcm16[:64])])
     wav("float32_extensible.wav", [chunk(b"fmt ", struct.pack("<HHIIHH", 0xFFFE, 2, 2400000, 2400000 * 8, 8, 32) + struct.pack("<HHIH", 22, 32, 3, 3) + bytes(14)), chunk(b"data", pcm16)])
+    # 7. a recorder that was killed: the data header says 0 / 0xFFFFFFFF / more than the file holds -- libsndfile reads to the end of the file
+    for name, claimed in (("killed_size0_97900000Hz.wav", 0), ("killed_sizeff_97900000Hz.wav", 0xFFFFFFFF), ("killed_toolong_97900000Hz.wav", 4 * 64 + 4000)):
+        wav(name, [fmt(2, 2400000, 16), b"data" + struct.pack("<I", claimed) + pcm16])
     print(sorted(os.listdir(HERE)))
 
 

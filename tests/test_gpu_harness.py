@@ -124,3 +124,110 @@ def test_harness_shards_over_all_visible_devices(gpu, tmp_path):
     parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 400_000:2 * (s + 1) * 400_000]) for s in range(shards)]
     assert np.array_equal(got, np.concatenate(parts))
     assert info["shards"] == shards
+
+
+# --------------------------------------------------------------------------------------------
+# SURVEY 8f-4 on the device: WAV capture -> iqgpu_wav_probe -> iqgpu_wav_shift_hz -> desc.shift_hz -> the HIP chain,
+# against the oracle chain fed the shift that oracle/wav_oracle.py derives from the same bytes
+# (src/input_wav.c:592-629 wav_initialize, src/frequency_shift.c:27-31 which shift the NCO gets)
+# --------------------------------------------------------------------------------------------
+def _riff(chunks):
+    import struct
+    body = b"WAVE" + b"".join(cid + struct.pack("<I", len(b)) + b + (b"\0" if len(b) & 1 else b"") for cid, b in chunks)
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+@pytest.mark.parametrize("case", ["console_xml", "sdruno_binary_cu8", "sdrsharp_filename"])
+@pytest.mark.parametrize("target_hz", [97.7e6, 97.70001e6])          # the second is not a float: the option is one (float)target
+def test_wav_capture_shift_reaches_the_hip_chain(gpu, oracle, tmp_path, case, target_hz):
+    import struct
+    from iq_tool_amd import wav_meta
+    from oracle import wav_oracle
+    fixtures = os.path.join(ROOT, "tests", "golden", "wav")
+    n = 300_000
+    if case == "sdruno_binary_cu8":
+        rate, fmt_name, bits, name = 2_000_000, "cu8", 8, "SDRuno_20240131_123456Z_97900kHz.wav"
+        st = struct.pack("<8H", 2024, 1, 3, 31, 12, 34, 56, 0)
+        auxi = st + st + struct.pack("<I", 97_900_000) + bytes(128)
+    elif case == "console_xml":
+        rate, fmt_name, bits, name = 2_400_000, "cs16", 16, "capture.wav"
+        src = open(os.path.join(fixtures, "console_capture.wav"), "rb").read()
+        p = src.index(b"auxi")
+        auxi = src[p + 8:p + 8 + struct.unpack_from("<I", src, p + 4)[0]]
+    else:
+        rate, fmt_name, bits, name, auxi = 2_400_000, "cs16", 16, "SDRSharp_20240131_123456Z_97900000Hz_IQ.wav", None
+    raw = synth.raw_stream(n, float(rate), 4, fmt_name)
+    ba = 2 * bits // 8
+    chunks = [(b"fmt ", struct.pack("<HHIIHH", 1, 2, rate, rate * ba, ba, bits))]
+    if auxi is not None:
+        chunks.append((b"auxi", auxi))
+    chunks.append((b"data", raw.tobytes()))
+    path = tmp_path / name
+    path.write_bytes(_riff(chunks))
+
+    # product side: the probe gives format, rate, frames, data range and the shift; nothing below is told what the file holds
+    md = wav_meta.probe(str(path))
+    assert md.frames == n and md.sample_rate == rate
+    shift = wav_meta.shift_hz(md, target_hz, 0.0)
+    in_fmt = {11: "cs16", 8: "cu8"}[md.in_format]
+    assert in_fmt == fmt_name
+    with open(path, "rb") as fh:
+        fh.seek(md.data_offset)
+        data = np.frombuffer(fh.read(md.data_bytes), np.int16 if in_fmt == "cs16" else np.uint8)
+    kw = dict(in_format=in_fmt, out_format="cs16", input_rate_hz=float(md.sample_rate), target_rate_hz=744187.5)
+    got = gpu.Chain(shift_hz=shift, **kw).process(data)
+
+    # oracle side: expat-parsed (or binary / file-name) metadata, the reference's shift rule, the oracle chain
+    ref = wav_oracle.new_md()
+    if auxi is not None:
+        wav_oracle.parse_auxi(auxi, ref)
+    wav_oracle.parse_filename(name, ref)
+    err, want_shift = wav_oracle.shift_hz(ref, target_hz, 0.0)
+    assert err is None and want_shift == 97_900_000.0 - float(np.float32(target_hz))
+    assert shift == want_shift
+    want = oracle.Chain(shift_hz=want_shift, **kw).process(raw)
+    assert got.size == want.size and got.size > 0
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.99, (d.max(), (d == 0).mean())
+    # and the shift matters: the same capture without it is a different signal
+    plain = gpu.Chain(shift_hz=0.0, **kw).process(data)
+    assert (plain != got).mean() > 0.5
+
+
+# --------------------------------------------------------------------------------------------
+# row e on one GPU: the REAL step under two ranks (the launcher, the gloo barrier / MAX and two processes on the card)
+# --------------------------------------------------------------------------------------------
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py --gpus 2 with both ranks on this box's one GPU (IQGPU_BENCH_SHARE_GPU): not a scaling figure -- a check that
+    the first multi-GPU run the driver makes is not lost to plumbing (spawned fresh children, one JSON line, n_gpus 2)"""
+    import sys
+    env = dict(os.environ, IQGPU_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-frames", "22",
+                        "--settle-seconds", "0.2", "--no-cpu-baseline", "--no-host-leg", "--no-secondary"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    # two ranks x 3 steps x 2^22 frames over the MAX-over-ranks time: above any CPU rate, below what one card can do
+    assert 1e3 < d["value"] < 2e6, d["value"]
+    assert abs(d["value"] - 2 * 3 * (1 << 22) / (d["ms_per_step"] * 3 * 1e-3) / 1e6) <= 0.01 * d["value"]
+    assert d["roofline"]["launches"] == 3 and d["roofline"]["kernel_ms"] > 0
+
+
+def test_harness_two_devices(gpu, tmp_path):
+    """iqgpu_run --shards 4 --devices 2: shards dealt round-robin over two cards, stitched in file order (skips on a one-GPU box)"""
+    if gpu.load().iqgpu_device_count() < 2:
+        pytest.skip("needs two HIP devices (BASELINE configs[4] runs one shard per GPU); this box has one")
+    n = 4 * 400_000
+    raw = synth.raw_stream(n, 2.4e6, 6, "cs16")
+    fin, fout = tmp_path / "in.cs16", tmp_path / "out.cs16"
+    raw.tofile(fin)
+    info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", "4", "--devices", "2", "--chunk-frames", "131072")
+    got = np.fromfile(fout, np.int16)
+    parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 400_000:2 * (s + 1) * 400_000]) for s in range(4)]
+    assert np.array_equal(got, np.concatenate(parts))
+    assert info["shards"] == 4

@@ -50,6 +50,10 @@ def int_close(a, b, min_same=0.97):
     d = np.abs(a.astype(np.int64) - b.astype(np.int64))
     assert d.max() <= 1, "max code difference %d" % d.max()
     same = float((d == 0).mean())
+    log = _os_agc.environ.get("IQGPU_SAME_LOG")                 # how the bars below were set: measured fraction per call site
+    if log:
+        with open(log, "a") as fh:
+            fh.write("%.6f %.4f %d %s\n" % (same, min_same, a.size, _os_agc.environ.get("PYTEST_CURRENT_TEST", "?")))
     assert same >= min_same, "only %.4f of codes identical" % same
     return same
 

@@ -258,6 +258,22 @@ def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
     assert d1["n_gpus"] == 1
 
 
+def test_bench_spawn_fails_fast_when_a_rank_dies():
+    """a rank that exits before the rendezvous (no GPU for its local rank, an import error) must end the whole
+    run within seconds with its exit code -- not leave rank 0 in the gloo rendezvous until its timeout"""
+    import time
+    env = dict(os.environ, IQGPU_BENCH_STUB="1", IQGPU_BENCH_STUB_FAIL_RANK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--log2-frames", "12"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    assert time.monotonic() - t0 < 60
+    assert "a rank failed" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]      # no result line from a broken run
+
+
 def test_bench_under_a_launcher_reads_ranks_from_the_environment():
     """the driver's form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
     env = dict(os.environ, IQGPU_BENCH_STUB="1")

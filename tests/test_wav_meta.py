@@ -81,6 +81,17 @@ def test_probe_fixtures(wm, wo, name, fmt, rate, frames, center, software, unix)
     assert raw == ch[b"data"]
 
 
+@pytest.mark.parametrize("name", ["killed_size0_97900000Hz.wav", "killed_sizeff_97900000Hz.wav", "killed_toolong_97900000Hz.wav"])
+def test_unclosed_capture_runs_to_the_end_of_the_file(wm, name):
+    """the data header of a capture that was never closed says 0, 0xFFFFFFFF or more than the file holds: libsndfile
+    (sf_open, src/input_wav.c:556) reports the frames that are really there, and so must the probe"""
+    path = os.path.join(WAV, name)
+    md = wm.probe(path)
+    assert md.frames == 64 and md.data_bytes == 256
+    assert md.data_offset + md.data_bytes == os.path.getsize(path)
+    assert md.center_freq_hz == 97900000.0
+
+
 def test_rejected_files(wm):
     import iq_tool_amd
     for name in ("mono.wav", "pcm24.wav", "float32_extensible.wav"):

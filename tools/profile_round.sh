@@ -9,8 +9,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$REPO/profiles"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-leg --settle-seconds 0"
-TIMED="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg"     # default settle: the sustained clock
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-leg --no-secondary --settle-seconds 0"
+TIMED="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-secondary"     # default settle: the sustained clock
 SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES")
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $TIMED > "$OUT/stats.log" 2>&1
 for cfg in 3 4 preset; do
