@@ -35,7 +35,7 @@ def test_harness_matches_chain_and_oracle(gpu, oracle, tmp_path):
     assert np.array_equal(got, want_gpu)                       # chunked + double-buffered == one call
     want = oracle.Chain(**NRSC5).process(raw)
     d = np.abs(got.astype(np.int64) - want.astype(np.int64))
-    assert d.max() <= 1 and (d == 0).mean() > 0.97
+    assert d.max() <= 1 and (d == 0).mean() >= 0.998
 
 
 def test_harness_shards_are_independent_streams_stitched_in_order(gpu, tmp_path):

@@ -3,7 +3,13 @@
 Bars (DESIGN.md "Parity contract"):
   * sample_convert paths (a3, a15): bit-exact;
   * cf32 results of every liquid-derived operator: max |delta| <= 1e-5 on unit-scale signals;
-  * integer outputs of full chains: never more than +-1 LSB apart, >= 97 % identical codes.
+  * integer outputs of full chains: never more than +-1 LSB apart and >= 99.8 % identical codes (>= 99.5 % behind the
+    output AGC, whose gain multiplies the float32 / double difference; >= 99.7 % in the randomised chains).  Set in round 3
+    from the fraction measured at every call site of int_close (IQGPU_SAME_LOG; gpurun_out/r3a/same.txt: cs16 chains
+    0.99903 - 0.99962, cu8 chains 0.99996 - 1.0, AGC chains 0.99671 - 0.99921, fuzz >= 0.99853): the accumulation-order
+    noise of a float32 sum against the oracle's double one is ~1e-7 of full scale = 0.003 LSB of a cs16 code, so about one
+    code in 2000 sits close enough to a rounding boundary to flip.  Arrays too short for the percentage to mean anything
+    may differ in 3 codes.
 """
 import os as _os_agc
 
@@ -45,7 +51,7 @@ def run_oracle(oracle, raw, **kw):
     return oracle.Chain(**kw).process(raw)
 
 
-def int_close(a, b, min_same=0.97):
+def int_close(a, b, min_same=0.998):
     assert a.shape == b.shape, (a.shape, b.shape)
     d = np.abs(a.astype(np.int64) - b.astype(np.int64))
     assert d.max() <= 1, "max code difference %d" % d.max()
@@ -54,7 +60,7 @@ def int_close(a, b, min_same=0.97):
     if log:
         with open(log, "a") as fh:
             fh.write("%.6f %.4f %d %s\n" % (same, min_same, a.size, _os_agc.environ.get("PYTEST_CURRENT_TEST", "?")))
-    assert same >= min_same, "only %.4f of codes identical" % same
+    assert int((d != 0).sum()) <= max(3, int(np.ceil((1.0 - min_same) * a.size))), "only %.5f of %d codes identical (bar %.4f)" % (same, a.size, min_same)
     return same
 
 
@@ -473,8 +479,8 @@ def test_s0_chain_cu8_nrsc5_preset_shape(gpu, oracle, monkeypatch, variant):
     if kw["out_format"] == "cf32":
         assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL and np.abs(cf(slow) - cf(got)).max() <= 6e-6
     else:
-        int_close(got, want, min_same=0.95)
-        int_close(slow, got, min_same=0.99)
+        int_close(got, want, min_same=0.995)
+        int_close(slow, got, min_same=0.998)
 
 
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
@@ -573,7 +579,7 @@ def test_agc_in_nrsc5_preset_chain(gpu, oracle, out_format):
     if out_format == "cf32":
         assert np.abs(cf(got) - cf(want)).max() <= TOL * 20          # gain ~ 3: tolerance scales with it
     else:
-        int_close(got, want, min_same=0.95)
+        int_close(got, want, min_same=0.995)
     assert ch.agc_state()["locked"]
 
 
@@ -611,7 +617,7 @@ def test_agc_rms_profiles_in_preset_chain(gpu, oracle, profile):
             err = np.abs(cf(got) - cf(want))
             assert err.max() <= 2e-5 * max(1.0, np.abs(cf(want)).max()), err.max()
         else:
-            int_close(got, want, min_same=0.98)
+            int_close(got, want, min_same=0.997)
         st = ch.agc_state()
         assert abs(st["gain"] - och.agc.gain) <= 1e-5 * och.agc.gain
         assert abs(st["peak_memory"] - och.agc.y2_prime) <= 1e-5 * och.agc.y2_prime
@@ -723,13 +729,13 @@ def test_cu8_preset_shapes_have_their_own_instantiations(gpu, oracle, monkeypatc
         assert st_fast == st_slow and st_fast["locked"]
     och = oracle.Chain(**kw)
     want = np.concatenate([och.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
-    int_close(fast, want, min_same=0.95 if agc else 0.97)
+    int_close(fast, want, min_same=0.995 if agc else 0.998)
     ch, och = gpu.Chain(**kw), oracle.Chain(**kw)
     for a, b in ((0, 1), (1, 3), (3, 1000), (1000, 70001)):
         g, w = ch.process(raw[2 * a:2 * b]), och.process(raw[2 * a:2 * b])
         assert g.size == w.size
         if w.size:
-            int_close(g, w, min_same=0.9)
+            int_close(g, w, min_same=0.997)
 
 
 @pytest.mark.parametrize("agc", [False, True])
@@ -753,16 +759,16 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
         assert st_fast == st_slow and st_fast["locked"]
     och = oracle.Chain(**kw)
     want = np.concatenate([och.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
-    int_close(fast, want, min_same=0.95 if agc else 0.97)
+    int_close(fast, want, min_same=0.995 if agc else 0.998)
     # one frame, odd sizes, a reset in between: the edge tiles of the instantiation
     ch, och = gpu.Chain(**kw), oracle.Chain(**kw)
     for a, b in ((0, 1), (1, 3), (3, 1000), (1000, 70001)):
         g, w = ch.process(raw[2 * a:2 * b]), och.process(raw[2 * a:2 * b])
         assert g.size == w.size
         if w.size:
-            int_close(g, w, min_same=0.9)
+            int_close(g, w, min_same=0.997)
     ch.reset(); och.reset()
-    int_close(ch.process(raw[:2 * 50000]), och.process(raw[:2 * 50000]), min_same=0.95)
+    int_close(ch.process(raw[:2 * 50000]), och.process(raw[:2 * 50000]), min_same=0.995)
 
 
 @pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,shift", [
@@ -799,7 +805,7 @@ def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatc
     assert np.array_equal(fast, slow)
     och = oracle.Chain(**kw)
     want = np.concatenate([och.process(raw[per * a:per * b]) for a, b in zip(cuts[:-1], cuts[1:])])
-    int_close(fast[:want.size], want, min_same=0.9 if out_format == "cu8" else 0.97)
+    int_close(fast[:want.size], want, min_same=0.998)
 
 
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
@@ -1034,7 +1040,7 @@ def test_random_chain_matches_oracle(gpu, oracle, seed):
         scale = max(1.0, float(np.abs(cf(want)).max()))
         assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL * scale, kw
     else:
-        int_close(got, want, min_same=0.9)
+        int_close(got, want, min_same=0.997)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1323,7 +1329,7 @@ def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case
         okw = dict(kw)
         want = run_oracle(oracle, raw, **okw) if case != "odd_chunk" else None
         if want is not None:
-            int_close(fused, want, min_same=0.95)
+            int_close(fused, want, min_same=0.995)
 
 
 def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):
@@ -1403,7 +1409,7 @@ def test_full_size_secondary_configs(gpu, oracle, name, kw, log2_frames, fmt, ra
     want = run_oracle(oracle, np.tile(seg.view(np.uint8), max(1, (head * bpf) // seg.nbytes))[:head * bpf], **kw)
     dt = want.dtype
     g = out1.view(dt)[:want.size]
-    int_close(g, want, min_same=0.97)
+    int_close(g, want, min_same=0.998)
     d_in.free(); d_out.free()
 
 
@@ -1465,4 +1471,4 @@ def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, sh
         och = oracle.Chain(**kw)
         want = np.concatenate([och.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:])])
         assert want.size == fused.size
-        int_close(fused, want, min_same=0.95)
+        int_close(fused, want, min_same=0.995)
