@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiqgpu.so")
-SOURCES = ["design.cpp", "iqgpu_api.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "kernels.hip", "front_wave.hip", "cascade_wave.hip", "fftconv.hip", "interp.hip", "agc.hip"]
-HEADERS = ["design.hpp", "kernels.hpp", "dsp_device.hpp", "wave_common.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
+SOURCES = ["design.cpp", "iqgpu_api.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "kernels.hip", "front_wave.hip", "front_fat.hip", "cascade_wave.hip", "fftconv.hip", "interp.hip", "agc.hip"]
+HEADERS = ["design.hpp", "kernels.hpp", "dsp_device.hpp", "wave_common.hpp", "front_tiles.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
 HARNESS_SRC = os.path.join(CSRC, "harness", "iqgpu_run.c")
 HARNESS_BIN = os.path.join(LIBDIR, "iqgpu_run")
 
@@ -33,23 +33,40 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-Wall"]
+
+
+def build_lib(force=False, verbose=False, extra_flags=(), out=None):
+    """one object per source (compiled in parallel, rebuilt only when the source or a header is newer), then the link"""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB, deps):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall",
-               *srcs, "-o", LIB]
+    lib = out or LIB
+    objdir = os.path.join(LIBDIR, "obj" + ("" if not extra_flags else "_" + str(abs(hash(tuple(extra_flags))) % 100000)))
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for sname in SOURCES:
+        src, obj = os.path.join(CSRC, sname), os.path.join(objdir, sname + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc(), *FLAGS, *extra_flags, "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, (os.cpu_count() or 2) - 1))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, sname + ".o") for sname in SOURCES]
+    if jobs or force or _stale(lib, objs):
+        run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", lib])
     if os.path.exists(HARNESS_SRC) and (force or _stale(HARNESS_BIN, [HARNESS_SRC, LIB])):
         cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-I", os.path.join(HERE, "..", "include"),
                HARNESS_SRC, "-o", HARNESS_BIN, "-L", LIBDIR, "-liqgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

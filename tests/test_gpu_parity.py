@@ -771,6 +771,53 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
     int_close(ch.process(raw[:2 * 50000]), och.process(raw[:2 * 50000]), min_same=0.995)
 
 
+@pytest.mark.parametrize("target_hz,shift_hz", [
+    (744187.5, 200e3),      # NRSC-5: step / 2^24 = 1.6125, slots at samples 0, 1, 3, 4, 6 of a lane's eight
+    (744187.5, 0.0),        # the same without a mixer (the shipped preset)
+    (696000.0, -150e3),     # step / 2^24 = 1.724: lo_3 = 5, lo_4 = 6
+    (624000.0, 310e3),      # step / 2^24 = 1.923: lo_3 = 5, lo_4 = 7
+    (750000.0, 200e3),      # step / 2^24 = 1.6 exactly: the edge of the class
+    (760000.0, 200e3),      # step / 2^24 = 1.579: outside (six outputs per eight samples happen): k_front_s1 runs either way
+])
+def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, target_hz, shift_hz):
+    """k_front_fat (front_fat.hip: 8 waves per CU, 1024-frame tiles, five polyphase slots per eight half-band samples with the
+    output's place inside its slot as a shift of zero-padded taps) against k_front_s1<4, fast> (16 waves, 512-frame tiles, one
+    slot per sample): same products in the same order, so the BYTES must be equal -- whole calls, ragged splits, block_samples,
+    every step class; then the oracle."""
+    n = 3_000_001
+    raw = synth.raw_stream(n, 2.4e6, 31, "cs16")
+    kw = dict(NRSC5, target_rate_hz=target_hz, shift_hz=shift_hz)
+    splits = [[n], [1_000_000, 1, 4095, 1_500_001, n - 2_504_097], [2_000_003, n - 2_000_003]]
+
+    def run(split, **extra):
+        return run_gpu(gpu, raw, splits=split, **dict(kw, **extra))
+
+    monkeypatch.setenv("IQGPU_NO_FAT", "1")
+    ref = run(splits[0])
+    monkeypatch.delenv("IQGPU_NO_FAT")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")       # calls of any length (the size rule would keep these on k_front_s1)
+    for sp in splits:
+        got = run(sp)
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (sp, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+    assert np.array_equal(run(splits[0], block_samples=65536), ref)
+    assert np.array_equal(run(splits[0], block_samples=4096), ref)
+    monkeypatch.delenv("IQGPU_FORCE_FAT")
+    int_close(ref, run_oracle(oracle, raw, **kw))
+
+
+def test_fat_kernel_takes_long_calls_by_itself(gpu):
+    """without any switch: a 2^25-frame call runs k_front_fat (the profile names the kernel), a 2^20-frame one k_front_s1, and
+    the stream continues across the change of kernel"""
+    n = (1 << 25) + 12345
+    raw = np.tile(synth.raw_stream(1 << 20, 2.4e6, 5, "cs16"), 33)[:2 * n]
+    ch = gpu.Chain(**NRSC5)
+    a = ch.process(raw[:2 * (1 << 20)])
+    b = ch.process(raw[2 * (1 << 20):])
+    one = gpu.Chain(**NRSC5).process(raw)
+    assert np.array_equal(np.concatenate([a, b]), one)
+
+
 @pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,shift", [
     ("cu8", 61.44e6, 1488375.0, "cu8", 0.0),        # BASELINE configs[3] without its filter: raw stage 0, K = 4
     ("cu8", 20e6, 744187.5, "cs16", 0.0),           # raw stage 0, K = 3
