@@ -166,9 +166,28 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     typedef __attribute__((address_space(3))) const v2f lds_v2f;
 
     v2f E[28], acc[8];
-    // ------------------------------------------------------------------ P1: pointwise -> LDS, window reads issued
-    auto P1 = [&](const int64_t T) {
-        v2f x[4][4];
+    v2f x[4][4];
+    v2f t2[8], t3[8], t4[8];                           // taps of slots 2 .. 4
+    v2f y[5];
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto taps = [&](v2f (&t)[8], unsigned row) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + (unsigned)kFTapPlaneB * i);
+    };
+    // The tile loop as a fixed sequence of small batches, LDS batches (at most ~16 operations: a wave can have 15 in flight)
+    // alternating with the FMA runs that cover them; every batch of reads is issued at least one FMA run before its first use.
+    // ---- polyphase window of the tile before: Hw[i] = half-band sample at row coordinate 8 lane + 2 + i (m = i - 14)
+    auto L_slide_h = [&]() { if (lane < 32) sl_h = *(const float *)(HB + sl_src); };     // (every tile: the warm-up ones too)
+    auto L_hw = [&]() {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const float4 v = ldq(wh + (q >> 2) * kFRowB + 16 * (q & 3));
+            Hw[2 * q - 2] = v2f{v.x, v.y}; Hw[2 * q - 1] = v2f{v.z, v.w};
+        }
+        keep(Hw[0]);
+    };
+    // ---- pointwise: unpack, mix
+    auto V_point = [&](const int64_t T) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -181,6 +200,9 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
 #pragma unroll
                 for (int s = 0; s < 4; ++s) x[c][s] = pk_cmul(x[c][s], cs_n[c][s]);
         }
+    };
+    // ---- the mixed samples -> XE / XO (on top of the half-band rows: L_hw has read them)
+    auto L_xwrite = [&]() {
         if (lane < 48) { *(float *)(XE + sl_dst) = sl_e; *(float *)(XO + sl_dst) = sl_o; }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -188,19 +210,22 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
             stq(XO + wq + 16 * c * kFRowB, make_float4(x[c][1].x, x[c][1].y, x[c][3].x, x[c][3].y));
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < 48) { sl_e = *(const float *)(XE + sl_src); sl_o = *(const float *)(XO + sl_src); }
-        // E[j] = even sample at row coordinate 8 lane + 4 + j (24 history samples in front of the tile): output i of the
-        // lane uses E[20 + i - k], k = 0 .. 19
+    };
+    // ---- half-band window: E[j] = even sample at row coordinate 8 lane + 4 + j; output i uses E[20 + i - k], k = 0 .. 19
+    auto L_erows = [&](const int r0, const int r1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = r0; r < r1; ++r)
 #pragma unroll
             for (int q = (r == 0 ? 2 : 0); q < 4; ++q) {
                 const float4 v = ldq(we + r * kFRowB + 16 * q);
                 const int j = 8 * r + 2 * q - 4;
                 E[j] = v2f{v.x, v.y}; E[j + 1] = v2f{v.z, v.w};
             }
-        keep(E[0]);
-        // centre tap: odd sample at row coordinate 8 lane + 14 + i
+        if (r0 == 0) keep(E[0]);
+    };
+    auto L_slide_x = [&]() { if (lane < 48) { sl_e = *(const float *)(XE + sl_src); sl_o = *(const float *)(XO + sl_src); } };
+    // ---- centre tap: odd sample at row coordinate 8 lane + 14 + i
+    auto L_odd = [&]() {
         const float4 o0 = ldq(wo + 1 * kFRowB + 48), o1 = ldq(wo + 2 * kFRowB), o2 = ldq(wo + 2 * kFRowB + 16), o3 = ldq(wo + 2 * kFRowB + 32);
         acc[0] = v2f{o0.x, o0.y}; acc[1] = v2f{o0.z, o0.w}; acc[2] = v2f{o1.x, o1.y}; acc[3] = v2f{o1.z, o1.w};
         acc[4] = v2f{o2.x, o2.y}; acc[5] = v2f{o2.z, o2.w}; acc[6] = v2f{o3.x, o3.y}; acc[7] = v2f{o3.z, o3.w};
@@ -210,31 +235,16 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
             for (int i = 0; i < 8; ++i) acc[i] = v2f{hc * acc[i].x, hc * acc[i].y};
         }
     };
-    // ------------------------------------------------------------------ P2: polyphase + pack + store of the tile before
-    auto P2 = [&]() {
-        // taps: slots 0, 1 were issued behind the half-band of the iteration before; slots 2 .. 4 are issued here, under the
-        // FMAs of the first two
-        auto taps = [&](v2f (&t)[8], unsigned row) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + (unsigned)kFTapPlaneB * i);
-        };
-        v2f t2[8], t3[8], t4[8];
-        taps(t2, trow[2]); taps(t3, trow[3]); taps(t4, trow[4]);
-        v2f y[5];
-        pp_slots2<0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
-        pp_slots3<3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]);
+    // ---- pack + store of the polyphase tile, on to the next one, its tap rows
+    auto V_emit = [&]() {
         uint32_t pk[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
         // the lane's 4 or 5 outputs are consecutive: one 16-byte store and at most one dword
-        {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-            char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 4;
-            keep(pk[4]);                               // computed by every lane beside the others, not as a chain of its own under the branch
-            *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            if (Pl + 4u * step < (8u << 24)) *(uint32_t *)(ob + 16) = pk[4];
-        }
-        // ---- on to the next polyphase tile
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+        char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 4;
+        *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        if (Pl + 4u * step < (8u << 24)) *(uint32_t *)(ob + 16) = pk[4];
         const uint32_t nt = n_est + (((uint64_t)delta0 + c_est) < ((uint64_t)1 << 33) ? 1u : 0u);
         k_tile0 += nt;
         const int32_t e = (int32_t)((int64_t)((uint64_t)nt * step) - ((int64_t)1 << 33));      // |e| < step
@@ -244,69 +254,70 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
         else if (pl >= (int32_t)step) { pl -= (int32_t)step; n0 -= 1u; }
         Pl = (uint32_t)pl;
     };
-    // ------------------------------------------------------------------ P3: half-band -> LDS, polyphase reads issued
-    auto P3 = [&](const int64_t T) {
-        if (!NONCO) nco_lookup(T + 1);
-        // tap rows of the polyphase tile T (computed here, under the window reads): slot j's output has phase Pl + j step
-        // from the lane's first sample: position p = phase >> 24, arm = the next 8 bits, shift d = p - lo_j in {0, 1, 2}:
-        // d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
-        {
-            uint32_t P = Pl;
+    // tap rows of the polyphase tile the state stands at: slot j's output has phase Pl + j step from the lane's first sample:
+    // position p = phase >> 24, arm = the next 8 bits, shift d = p - lo_j in {0, 1, 2}:
+    // d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
+    auto V_taprows = [&]() {
+        uint32_t P = Pl;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const uint32_t arm = (P >> 16) & 255u;
-                const uint32_t d = (P >> 24) - (uint32_t)LO[j];
-                const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
-                trow[j] = w.tap_lds + (arm ^ (arm >> 5)) * 8u + off;
-                P += step;
-            }
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t arm = (P >> 16) & 255u;
+            const uint32_t d = (P >> 24) - (uint32_t)LO[j];
+            const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
+            trow[j] = w.tap_lds + (arm ^ (arm >> 5)) * 8u + off;
+            P += step;
         }
+    };
+    auto V_hb = [&](const int q0, const int q1) {
 #pragma unroll
-        for (int q2 = 0; q2 < 10; ++q2) {
+        for (int q2 = q0; q2 < q1; ++q2) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = fma2(hb[2 * q2], E[20 + i - 2 * q2], acc[i]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = fma2(hb[2 * q2 + 1], E[19 + i - 2 * q2], acc[i]);
         }
-        // the half-band rows live on top of XE: its reads for this tile are all issued
+    };
+    // ---- half-band rows (on top of XE: its reads for this tile are long issued); the lane keeps its own row
+    auto L_hbwrite = [&]() {
         if (lane < 32) *(float *)(HB + sl_dst) = sl_h;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             stq(HB + (2 + lane) * kFRowB + 16 * q, make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y));
         __builtin_amdgcn_wave_barrier();
-        if (lane < 32) sl_h = *(const float *)(HB + sl_src);
-        // Hw[i] = half-band sample at row coordinate 8 lane + 2 + i (16 history samples in front): m = i - 14
-#pragma unroll
-        for (int q = 1; q < 8; ++q) {
-            const float4 v = ldq(wh + (q >> 2) * kFRowB + 16 * (q & 3));
-            Hw[2 * q - 2] = v2f{v.x, v.y}; Hw[2 * q - 1] = v2f{v.z, v.w};
-        }
-        keep(Hw[0]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) own[i] = acc[i];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tp[j][i] = *(lds_v2f *)(size_t)(trow[j] + (unsigned)kFTapPlaneB * i);
     };
 
-    // warm-up tiles and the first emitting one: no polyphase yet
-    for (int64_t T = T_begin; T <= T_emit0; ++T) {
-        P1(T);
-        __builtin_amdgcn_sched_barrier(0);
-        P3(T);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // steady state: three phases, no branch in the body
-    for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) {
-        P1(T);
-        __builtin_amdgcn_sched_barrier(0);
-        P2();
-        __builtin_amdgcn_sched_barrier(0);
-        P3(T);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    P2();                                              // the last tile's polyphase
+    // front half of a tile: pointwise -> X -> half-band -> HB rows; with PP = true the polyphase of the tile before runs between them
+    auto tile = [&](const int64_t T, const bool PP) {
+        L_slide_h(); if (PP) L_hw();
+        FENCE();
+        V_point(T); FENCE();
+        L_xwrite(); if (PP) { taps(t3, trow[3]); taps(t4, trow[4]); } FENCE();
+        if (PP) { pp_slots2<0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]); FENCE(); }
+        L_slide_x(); L_erows(0, 2); FENCE();
+        if (PP) { pp_slots3<3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]); FENCE(); }
+        L_erows(2, 4); L_odd(); FENCE();
+        if (PP) { V_emit(); }
+        V_taprows(); FENCE();
+        if (!NONCO) { nco_lookup(T + 1); FENCE(); }
+        V_hb(0, 3); FENCE();
+        taps(tp[0], trow[0]); FENCE();
+        V_hb(3, 6); FENCE();
+        taps(tp[1], trow[1]); FENCE();
+        V_hb(6, 10); FENCE();
+        taps(t2, trow[2]);
+        L_hbwrite();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) own[i] = acc[i];
+        FENCE();
+    };
+    for (int64_t T = T_begin; T <= T_emit0; ++T) tile(T, false);          // warm-up tiles and the first emitting one: no polyphase yet
+    for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true);        // steady state
+    // the last tile's polyphase
+    L_hw(); taps(t3, trow[3]); taps(t4, trow[4]); FENCE();        // (no slide: nothing follows)
+    pp_slots2<0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+    pp_slots3<3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]);
+    V_emit();
+#undef FENCE
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_fat scales hb0)
