@@ -32,6 +32,7 @@
 // call, unaligned buffers) are run by the scalar-load instantiation of run_tiles (front_tiles.hpp) on a few extra
 // waves, two 512-frame tiles per 1024-frame tile.
 #include "front_tiles.hpp"
+#include "front_fat_common.hpp"
 
 namespace iqgpu {
 
@@ -40,14 +41,9 @@ constexpr int kFatThreads = kFatWaves * 64;
 constexpr int kFRowB = 80;                                  // LDS row: 8 cf32 + 16 B pad (5 slots of 16 bytes)
 constexpr int kFXRows = 3 + 64;                             // 24 history + 512 samples per parity stream
 constexpr int kFatWaveLds = 2 * kFXRows * kFRowB;           // XE, XO; the half-band output rows (2 + 64) live on top of XE
-// polyphase taps: per arm R = 0 0 tap13 .. tap0 0 0 (18 floats).  Pair p of R (R[2p], R[2p+1]) of EVERY arm lives in plane p
-// (8 bytes per arm, arm a at slot a ^ (a >> 5)), planes 0 .. 8; the pairs one float on (R[2p+1], R[2p+2]) in planes 9 .. 16.  A
-// slot reads its 8 pairs from 8 consecutive planes: planes 2056 bytes apart cannot be fused into (half-rate) ds_read2_b64.
-constexpr int kFTapPlaneB = 2048 + 8;
-constexpr int kFTapPlanes = 17;
 constexpr int kFatNcoLds = 2 * 1024 * 8;
 constexpr int kFatArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
-constexpr int kFatTabLds = kFatNcoLds + kFatArbLds + (kFTapPlanes * kFTapPlaneB + 15) / 16 * 16;
+constexpr int kFatTabLds = kFatNcoLds + kFatArbLds + kFTapLds;
 static_assert(kFatWaveLds >= kWaveLds, "an edge wave uses the slice with k_front_s1's layout");
 static_assert(kFatTabLds + kFatWaves * kFatWaveLds <= 160 * 1024, "LDS");
 
@@ -55,44 +51,6 @@ int front_fat_waves() { return kFatWaves; }
 size_t front_fat_lds_bytes() { return (size_t)kFatTabLds + (size_t)kFatWaves * kFatWaveLds; }
 
 struct FatLds { char *XE, *XO; const cf2 *nco; unsigned tap_lds; };
-
-__device__ __forceinline__ v2f fma2(float t, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{t, t}, x, acc); }
-__device__ __forceinline__ v2f mul2(float t, v2f x) { return v2f{t, t} * x; }
-__device__ __forceinline__ float4 ldq(const char *p) { return *(const float4 *)__builtin_assume_aligned(p, 16); }
-__device__ __forceinline__ void stq(char *p, float4 v) { *(float4 *)__builtin_assume_aligned(p, 16) = v; }
-// a loaded register that no FMA touches still counts as used: hipcc would otherwise trim the 16-byte read and re-chunk it
-template <typename T> __device__ __forceinline__ void keep(const T &v) { asm volatile("" :: "v"(v)); }
-
-// One polyphase slot: its output sits at half-band sample LOJ + d of the lane's eight, d in {0, 1, 2}; t = the arm's taps shifted
-// by d between zeros, T[w] = tap[13 + d - w] (0 outside 0 .. 13), w = 0 .. 15 <-> sample LOJ - 13 + w.  Sum in ascending tap
-// order = descending w, started by the first product (k_front_s1's order; the zero taps in front leave +-0).
-// Hw[i] = sample i - 14 (the 13 in front of the lane's own; Hw[0] unused), own[m] = sample m.
-template <int LOJ> struct PpGeom { static constexpr int HI = LOJ + 2 < 7 ? LOJ + 2 : 7, W = HI - LOJ + 14; };
-// step wi of a slot's chain (wi counts down from 15; a slot whose window is shorter starts later)
-template <int LOJ>
-__device__ __forceinline__ void pp_step(const int wi, const v2f (&Hw)[14], const v2f (&own)[8], const v2f (&t)[8], v2f &y)
-{
-    constexpr int W = PpGeom<LOJ>::W;
-    if (wi >= W) return;
-    const int m = LOJ - 13 + wi;
-    const v2f h = m < 0 ? Hw[m + 14] : own[m];
-    const float tw = (wi & 1) ? t[wi >> 1].y : t[wi >> 1].x;
-    y = wi == W - 1 ? mul2(tw, h) : fma2(tw, h, y);
-}
-// two / three slots side by side: their chains are independent, so that no FMA waits for the one before it
-template <int LA, int LB>
-__device__ __forceinline__ void pp_slots2(const v2f (&Hw)[14], const v2f (&own)[8], const v2f (&ta)[8], const v2f (&tb)[8], v2f &ya, v2f &yb)
-{
-#pragma unroll
-    for (int wi = 15; wi >= 0; --wi) { pp_step<LA>(wi, Hw, own, ta, ya); pp_step<LB>(wi, Hw, own, tb, yb); }
-}
-template <int LA, int LB, int LC>
-__device__ __forceinline__ void pp_slots3(const v2f (&Hw)[14], const v2f (&own)[8], const v2f (&ta)[8], const v2f (&tb)[8], const v2f (&tc)[8],
-                                          v2f &ya, v2f &yb, v2f &yc)
-{
-#pragma unroll
-    for (int wi = 15; wi >= 0; --wi) { pp_step<LA>(wi, Hw, own, ta, ya); pp_step<LB>(wi, Hw, own, tb, yb); pp_step<LC>(wi, Hw, own, tc, yc); }
-}
 
 // Tiles [T_begin, T_emit1) of 1024 frames; those from T_emit0 on produce output.  Every tile, and the one behind the
 // last (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
@@ -260,13 +218,7 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     auto V_taprows = [&]() {
         uint32_t P = Pl;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint32_t arm = (P >> 16) & 255u;
-            const uint32_t d = (P >> 24) - (uint32_t)LO[j];
-            const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
-            trow[j] = w.tap_lds + (arm ^ (arm >> 5)) * 8u + off;
-            P += step;
-        }
+        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
     };
     auto V_hb = [&](const int q0, const int q1) {
 #pragma unroll
@@ -292,11 +244,11 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
         FENCE();
         V_point(T); FENCE();
         L_xwrite(); if (PP) { taps(t3, trow[3]); taps(t4, trow[4]); } FENCE();
-        if (PP) { pp_slots2<0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]); FENCE(); }
+        if (PP) { pp_slots2<8, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]); FENCE(); }
         L_slide_x(); L_erows(0, 2); FENCE();
-        if (PP) { pp_slots3<3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]); FENCE(); }
+        if (PP) { pp_slots3<8, 3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]); FENCE(); }
         L_erows(2, 4); L_odd(); FENCE();
-        if (PP) { V_emit(); }
+        if (PP) { keep(y[4]); V_emit(); }       // (slot 4 is computed by every lane beside the others, not as a chain of its own under the store's branch)
         V_taprows(); FENCE();
         if (!NONCO) { nco_lookup(T + 1); FENCE(); }
         V_hb(0, 3); FENCE();
@@ -314,8 +266,9 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true);        // steady state
     // the last tile's polyphase
     L_hw(); taps(t3, trow[3]); taps(t4, trow[4]); FENCE();        // (no slide: nothing follows)
-    pp_slots2<0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
-    pp_slots3<3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]);
+    pp_slots2<8, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+    pp_slots3<8, 3, L3, L4>(Hw, own, t2, t3, t4, y[2], y[3], y[4]);
+    keep(y[4]);
     V_emit();
 #undef FENCE
 }
@@ -346,14 +299,7 @@ __global__ __launch_bounds__(kFatThreads) void k_front_fat(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    for (int i = tid; i < 256 * kFTapPlanes; i += kFatThreads) {        // R[k] = tap[15 - k] for k = 2 .. 15, else 0
-        const int arm = i & 255, pl = i >> 8, row = arm ^ (arm >> 5);
-        const int k0 = pl < 9 ? 2 * pl : 2 * (pl - 9) + 1;
-        const float r0 = (k0 >= 2 && k0 < 16) ? a.arb_table[arm * 16 + 15 - k0] : 0.0f;
-        const float r1 = (k0 + 1 >= 2 && k0 + 1 < 16) ? a.arb_table[arm * 16 + 14 - k0] : 0.0f;
-        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + row * 8);
-        d[0] = r0; d[1] = r1;
-    }
+    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads);
     for (int i = lane; i < kFatWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 

@@ -1,0 +1,78 @@
+// front_fat_common.hpp -- what k_front_fat (front_fat.hip: 8 half-band outputs per lane, 8 waves per CU) and k_front_mid
+// (front_mid.hip: 6 per lane, 12 waves) share: float2 arithmetic the compiler can schedule, aligned LDS accesses, the tap planes
+// of the shifted-tap polyphase slots and the slots themselves.
+#pragma once
+#include "front_tiles.hpp"
+
+namespace iqgpu {
+
+// polyphase taps: per arm R = 0 0 tap13 .. tap0 0 0 (18 floats).  Pair p of R (R[2p], R[2p+1]) of EVERY arm lives in plane p
+// (8 bytes per arm, arm a at slot a ^ (a >> 5)), planes 0 .. 8; the pairs one float on (R[2p+1], R[2p+2]) in planes 9 .. 16.  A
+// slot reads its 8 pairs from 8 consecutive planes: planes 2056 bytes apart cannot be fused into (half-rate) ds_read2_b64.
+constexpr int kFTapPlaneB = 2048 + 8;
+constexpr int kFTapPlanes = 17;
+constexpr int kFTapLds = (kFTapPlanes * kFTapPlaneB + 15) / 16 * 16;
+
+// fills the planes from the [256][16] table of the chain (all threads of the workgroup)
+__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads)
+{
+    for (int i = tid; i < 256 * kFTapPlanes; i += nthreads) {           // R[k] = tap[15 - k] for k = 2 .. 15, else 0
+        const int arm = i & 255, pl = i >> 8, row = arm ^ (arm >> 5);
+        const int k0 = pl < 9 ? 2 * pl : 2 * (pl - 9) + 1;
+        const float r0 = (k0 >= 2 && k0 < 16) ? arb_table[arm * 16 + 15 - k0] : 0.0f;
+        const float r1 = (k0 + 1 >= 2 && k0 + 1 < 16) ? arb_table[arm * 16 + 14 - k0] : 0.0f;
+        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + row * 8);
+        d[0] = r0; d[1] = r1;
+    }
+}
+// LDS address of the (shifted) tap pairs of an output with phase P from the lane's first sample, in the slot whose first
+// possible sample is LOJ: position p = P >> 24, arm = the next 8 bits, shift d = p - LOJ in {0, 1, 2}:
+// d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
+__device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ)
+{
+    const uint32_t arm = (P >> 16) & 255u;
+    const uint32_t d = (P >> 24) - (uint32_t)LOJ;
+    const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
+    return tap_lds + (arm ^ (arm >> 5)) * 8u + off;
+}
+
+__device__ __forceinline__ v2f fma2(float t, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{t, t}, x, acc); }
+__device__ __forceinline__ v2f mul2(float t, v2f x) { return v2f{t, t} * x; }
+__device__ __forceinline__ float4 ldq(const char *p) { return *(const float4 *)__builtin_assume_aligned(p, 16); }
+__device__ __forceinline__ void stq(char *p, float4 v) { *(float4 *)__builtin_assume_aligned(p, 16) = v; }
+// a loaded register that no FMA touches still counts as used: hipcc would otherwise trim the 16-byte read and re-chunk it
+template <typename T> __device__ __forceinline__ void keep(const T &v) { asm volatile("" :: "v"(v)); }
+
+// One polyphase slot: its output sits at half-band sample LOJ + d of the lane's NL, d in {0, 1, 2}; t = the arm's taps shifted
+// by d between zeros, T[w] = tap[13 + d - w] (0 outside 0 .. 13), w = 0 .. 15 <-> sample LOJ - 13 + w.  Sum in ascending tap
+// order = descending w, started by the first product (k_front_s1's order; the zero taps in front leave +-0).
+// Hw[i] = sample i - 14 (the 13 in front of the lane's own; Hw[0] unused), own[m] = sample m.
+template <int NL, int LOJ> struct PpGeom { static constexpr int HI = LOJ + 2 < NL - 1 ? LOJ + 2 : NL - 1, W = HI - LOJ + 14; };
+// step wi of a slot's chain (wi counts down from 15; a slot whose window is shorter starts later)
+template <int NL, int LOJ>
+__device__ __forceinline__ void pp_step(const int wi, const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&t)[8], v2f &y)
+{
+    constexpr int W = PpGeom<NL, LOJ>::W;
+    if (wi >= W) return;
+    const int m = LOJ - 13 + wi;
+    const v2f h = m < 0 ? Hw[m + 14] : own[m];
+    const float tw = (wi & 1) ? t[wi >> 1].y : t[wi >> 1].x;
+    y = wi == W - 1 ? mul2(tw, h) : fma2(tw, h, y);
+}
+// two / three slots side by side: their chains are independent, so that no FMA waits for the one before it
+template <int NL, int LA, int LB>
+__device__ __forceinline__ void pp_slots2(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], const v2f (&tb)[8], v2f &ya, v2f &yb)
+{
+#pragma unroll
+    for (int wi = 15; wi >= 0; --wi) { pp_step<NL, LA>(wi, Hw, own, ta, ya); pp_step<NL, LB>(wi, Hw, own, tb, yb); }
+}
+template <int NL, int LA, int LB, int LC>
+__device__ __forceinline__ void pp_slots3(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], const v2f (&tb)[8], const v2f (&tc)[8],
+                                          v2f &ya, v2f &yb, v2f &yc)
+{
+#pragma unroll
+    for (int wi = 15; wi >= 0; --wi) { pp_step<NL, LA>(wi, Hw, own, ta, ya); pp_step<NL, LB>(wi, Hw, own, tb, yb); pp_step<NL, LC>(wi, Hw, own, tc, yc); }
+}
+
+
+} // namespace iqgpu

@@ -1,0 +1,347 @@
+// front_mid.hip -- k_front_mid: the NRSC-5 preset shape with SIX half-band outputs per lane, 12 waves per CU (3 per SIMD,
+// <= 168 VGPRs), 768-frame tiles.
+//
+// Why a third shape.  On gfx950 one wave issues at most one instruction per four cycles, whatever the instruction, while a SIMD
+// executes a plain VALU instruction in two and a packed one in four: k_front_fat's two waves per SIMD (front_fat.hip) do a
+// third less work per frame than k_front_s1's four, but half of every SIMD's issue slots stay empty whenever one of the two
+// waits -- 0.407 ms against 0.437.  k_front_s1 itself gains nothing from its last four waves (8 / 12 / 16 waves per CU: 0.507 /
+// 0.452 / 0.441 ms), i.e. it is bound by the work, not by latency.  This kernel keeps k_front_fat's formulation (a lane owns a
+// run of consecutive half-band outputs, polyphase slots with shifted zero-padded taps from the tap planes, LDS batches issued
+// a phase ahead) at the widest run that still leaves three waves per SIMD:
+//
+//   * a lane owns 6 consecutive half-band outputs: 25 / 6 = 4.2 reads per even sample (8 per lane: 3.4, 4 per lane: 5.75),
+//     FOUR polyphase slots per 6 samples (a lane's six hold 3 or 4 outputs for step / 2^24 >= 1.5): 63 FMAs per 6 samples
+//     (8 per lane: 79 per 8, 4 per lane: 56 per 4);
+//   * rows need no padding: 6 cf32 are 48 bytes = 3 slots of 16, an odd number, so the sample streams are plain linear arrays
+//     (sample n at byte 8 n) and every window read is a conflict-free ds_read_b128 at an even sample; the writes of 8
+//     consecutive lanes are 128 contiguous bytes;
+//   * tile = 768 frames = 3 coalesced 16-byte loads per lane; 6.7 KB of LDS per wave.
+//
+// Order of a tile (every LDS batch one FMA run ahead of its use, the same window registers never live across two runs):
+//     pointwise(T) -> X(T) in LDS | polyphase(T - 1) + pack + store | raw frames of T + 1, half-band window reads | NCO phasors of T + 1 |
+//     half-band(T) | HB(T) -> LDS, polyphase window + first taps of T
+// Arithmetic and summation order are k_front_s1's: bit-identical output (test_fat_kernel_equals_the_sixteen_wave_kernel).
+// Edge tiles run on the scalar-load run_tiles (front_tiles.hpp): runs of two 768-frame tiles = three of its 512-frame ones.
+#include "front_tiles.hpp"
+#include "front_fat_common.hpp"
+
+namespace iqgpu {
+
+constexpr int kMidWaves = 12;
+constexpr int kMidThreads = kMidWaves * 64;
+constexpr int kMidHb = 384;                                 // half-band samples per tile
+constexpr int kMidXHist = 24, kMidHHist = 18;               // samples of history in front of a tile: even / odd stream, half-band stream
+constexpr int kMidXBytes = (kMidXHist + kMidHb) * 8;        // 3264: one parity stream, sample at row coordinate r at byte 8 r
+constexpr int kMidSlice = 2 * kMidXBytes;                   // XE, XO; the half-band stream lives on top of XE
+constexpr int kMidWaveLds = kMidSlice > kWaveLds ? kMidSlice : kWaveLds;     // (an edge wave uses the slice with k_front_s1's layout)
+constexpr int kMidNcoLds = 2 * 1024 * 8;
+constexpr int kMidArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
+constexpr int kMidTabLds = kMidNcoLds + kMidArbLds + kFTapLds;
+static_assert(kMidTabLds + kMidWaves * kMidWaveLds <= 160 * 1024, "LDS");
+
+int front_mid_waves() { return kMidWaves; }
+size_t front_mid_lds_bytes() { return (size_t)kMidTabLds + (size_t)kMidWaves * kMidWaveLds; }
+
+struct MidLds { char *XE, *XO; const cf2 *nco; unsigned tap_lds; };
+
+// Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
+// (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
+// L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
+template <bool NONCO, int L3>
+__device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
+                                        const int64_t T_begin, const int64_t T_emit0, const int64_t T_emit1)
+{
+    constexpr int NL = 6;
+    constexpr int LO[4] = {0, 1, 3, L3};
+    char *XE = w.XE, *XO = w.XO, *HB = w.XE;
+    const uint32_t step = a.step;
+    float hb[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) hb[k] = a.hb0[k];
+
+    // ---- output bookkeeping of the polyphase tile T_emit0 (wave-uniform), then per lane
+    constexpr uint64_t SPAN = (uint64_t)kMidHb << 24;
+    uint64_t k_tile0 = first_k_at((uint64_t)T_emit0 * SPAN, a.phi0, step);
+    uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - (uint64_t)T_emit0 * SPAN);            // < step
+    const uint32_t n_est = (uint32_t)(SPAN / step);                      // outputs of a tile: n_est or n_est + 1
+    const uint64_t c_est = (uint64_t)n_est * step;
+    uint32_t n0, Pl;                                   // the lane's first output of the tile: index in the tile, phase from sample 6 lane
+    {
+        const uint64_t tgt = (uint64_t)(NL * lane) << 24;
+        const uint64_t nn = tgt > delta0 ? (tgt - delta0 + step - 1) / step : 0;
+        n0 = (uint32_t)nn;
+        Pl = (uint32_t)((uint64_t)delta0 + nn * step - tgt);
+    }
+
+    // ---- per-lane LDS offsets (bytes; a sample at row coordinate r sits at 8 r)
+    const int wq = 8 * kMidXHist + 16 * lane;                           // write slot of chunk 0: even samples 2 lane, 2 lane + 1 (chunk c: 1024 c on)
+    const int sl_src = 8 * kMidHb + 4 * lane, sl_dst = 4 * lane;        // one dword per lane: the stream's tail becomes the next tile's history
+    const char *we = XE + 48 * lane, *wo = XO + 48 * lane, *wh = HB + 48 * lane;
+    typedef __attribute__((address_space(3))) const v2f lds_v2f;
+
+    RawChunk nxt[3];
+    v2f cs_n[3][4];
+    auto load_tile = [&](int64_t T) {
+        const char *src = (const char *)a.raw + (T * 768 - a.rem0) * 4 + 16 * lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
+    };
+    auto nco_lookup = [&](int64_t T) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t th = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                cs_n[c][s] = nco_phasor2(w.nco, th, s & 1);     // the odd stream only meets the centre tap 0.5: half-scaled copy
+                th += a.nco_dtheta;
+            }
+        }
+    };
+    load_tile(T_begin);
+    if (!NONCO) nco_lookup(T_begin);
+
+    float sl_e = 0.f, sl_o = 0.f, sl_h = 0.f;
+    v2f own[NL];                                       // the lane's own half-band outputs of the tile before
+    v2f Hw[14];                                        // the 13 half-band samples in front of them (+ one unused)
+    v2f tp[2][8], tq[2][8];                            // taps of slots 0, 1 (issued a phase ahead) and 2, 3
+    unsigned trow[4];
+    v2f E[26], acc[NL], y[4];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) own[i] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 14; ++i) Hw[i] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tp[j][i] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) trow[j] = w.tap_lds;
+
+    // (the empty asm with a memory clobber orders the LDS accesses around it already when the instruction stream is first laid
+    //  out -- sched_barrier by itself only stops the machine scheduler, and the loads had floated above it before that)
+#define FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    auto taps = [&](v2f (&t)[8], unsigned row) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + (unsigned)kFTapPlaneB * i);
+    };
+    // ---- pointwise, chunk by chunk: unpack, mix, -> XE / XO (on top of the half-band stream: its window reads are issued)
+    auto VL_point = [&]() {
+        if (lane < 48) { *(float *)(XE + sl_dst) = sl_e; *(float *)(XO + sl_dst) = sl_o; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v2f x[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                x[s] = v2f{(float)(short)(nxt[c].w[s] & 0xffffu), (float)(short)(nxt[c].w[s] >> 16)};     // 2^-15: in the table (taps when NONCO)
+                if (!NONCO) x[s] = pk_cmul(x[s], cs_n[c][s]);
+            }
+            stq(XE + wq + 1024 * c, make_float4(x[0].x, x[0].y, x[2].x, x[2].y));
+            stq(XO + wq + 1024 * c, make_float4(x[1].x, x[1].y, x[3].x, x[3].y));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) { sl_e = *(const float *)(XE + sl_src); sl_o = *(const float *)(XO + sl_src); }
+    };
+    // ---- the half-band window: E[j] = even sample at row coordinate 6 lane + 4 + j, output i uses E[20 + i - k], k = 0 .. 19;
+    //      centre tap: odd sample at row coordinate 6 lane + 14 + i
+    auto L_xr = [&]() {
+#pragma unroll
+        for (int q = 0; q < 13; ++q) {
+            const float4 v = ldq(we + 32 + 16 * q);
+            E[2 * q] = v2f{v.x, v.y}; E[2 * q + 1] = v2f{v.z, v.w};
+        }
+        keep(E[0]);
+        const float4 o0 = ldq(wo + 112), o1 = ldq(wo + 128), o2 = ldq(wo + 144);
+        acc[0] = v2f{o0.x, o0.y}; acc[1] = v2f{o0.z, o0.w}; acc[2] = v2f{o1.x, o1.y}; acc[3] = v2f{o1.z, o1.w};
+        acc[4] = v2f{o2.x, o2.y}; acc[5] = v2f{o2.z, o2.w};
+        if (NONCO) {                                   // with a mixer the odd stream is stored as 0.5 x
+            const float hc = 0.5f / 32768.0f;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc[i] = v2f{hc * acc[i].x, hc * acc[i].y};
+        }
+    };
+    // ---- pack + store of the polyphase tile, on to the next one, its tap rows
+    auto V_emit = [&]() {
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
+        // the lane's 3 or 4 outputs are consecutive: one 12-byte store and at most one dword
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 4;
+        *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
+        if (Pl + 3u * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 12) = pk[3];
+        const uint32_t nt = n_est + (((uint64_t)delta0 + c_est) < SPAN ? 1u : 0u);
+        k_tile0 += nt;
+        const int32_t e = (int32_t)((int64_t)((uint64_t)nt * step) - (int64_t)SPAN);           // |e| < step
+        delta0 = (uint32_t)((int32_t)delta0 + e);
+        int32_t pl = (int32_t)Pl + e;
+        if (pl < 0) { pl += (int32_t)step; n0 += 1u; }
+        else if (pl >= (int32_t)step) { pl -= (int32_t)step; n0 -= 1u; }
+        Pl = (uint32_t)pl;
+    };
+    auto V_taprows = [&]() {
+        uint32_t P = Pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
+    };
+    auto V_hb = [&]() {
+#pragma unroll
+        for (int q2 = 0; q2 < 10; ++q2) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc[i] = fma2(hb[2 * q2], E[20 + i - 2 * q2], acc[i]);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc[i] = fma2(hb[2 * q2 + 1], E[19 + i - 2 * q2], acc[i]);
+        }
+    };
+    // ---- half-band outputs -> LDS (on top of XE: its reads for this tile are long issued); the lane keeps its own six; then
+    //      the polyphase window of this tile: Hw[i] = half-band sample at row coordinate 6 lane + 4 + i (m = i - 14), and the
+    //      taps of its first two slots
+    auto L_hb = [&](const bool with_pp_reads) {
+        if (lane < 36) *(float *)(HB + sl_dst) = sl_h;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            stq(HB + 8 * kMidHHist + 48 * lane + 16 * q, make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y));
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36) sl_h = *(const float *)(HB + sl_src);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) own[i] = acc[i];
+        if (with_pp_reads) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const float4 v = ldq(wh + 32 + 16 * q);
+                Hw[2 * q] = v2f{v.x, v.y}; Hw[2 * q + 1] = v2f{v.z, v.w};
+            }
+            keep(Hw[0]);
+            taps(tp[0], trow[0]); taps(tp[1], trow[1]);
+        }
+    };
+
+    auto tile = [&](const int64_t T, const bool PP, const bool next_pp) {
+        VL_point();                                    // (before the polyphase, so that the mixed samples are not held across it)
+        if (PP) { taps(tq[0], trow[2]); taps(tq[1], trow[3]); }
+        FENCE();
+        if (PP) {
+            pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+            pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
+            keep(y[3]);                                // (computed by every lane beside the others, not as a chain of its own under the store's branch)
+            V_emit();
+        }
+        V_taprows();
+        load_tile(T + 1);                              // (tile T_emit1 is readable too: the plan keeps one tile behind every run)
+        FENCE();
+        L_xr(); FENCE();
+        if (!NONCO) { nco_lookup(T + 1); FENCE(); }
+        V_hb(); FENCE();
+        L_hb(next_pp); FENCE();
+    };
+    for (int64_t T = T_begin; T < T_emit0; ++T) tile(T, false, false);     // warm-up tiles
+    tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
+    for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true, true);    // steady state
+    // the last tile's polyphase
+    taps(tq[0], trow[2]); taps(tq[1], trow[3]);
+    pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+    pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
+    keep(y[3]);
+    V_emit();
+#undef FENCE
+}
+
+// NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
+template <bool NONCO, int L3>
+__global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cf2   *s_nco = (cf2 *)smem, *s_nco_half = s_nco + 1024;
+    float *s_arb = (float *)(smem + kMidNcoLds);
+    float *s_tap = (float *)(smem + kMidNcoLds + kMidArbLds);
+    char *slice = (char *)smem + kMidTabLds + wave * kMidWaveLds;
+    if (((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
+
+    if (!NONCO) {
+        const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;               // mix down: conj(phasor)
+        const float scl = 1.0f / 32768.0f;                             // the cs16 normaliser, folded into the table (exact)
+        for (int i = tid; i < 1024; i += kMidThreads) {
+            const cf2 v = a.nco_tab[i];
+            s_nco[i] = cf2{v.x * scl, sgn * v.y * scl};
+            s_nco_half[i] = cf2{v.x * (0.5f * scl), sgn * v.y * (0.5f * scl)};
+        }
+    }
+    for (int i = tid; i < 256 * 14; i += kMidThreads) {                 // the edge waves' rows: arm a in row a ^ (a >> 5) of 56 B
+        const int arm = i / 14, k = i % 14;
+        s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
+    }
+    fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads);
+    for (int i = lane; i < kMidWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int64_t gw = (int64_t)blockIdx.x * kMidWaves + wave;
+    if (gw == 0 && a.frames_in < (int64_t)a.hist_cap) {
+        const int keep_n = a.hist_cap - (int)a.frames_in;
+        for (int i = lane; i < keep_n; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
+    }
+    if (gw < a.w_n_edge) {
+        // edge work in 768-frame tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles), runs of w_edge_tpw = 2 of them from an even
+        // tile: three 512-frame tiles of run_tiles each
+        int64_t t0, t1;
+        if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
+        else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        WaveLds w;
+        w.XE = slice; w.XO = w.XE + kXRows * kRowB; w.HB = w.XO + kHBOff * kRowB;
+        w.nco = s_nco; w.arb = s_arb;
+        w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
+        const int64_t o0 = 3 * t0 / 2, o1 = (3 * t1 + 1) / 2;
+        run_tiles<4, true, true, false, false, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
+    } else {
+        const int64_t r = gw - a.w_n_edge;
+        if (r >= a.w_n_stream) return;
+        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        MidLds w;
+        w.XE = slice; w.XO = slice + kMidXBytes; w.nco = s_nco;
+        w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
+        run_mid<NONCO, L3>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+    }
+}
+
+// step class of the four-slot polyphase: 1.5 <= s < 2 (a lane's 6 samples hold 3 or 4 outputs), lo_3 = floor(3 s)
+static int mid_step_class(uint32_t step)
+{
+    const uint64_t one = (uint64_t)1 << 24;
+    if ((uint64_t)step * 2 < 3 * one || (uint64_t)step >= 2 * one) return 0;      // s < 1.5 or s >= 2
+    const int l3 = (int)(((uint64_t)step * 3) >> 24);
+    return l3 == 4 ? 1 : l3 == 5 ? 2 : 0;
+}
+
+bool front_mid_shape(const FrontArgs &a)
+{
+    return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
+           a.pnco_mode == 0 && !a.agc_fused && !(a.dbg & (kDbgNoFast | kDbgNoFat)) && mid_step_class(a.step) != 0;
+}
+
+hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
+{
+    const bool nonco = a_in.nco_mode == 0;
+    FrontArgs a = a_in;
+    if (nonco) for (float &h : a.hb0) h *= 1.0f / 32768.0f;           // the cs16 normaliser rides on the half-band taps (exact: a power of two)
+    const size_t lds = front_mid_lds_bytes();
+    const int64_t n_items = a.w_n_edge + a.w_n_stream;
+    const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
+    if (grid == 0) return hipSuccess;
+#define IQGPU_LAUNCH_MID(NONCO, L3)                                                                                  \
+    do {                                                                                                              \
+        static LdsAttrCache cache;                /* per instantiation */                                          \
+        { const hipError_t e = cache.ensure((const void *)k_front_mid<NONCO, L3>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_mid<NONCO, L3>), dim3(grid), dim3(kMidThreads), lds, s, a);                     \
+    } while (0)
+    switch (mid_step_class(a.step) * 2 + (nonco ? 1 : 0)) {
+    case 2: IQGPU_LAUNCH_MID(false, 4); break;
+    case 3: IQGPU_LAUNCH_MID(true, 4); break;
+    case 4: IQGPU_LAUNCH_MID(false, 5); break;
+    case 5: IQGPU_LAUNCH_MID(true, 5); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef IQGPU_LAUNCH_MID
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

@@ -238,7 +238,7 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
 // the XCDs finish 10 - 25 % apart, but evening that out inside a workgroup (a wave out of tiles taking half of
 // the longest remaining run over an LDS compare-and-swap) made the launch 15 % SLOWER: a CU's throughput does
 // not fall while its waves retire, so the static deal stays.
-void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames)
+void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames, int align)
 {
     const int kWTile = tile_frames;                 // 512 with a half-band stage in the kernel, 256 without
     const int64_t total = a.w_total_tiles;
@@ -260,6 +260,12 @@ void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_til
         const int64_t t_max = lim >= kWTile ? lim / kWTile - 1 : -1;              // last streamable tile
         // a run over tiles [t0, t1) touches tiles [t0 - warm, t1] (one past its end for the prefetch)
         if (t_max > t_min + warm_tiles) { ta = t_min + warm_tiles; tb = t_max; }
+        // (k_front_mid's 768-frame tiles: the edge runs are handed to the 512-frame tile routine, so the streaming part starts
+        //  and ends at an even tile)
+        if (align > 1 && ta < total) {
+            ta = (ta + align - 1) / align * align; tb = tb / align * align;
+            if (tb <= ta) { ta = total; tb = total; }
+        }
     }
     if (ta > total) ta = total;
     if (tb > total) tb = total;

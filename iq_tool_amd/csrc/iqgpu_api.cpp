@@ -285,7 +285,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
         c->dbg = (getenv("IQGPU_NO_FAST") ? kDbgNoFast : 0u) | (getenv("IQGPU_AGC_NOFUSE") ? kDbgAgcNoFuse : 0u) |
                  (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
                  (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
-                 (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u);
+                 (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_MID") ? kDbgUseMid : 0u);
     }
 
     // ---- ratio (src/setup.c:91-122) ----
@@ -773,6 +773,7 @@ struct Call {
     int64_t total_tiles; int tpb, n_blocks;  // geometry of the workgroup-tiled k_front
     bool casc, fast_s0, fast_s1;             // which front path runs
     bool fat = false;                        // fast_s1 as k_front_fat (front_fat.hip): 8 waves per CU, 1024-frame tiles
+    bool mid = false;                        // ... or as k_front_mid (front_mid.hip): 12 waves per CU, 768-frame tiles
     int wtile, casc_K, rem_k;
     float iq_mag = 0.0f, iq_phase = 0.0f;    // the correction factors this call applies (snapshot under aux_mu)
     bool agc_fused = false;                  // this call: gain applied in the front kernel, verified behind it
@@ -857,14 +858,21 @@ void Call::plan_geometry()
         cplan.step = c->rp.step;
         // the preset shape on a call long enough to give every one of the 8 x CUs fat waves a run of tiles: k_front_fat
         // (shorter calls keep k_front_s1's 16 x CUs waves of 512-frame tiles: what counts for them is latency; same bytes either way)
-        fat = !casc && !fast_s0 && front_fat_shape(cplan) &&
+        const bool fat_ok = !casc && !fast_s0 && front_fat_shape(cplan) &&
               ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * kFatTile * wave_slots(front_fat_waves()));
+        const bool mid_ok = !casc && !fast_s0 && front_mid_shape(cplan) &&
+              ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * kMidTile * wave_slots(front_mid_waves()));
+        mid = mid_ok && ((c->dbg & kDbgUseMid) || !fat_ok);
+        fat = fat_ok && !mid;
         if (fat) wtile = kFatTile;
+        if (mid) wtile = kMidTile;
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
-        plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : front_s1_waves(cplan)),
-                      fat && fixed_tpw() > 1 ? fixed_tpw() / 2 : fixed_tpw(), warm, 1, wtile);
+        int ftpw = fixed_tpw();
+        if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
+        plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves() : front_s1_waves(cplan)),
+                      ftpw, warm, mid ? 2 : 1, wtile, mid ? 2 : 1);
     }
 }
 
@@ -1043,7 +1051,7 @@ int Call::stage_front()
             a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
             HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
         }
-        { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : launch_front_s1(a, c->stream)); }
+        { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream) : launch_front_s1(a, c->stream)); }
         if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
     } else {
         KernelTimer kt(c, IQGPU_K_FRONT);

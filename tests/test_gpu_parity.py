@@ -779,11 +779,14 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
     (750000.0, 200e3),      # step / 2^24 = 1.6 exactly: the edge of the class
     (760000.0, 200e3),      # step / 2^24 = 1.579: outside (six outputs per eight samples happen): k_front_s1 runs either way
 ])
-def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, target_hz, shift_hz):
+@pytest.mark.parametrize("variant", ["fat", "mid"])
+def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, target_hz, shift_hz, variant):
     """k_front_fat (front_fat.hip: 8 waves per CU, 1024-frame tiles, five polyphase slots per eight half-band samples with the
-    output's place inside its slot as a shift of zero-padded taps) against k_front_s1<4, fast> (16 waves, 512-frame tiles, one
-    slot per sample): same products in the same order, so the BYTES must be equal -- whole calls, ragged splits, block_samples,
-    every step class; then the oracle."""
+    output's place inside its slot as a shift of zero-padded taps) and k_front_mid (front_mid.hip: 12 waves, 768-frame tiles, four
+    slots per six samples) against k_front_s1<4, fast> (16 waves, 512-frame tiles, one slot per sample): same products in the
+    same order, so the BYTES must be equal -- whole calls, ragged splits, block_samples, every step class; then the oracle."""
+    if variant == "mid":
+        monkeypatch.setenv("IQGPU_MID", "1")
     n = 3_000_001
     raw = synth.raw_stream(n, 2.4e6, 31, "cs16")
     kw = dict(NRSC5, target_rate_hz=target_hz, shift_hz=shift_hz)
