@@ -32,7 +32,7 @@ constexpr int kMidThreads = kMidWaves * 64;
 constexpr int kMidHb = 384;                                 // half-band samples per tile
 constexpr int kMidXHist = 24, kMidHHist = 18;               // samples of history in front of a tile: even / odd stream, half-band stream
 constexpr int kMidXBytes = (kMidXHist + kMidHb) * 8;        // 3264: one parity stream, sample at row coordinate r at byte 8 r
-constexpr int kMidSlice = 2 * kMidXBytes;                   // XE, XO; the half-band stream lives on top of XE
+constexpr int kMidSlice = kMidXBytes;                       // XE; the half-band stream lives on top of it (there is no XO stream: see run_mid)
 constexpr int kMidWaveLds = kMidSlice > kWaveLds ? kMidSlice : kWaveLds;     // (an edge wave uses the slice with k_front_s1's layout)
 constexpr int kMidNcoLds = 2 * 1024 * 8;
 constexpr int kMidArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
@@ -42,7 +42,7 @@ static_assert(kMidTabLds + kMidWaves * kMidWaveLds <= 160 * 1024, "LDS");
 int front_mid_waves() { return kMidWaves; }
 size_t front_mid_lds_bytes() { return (size_t)kMidTabLds + (size_t)kMidWaves * kMidWaveLds; }
 
-struct MidLds { char *XE, *XO; const cf2 *nco; unsigned tap_lds; };
+struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 
 // Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
 // (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
@@ -53,7 +53,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 {
     constexpr int NL = 6;
     constexpr int LO[4] = {0, 1, 3, L3};
-    char *XE = w.XE, *XO = w.XO, *HB = w.XE;
+    char *XE = w.XE, *HB = w.XE;
     const uint32_t step = a.step;
     float hb[20];
 #pragma unroll
@@ -76,31 +76,44 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // ---- per-lane LDS offsets (bytes; a sample at row coordinate r sits at 8 r)
     const int wq = 8 * kMidXHist + 16 * lane;                           // write slot of chunk 0: even samples 2 lane, 2 lane + 1 (chunk c: 1024 c on)
     const int sl_src = 8 * kMidHb + 4 * lane, sl_dst = 4 * lane;        // one dword per lane: the stream's tail becomes the next tile's history
-    const char *we = XE + 48 * lane, *wo = XO + 48 * lane, *wh = HB + 48 * lane;
+    const char *we = XE + 48 * lane, *wh = HB + 48 * lane;
     typedef __attribute__((address_space(3))) const v2f lds_v2f;
 
-    RawChunk nxt[3];
-    v2f cs_n[3][4];
-    auto load_tile = [&](int64_t T) {
+    // Raw frames: the coalesced stream (lane: frames 256 c + 4 lane .. + 3 of the tile) feeds the EVEN samples, which every lane's
+    // window needs and which therefore go through LDS.  The ODD samples meet one tap only, the centre tap of one output -- output
+    // i of the lane takes the odd sample 6 lane + i - 10, frame 12 lane - 19 + 2 i of the tile -- so the lane fetches its own six
+    // straight from memory a second time (three more 16-byte loads at frame 12 lane - 20: the lines are in L2 / L1 from the
+    // coalesced loads, HBM sees them once) instead of writing them to LDS for another lane to read: no XO stream at all.
+    RawChunk nxt[3], nxo[3];
+    v2f cs_n[3][2], cs_o[NL];
+    auto load_even = [&](int64_t T) {
         const char *src = (const char *)a.raw + (T * 768 - a.rem0) * 4 + 16 * lane;
 #pragma unroll
         for (int c = 0; c < 3; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
     };
+    auto load_odd = [&](int64_t T) {
+        const char *src = (const char *)a.raw + (T * 768 - a.rem0) * 4 + 48 * lane - 80;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_chunk<4>(src + 16 * c, nxo[c]);
+    };
     auto nco_lookup = [&](int64_t T) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            uint32_t th = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+            const uint32_t th = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+            cs_n[c][0] = nco_phasor2(w.nco, th, 0);
+            cs_n[c][1] = nco_phasor2(w.nco, th + 2u * a.nco_dtheta, 0);
+        }
+        uint32_t tho = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(12 * lane - 19)) * a.nco_dtheta;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                cs_n[c][s] = nco_phasor2(w.nco, th, s & 1);     // the odd stream only meets the centre tap 0.5: half-scaled copy
-                th += a.nco_dtheta;
-            }
+        for (int i = 0; i < NL; ++i) {
+            cs_o[i] = nco_phasor2(w.nco, tho, 1);               // the odd stream only meets the centre tap 0.5: half-scaled copy
+            tho += 2u * a.nco_dtheta;
         }
     };
-    load_tile(T_begin);
+    load_even(T_begin); load_odd(T_begin);
     if (!NONCO) nco_lookup(T_begin);
 
-    float sl_e = 0.f, sl_o = 0.f, sl_h = 0.f;
+    float sl_e = 0.f, sl_h = 0.f;
     v2f own[NL];                                       // the lane's own half-band outputs of the tile before
     v2f Hw[14];                                        // the 13 half-band samples in front of them (+ one unused)
     v2f tp[2][8], tq[2][8];                            // taps of slots 0, 1 (issued a phase ahead) and 2, 3
@@ -126,23 +139,19 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     };
     // ---- pointwise, chunk by chunk: unpack, mix, -> XE / XO (on top of the half-band stream: its window reads are issued)
     auto VL_point = [&]() {
-        if (lane < 48) { *(float *)(XE + sl_dst) = sl_e; *(float *)(XO + sl_dst) = sl_o; }
+        if (lane < 48) *(float *)(XE + sl_dst) = sl_e;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            v2f x[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                x[s] = v2f{(float)(short)(nxt[c].w[s] & 0xffffu), (float)(short)(nxt[c].w[s] >> 16)};     // 2^-15: in the table (taps when NONCO)
-                if (!NONCO) x[s] = pk_cmul(x[s], cs_n[c][s]);
-            }
-            stq(XE + wq + 1024 * c, make_float4(x[0].x, x[0].y, x[2].x, x[2].y));
-            stq(XO + wq + 1024 * c, make_float4(x[1].x, x[1].y, x[3].x, x[3].y));
+            v2f x0 = v2f{(float)(short)(nxt[c].w[0] & 0xffffu), (float)(short)(nxt[c].w[0] >> 16)};      // 2^-15: in the table (taps when NONCO)
+            v2f x2 = v2f{(float)(short)(nxt[c].w[2] & 0xffffu), (float)(short)(nxt[c].w[2] >> 16)};
+            keep(nxt[c].w[1]); keep(nxt[c].w[3]);       // (whole 16-byte loads: unused words declared used, or hipcc narrows them to dword loads)
+            if (!NONCO) { x0 = pk_cmul(x0, cs_n[c][0]); x2 = pk_cmul(x2, cs_n[c][1]); }
+            stq(XE + wq + 1024 * c, make_float4(x0.x, x0.y, x2.x, x2.y));
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < 48) { sl_e = *(const float *)(XE + sl_src); sl_o = *(const float *)(XO + sl_src); }
+        if (lane < 48) sl_e = *(const float *)(XE + sl_src);
     };
-    // ---- the half-band window: E[j] = even sample at row coordinate 6 lane + 4 + j, output i uses E[20 + i - k], k = 0 .. 19;
-    //      centre tap: odd sample at row coordinate 6 lane + 14 + i
+    // ---- the half-band window: E[j] = even sample at row coordinate 6 lane + 4 + j, output i uses E[20 + i - k], k = 0 .. 19
     auto L_xr = [&]() {
 #pragma unroll
         for (int q = 0; q < 13; ++q) {
@@ -150,13 +159,17 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
             E[2 * q] = v2f{v.x, v.y}; E[2 * q + 1] = v2f{v.z, v.w};
         }
         keep(E[0]);
-        const float4 o0 = ldq(wo + 112), o1 = ldq(wo + 128), o2 = ldq(wo + 144);
-        acc[0] = v2f{o0.x, o0.y}; acc[1] = v2f{o0.z, o0.w}; acc[2] = v2f{o1.x, o1.y}; acc[3] = v2f{o1.z, o1.w};
-        acc[4] = v2f{o2.x, o2.y}; acc[5] = v2f{o2.z, o2.w};
-        if (NONCO) {                                   // with a mixer the odd stream is stored as 0.5 x
-            const float hc = 0.5f / 32768.0f;
+    };
+    // ---- centre taps: the lane's own six odd samples (words 1, 3, .. 11 of its second load), mixed with the half-scaled table
+    auto V_centre = [&]() {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) acc[i] = v2f{hc * acc[i].x, hc * acc[i].y};
+        for (int c = 0; c < 3; ++c) { keep(nxo[c].w[0]); keep(nxo[c].w[2]); }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const uint32_t wd = nxo[(2 * i + 1) >> 2].w[(2 * i + 1) & 3];
+            const v2f o = v2f{(float)(short)(wd & 0xffffu), (float)(short)(wd >> 16)};
+            if (NONCO) { const float hc = 0.5f / 32768.0f; acc[i] = v2f{hc * o.x, hc * o.y}; }
+            else acc[i] = pk_cmul(o, cs_o[i]);
         }
     };
     // ---- pack + store of the polyphase tile, on to the next one, its tap rows
@@ -226,9 +239,12 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
             V_emit();
         }
         V_taprows();
-        load_tile(T + 1);                              // (tile T_emit1 is readable too: the plan keeps one tile behind every run)
+        load_even(T + 1);                              // (tile T_emit1 is readable too: the plan keeps one tile behind every run)
         FENCE();
-        L_xr(); FENCE();
+        L_xr();
+        V_centre();
+        load_odd(T + 1);
+        FENCE();
         if (!NONCO) { nco_lookup(T + 1); FENCE(); }
         V_hb(); FENCE();
         L_hb(next_pp); FENCE();
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
         MidLds w;
-        w.XE = slice; w.XO = slice + kMidXBytes; w.nco = s_nco;
+        w.XE = slice; w.nco = s_nco;
         w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
         run_mid<NONCO, L3>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
     }

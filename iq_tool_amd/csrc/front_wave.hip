@@ -238,7 +238,7 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
 // the XCDs finish 10 - 25 % apart, but evening that out inside a workgroup (a wave out of tiles taking half of
 // the longest remaining run over an LDS compare-and-swap) made the launch 15 % SLOWER: a CU's throughput does
 // not fall while its waves retire, so the static deal stays.
-void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames, int align)
+void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tpw, int tile_frames, int align, int lead)
 {
     const int kWTile = tile_frames;                 // 512 with a half-band stage in the kernel, 256 without
     const int64_t total = a.w_total_tiles;
@@ -255,7 +255,7 @@ void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_til
     // (cs24 output takes six byte stores per frame: the streaming loop counts on one)
     if (vb != 0 && a.out_fmt != IQGPU_FMT_CS24 && a.raw_aligned && (((int64_t)a.rem0 * vb) & 15) == 0) {
         // tile t is streamable iff 512 t - rem0 >= 0 and 512 (t + 1) - rem0 <= frames_in - hist_cap
-        const int64_t t_min = (a.rem0 + kWTile - 1) / kWTile;
+        const int64_t t_min = (a.rem0 + lead + kWTile - 1) / kWTile;     // (lead: frames in front of its first tile that a streaming run reads as well)
         const int64_t lim = a.frames_in - (int64_t)a.hist_cap + a.rem0;
         const int64_t t_max = lim >= kWTile ? lim / kWTile - 1 : -1;              // last streamable tile
         // a run over tiles [t0, t1) touches tiles [t0 - warm, t1] (one past its end for the prefetch)

@@ -872,7 +872,7 @@ void Call::plan_geometry()
         int ftpw = fixed_tpw();
         if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
         plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves() : front_s1_waves(cplan)),
-                      ftpw, warm, mid ? 2 : 1, wtile, mid ? 2 : 1);
+                      ftpw, warm, mid ? 2 : 1, wtile, mid ? 2 : 1, mid ? kMidLead : 0);
     }
 }
 

@@ -169,13 +169,14 @@ size_t front_fat_lds_bytes();
 hipError_t launch_front_fat(const FrontArgs &a, hipStream_t s);
 // ... and with 6 half-band outputs per lane, 12 waves per CU, 768-frame tiles (front_mid.hip)
 constexpr int kMidTile = 768;
+constexpr int kMidLead = 20;                 // a streaming run of k_front_mid reads this many frames in front of its first tile
 int front_mid_waves();
 bool front_mid_shape(const FrontArgs &a);
 size_t front_mid_lds_bytes();
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
 // wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles
-void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile, int align = 1);
+void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile, int align = 1, int lead = 0);
 
 // ---------------------------------------------------------------------------------------------
 // DC-blocker carry: per-segment aggregates, then a sequential scan over the (few) segments
