@@ -218,7 +218,7 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     auto V_taprows = [&]() {
         uint32_t P = Pl;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
+        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j], a.tap_fold_mul, a.tap_fold_shift); P += step; }
     };
     auto V_hb = [&](const int q0, const int q1) {
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kFatThreads) void k_front_fat(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads);
+    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads, a.tap_fold_mul, a.tap_fold_shift);
     for (int i = lane; i < kFatWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 

@@ -14,10 +14,15 @@ constexpr int kFTapPlanes = 17;
 constexpr int kFTapLds = (kFTapPlanes * kFTapPlaneB + 15) / 16 * 16;
 
 // fills the planes from the [256][16] table of the chain (all threads of the workgroup)
-__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads)
+__device__ __forceinline__ uint32_t tap_fold(const uint32_t arm, const uint32_t mul, const uint32_t shift)
+{
+    const uint32_t m = (arm * mul) & 255u;
+    return m ^ (m >> shift);
+}
+__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads, const uint32_t mul, const uint32_t shift)
 {
     for (int i = tid; i < 256 * kFTapPlanes; i += nthreads) {           // R[k] = tap[15 - k] for k = 2 .. 15, else 0
-        const int arm = i & 255, pl = i >> 8, row = arm ^ (arm >> 5);
+        const int arm = i & 255, pl = i >> 8, row = (int)tap_fold((uint32_t)arm, mul, shift);
         const int k0 = pl < 9 ? 2 * pl : 2 * (pl - 9) + 1;
         const float r0 = (k0 >= 2 && k0 < 16) ? arb_table[arm * 16 + 15 - k0] : 0.0f;
         const float r1 = (k0 + 1 >= 2 && k0 + 1 < 16) ? arb_table[arm * 16 + 14 - k0] : 0.0f;
@@ -28,12 +33,12 @@ __device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_t
 // LDS address of the (shifted) tap pairs of an output with phase P from the lane's first sample, in the slot whose first
 // possible sample is LOJ: position p = P >> 24, arm = the next 8 bits, shift d = p - LOJ in {0, 1, 2}:
 // d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
-__device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ)
+__device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ, const uint32_t mul, const uint32_t shift)
 {
     const uint32_t arm = (P >> 16) & 255u;
     const uint32_t d = (P >> 24) - (uint32_t)LOJ;
     const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
-    return tap_lds + (arm ^ (arm >> 5)) * 8u + off;
+    return tap_lds + tap_fold(arm, mul, shift) * 8u + off;
 }
 
 __device__ __forceinline__ v2f fma2(float t, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{t, t}, x, acc); }

@@ -62,10 +62,13 @@ struct cd2 { double x, y; };
 // ---------------------------------------------------------------------------------------------
 // diagnostic switches (IQGPU_NO_FAST, IQGPU_AGC_NOFUSE, IQGPU_NO_RAW0, IQGPU_NO_KT, IQGPU_FFT_NO_R16): read from the
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
-enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseMid = 128u };
+enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u };
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
+    // k_front_fat / k_front_mid: where arm a sits in a tap plane: slot f(a) = m ^ (m >> tap_fold_shift), m = (a * tap_fold_mul) & 255
+    // (tap_fold_mul odd: a bijection; chosen per chain for the fewest LDS bank conflicts of its step, iqgpu_api.cpp)
+    uint32_t    tap_fold_mul, tap_fold_shift;
     // input
     const void *raw;          // frames_in new samples, in_fmt
     const cf2  *hist_in;      // hist_cap processed samples that precede this call

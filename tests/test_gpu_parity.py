@@ -785,8 +785,8 @@ def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, tar
     output's place inside its slot as a shift of zero-padded taps) and k_front_mid (front_mid.hip: 12 waves, 768-frame tiles, four
     slots per six samples) against k_front_s1<4, fast> (16 waves, 512-frame tiles, one slot per sample): same products in the
     same order, so the BYTES must be equal -- whole calls, ragged splits, block_samples, every step class; then the oracle."""
-    if variant == "mid":
-        monkeypatch.setenv("IQGPU_MID", "1")
+    if variant == "fat":
+        monkeypatch.setenv("IQGPU_FAT", "1")
     n = 3_000_001
     raw = synth.raw_stream(n, 2.4e6, 31, "cs16")
     kw = dict(NRSC5, target_rate_hz=target_hz, shift_hz=shift_hz)
