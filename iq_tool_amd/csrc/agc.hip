@@ -190,23 +190,28 @@ __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
 // the state advances here: samples_seen, and the strong-peak time of the last healthy chunk.  Anything else sets
 // *verify_flag: the unfused kernels queued behind redo the call from the untouched state.
 // verify_flag[0] = the verdict (the fallback launches' run_if); [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk
-// (reset by k_agc_verify for the next call; zero / -1 at create)
+// (reset by k_agc_verify for the next call; zero / -1 at create).  k_agc_classify hands the peak array back zeroed (round 3:
+// a fill in front of every fused launch did that; folding the classification into the one verdict workgroup was tried and
+// is slower -- 16384 chunks of closed-form bookkeeping on one CU take 30 us).
 __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const AgcState st = *a.state;
     int bad = 0, weak = 0, last_h = -1;
-    if (st.locked && c < a.geom.n_chunks) {
-        const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+    if (c < a.geom.n_chunks) {
         int k = 0;
-        if (e > b) {                                               // empty chunks never reach agc_apply
-            const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
-            const float outp = pk * st.gain;
-            if (outp > 1.0f) bad = 1;                              // ratchet
-            else if (outp > a.target * kAgcLower) { k = 1; last_h = c; }
-            else { k = 2; weak = 1; }
+        if (st.locked) {
+            const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+            if (e > b) {                                           // empty chunks never reach agc_apply
+                const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
+                const float outp = pk * st.gain;
+                if (outp > 1.0f) bad = 1;                          // ratchet
+                else if (outp > a.target * kAgcLower) { k = 1; last_h = c; }
+                else { k = 2; weak = 1; }
+            }
         }
         a.chunk_len[c] = k;                                        // scratch: 0 empty, 1 healthy, 2 weak
+        a.peak2[c] = 0ull;                                         // handed back zeroed: the next fused launch accumulates into it (no fill on the hot path)
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 1, 1);
     if (__ballot(weak) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 2, 1);

@@ -47,7 +47,7 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
 // (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
 // L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
-template <bool NONCO, int L3>
+template <bool NONCO, int L3, bool AGC>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, const int64_t T_emit1)
 {
@@ -71,6 +71,20 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         const uint64_t nn = tgt > delta0 ? (tgt - delta0 + step - 1) / step : 0;
         n0 = (uint32_t)nn;
         Pl = (uint32_t)((uint64_t)delta0 + nn * step - tgt);
+    }
+
+    // fused output AGC of the locked phase (as in k_front_s1, front_tiles.hpp): the gain from the device state multiplies every
+    // output before the pack, and the exact max |y|^2 (double) of the chunk the run is in and of the next one is kept per lane;
+    // a chunk ends where input frame (c + 1) chunk - 1 completes a half-band sample: at most one boundary per tile (chunk >= 768)
+    float agc_g = 1.0f;
+    double agc_m0 = 0.0, agc_m1 = 0.0;
+    int64_t agc_c = 0, agc_B = 0, agc_T = T_emit0;
+    const int AS = AGC ? a.agc_shift : 0;
+    if (AGC) {
+        agc_g = a.agc_state->gain;
+        const int64_t F0 = (((int64_t)kMidHb * T_emit0 + 1) << AS) - 1 - a.agc_rem;
+        agc_c = F0 > 0 ? F0 / a.agc_chunk_frames : 0;
+        agc_B = (agc_c + 1) * a.agc_chunk_frames;
     }
 
     // ---- per-lane LDS offsets (bytes; a sample at row coordinate r sits at 8 r)
@@ -174,6 +188,36 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     };
     // ---- pack + store of the polyphase tile, on to the next one, its tap rows
     auto V_emit = [&]() {
+        if (AGC) {
+            uint32_t agc_qb = (uint32_t)kMidHb;             // half-band samples of this tile below it are in chunk agc_c
+            const int64_t F0 = (((int64_t)kMidHb * agc_T + 1) << AS) - 1 - a.agc_rem;   // last input frame that sample 0 of the tile needs
+            if (F0 >= agc_B) {                              // the boundary fell between two tiles
+                const double m = wave_max_d(agc_m0);
+                if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+                agc_m0 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
+            }
+            const int64_t d = agc_B - F0;
+            if (d < ((int64_t)kMidHb << AS)) agc_qb = (uint32_t)((d + ((int64_t)1 << AS) - 1) >> AS);
+            uint32_t P = Pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pos = P >> 24;               // the output's half-band sample among the lane's six (slot 3: may be past them)
+                if (j < 3 || pos < (uint32_t)NL) {
+                    // agc_apply: peak of the chunk over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
+                    const double re = (double)y[j].x, im = (double)y[j].y;
+                    const double m2 = fma(re, re, im * im);  // exact: products of floats, sum below 2^53 ulps
+                    if ((uint32_t)(NL * lane) + pos < agc_qb) agc_m0 = fmax(agc_m0, m2); else agc_m1 = fmax(agc_m1, m2);
+                }
+                y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
+                P += step;
+            }
+            if (agc_qb < (uint32_t)kMidHb) {                // the tile held a boundary: chunk agc_c is complete for this run
+                const double m = wave_max_d(agc_m0);
+                if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+                agc_m0 = agc_m1; agc_m1 = 0.0; agc_c += 1; agc_B += a.agc_chunk_frames;
+            }
+            agc_T += 1;
+        }
         uint32_t pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
@@ -258,13 +302,18 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
     keep(y[3]);
     V_emit();
+    if (AGC) {
+        const double m = wave_max_d(agc_m0);
+        if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
+    }
 #undef FENCE
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
-template <bool NONCO, int L3>
+template <bool NONCO, int L3, bool AGC>
 __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;         // (a fallback launch whose fused predecessor stood: never the case today, kept for symmetry)
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,7 +356,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         w.nco = s_nco; w.arb = s_arb;
         w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
         const int64_t o0 = 3 * t0 / 2, o1 = (3 * t1 + 1) / 2;
-        run_tiles<4, true, true, false, false, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
+        run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
@@ -315,7 +364,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         MidLds w;
         w.XE = slice; w.nco = s_nco;
         w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_mid<NONCO, L3>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        run_mid<NONCO, L3, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
     }
 }
 
@@ -331,7 +380,8 @@ static int mid_step_class(uint32_t step)
 bool front_mid_shape(const FrontArgs &a)
 {
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
-           a.pnco_mode == 0 && !a.agc_fused && !(a.dbg & (kDbgNoFast | kDbgNoFat)) && mid_step_class(a.step) != 0;
+           a.pnco_mode == 0 && (!a.agc_fused || (a.agc_shift == 1 && a.agc_chunk_frames >= kMidTile)) &&
+           !(a.dbg & (kDbgNoFast | kDbgNoFat)) && mid_step_class(a.step) != 0;
 }
 
 hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
@@ -343,17 +393,21 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_MID(NONCO, L3)                                                                                  \
+#define IQGPU_LAUNCH_MID(NONCO, L3, AGC)                                                                             \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_mid<NONCO, L3>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_mid<NONCO, L3>), dim3(grid), dim3(kMidThreads), lds, s, a);                     \
+        { const hipError_t e = cache.ensure((const void *)k_front_mid<NONCO, L3, AGC>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_mid<NONCO, L3, AGC>), dim3(grid), dim3(kMidThreads), lds, s, a);                \
     } while (0)
-    switch (mid_step_class(a.step) * 2 + (nonco ? 1 : 0)) {
-    case 2: IQGPU_LAUNCH_MID(false, 4); break;
-    case 3: IQGPU_LAUNCH_MID(true, 4); break;
-    case 4: IQGPU_LAUNCH_MID(false, 5); break;
-    case 5: IQGPU_LAUNCH_MID(true, 5); break;
+    switch (mid_step_class(a.step) * 4 + (nonco ? 1 : 0) + (a.agc_fused ? 2 : 0)) {
+    case 4: IQGPU_LAUNCH_MID(false, 4, false); break;
+    case 5: IQGPU_LAUNCH_MID(true, 4, false); break;
+    case 6: IQGPU_LAUNCH_MID(false, 4, true); break;
+    case 7: IQGPU_LAUNCH_MID(true, 4, true); break;
+    case 8: IQGPU_LAUNCH_MID(false, 5, false); break;
+    case 9: IQGPU_LAUNCH_MID(true, 5, false); break;
+    case 10: IQGPU_LAUNCH_MID(false, 5, true); break;
+    case 11: IQGPU_LAUNCH_MID(true, 5, true); break;
     default: return hipErrorInvalidValue;
     }
 #undef IQGPU_LAUNCH_MID

@@ -138,6 +138,7 @@ struct iqgpu_chain {
     AgcState *d_agc_state = nullptr; AgcState agc_init{};
     float agc_rms_alpha = 0.0f;     // > 0: profile dx / local (liquid agc_crcf), AgcState.gain = g, .peak_memory = y2_prime
     DevBuf abuf, agc_peak, agc_gain, agc_peak_b;
+    bool agc_peak_clean = false;  // agc_peak is all zero: what a fused front launch needs (k_agc_verify leaves it so; the unfused kernels do not)
     // fused AGC of the locked phase (k_front_s1<.., AGC> + k_agc_verify): which chains qualify, the host's mirror of
     // "has the stream locked" (a closed form: the first chunk that starts after AGC_DIGITAL_LOCK_TIME of output), the
     // flag the verifier leaves for the fallback launches
@@ -802,6 +803,15 @@ struct Call {
         dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
     }
     int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
+    // the per-chunk peaks a fused front launch accumulates into start from zero: k_agc_verify zeroes what it has read, so only
+    // the first fused call behind an unfused one (or behind a reallocation) pays for a fill
+    hipError_t clean_agc_peaks()
+    {
+        if (c->agc_peak_clean) return hipSuccess;
+        const hipError_t e = hipMemsetAsync(c->agc_peak.p, 0, c->agc_peak.cap, c->stream);
+        if (e == hipSuccess) c->agc_peak_clean = true;
+        return e;
+    }
 
     void plan_geometry();
     DcGeom dc_geom() const;
@@ -853,7 +863,7 @@ void Call::plan_geometry()
             for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
             cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);
         }
-        cplan.agc_fused = agc_fused ? 1 : 0;
+        cplan.agc_fused = agc_fused ? 1 : 0; cplan.agc_shift = c->S; cplan.agc_chunk_frames = c->agc_chunk;
         cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
         cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
         cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;
@@ -951,8 +961,10 @@ int Call::prepare_buffers()
     } else if (c->agc) {
         const AgcGeom g = agc_geom();
         if (agc_out_end(g, g.n_chunks - 1) != p.n_emit) return fail(IQGPU_EINVAL, "internal: AGC chunk map disagrees with the call plan");
-        int rc = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
-        rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
+        { const void *was = c->agc_peak.p;
+          int rc0 = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc0) return rc0;
+          if (c->agc_peak.p != was) c->agc_peak_clean = false; }
+        int rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t))); if (rc) return rc;
         if (agc_fused) {   // what the fallback launches need, should the verifier reject the fused pass
             rc = c->agc_peak_b.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
             rc = c->abuf.ensure(((size_t)p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
@@ -1041,7 +1053,7 @@ int Call::stage_front()
             if (agc_fused) {
                 a2.agc_fused = 1; a2.agc_state = c->d_agc_state; a2.agc_peak2 = (unsigned long long *)c->agc_peak.p;
                 a2.agc_chunk_frames = c->agc_chunk; a2.agc_shift = c->S; a2.agc_rem = c->rem;
-                HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
+                HIP_TRY(clean_agc_peaks());
             }
             { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
             if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a2); if (rc) return rc; }
@@ -1054,7 +1066,7 @@ int Call::stage_front()
         if (agc_fused) {
             a.agc_fused = 1; a.agc_state = c->d_agc_state; a.agc_peak2 = (unsigned long long *)c->agc_peak.p;
             a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
-            HIP_TRY(hipMemsetAsync(c->agc_peak.p, 0, (size_t)agc_geom().n_chunks * sizeof(unsigned long long), c->stream));
+            HIP_TRY(clean_agc_peaks());
         }
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream) : launch_front_s1(a, c->stream)); }
         if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
@@ -1160,6 +1172,7 @@ int Call::stage_agc()
     }
     const AgcArgs ga = agc_args();
     KernelTimer kt(c, IQGPU_K_AGC);
+    c->agc_peak_clean = false;                       // (k_agc_peak leaves its maxima in agc_peak)
     HIP_TRY(launch_agc(ga, c->stream));
     return IQGPU_OK;
 }
@@ -1176,6 +1189,13 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr;
     fb.out_fmt = IQGPU_FMT_CF32; fb.out = c->abuf.p;
     fb.run_if = c->d_agc_flag;
+    if (fat || mid) {
+        // the fused launch ran on k_front_fat / k_front_mid with its own tile geometry: the fallback is k_front_s1's (512-frame tiles)
+        fb.w_total_tiles = ((int64_t)fb.rem0 + fb.frames_in + kWTile - 1) / kWTile;
+        int warm = (int)((c->rp.history_in + kWTile - 1) / kWTile);
+        if (warm < 1) warm = 1;
+        plan_front_s1(fb, wave_slots(front_s1_waves(fb)), fixed_tpw(), warm, 1, kWTile);
+    }
     HIP_TRY(launch_front_s1(fb, c->stream));
     AgcArgs ga = va;
     ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
@@ -1570,7 +1590,7 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     { const int rc = pipe_advance(c, c->pipe_seq); if (rc && !c->poisoned) return rc; }   // batches in flight come first (same stream)
     c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
-    c->agc_locked_host = false; c->agc_seen_host = 0;
+    c->agc_locked_host = false; c->agc_seen_host = 0; c->agc_peak_clean = false;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
     if (c->agc) { // agc_reset, src/agc.c:224-238
         c->agc_init.last_strong = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0;

@@ -1336,8 +1336,13 @@ def _enveloped_stream(n, seed, segments):
     return np.clip(np.rint(raw * env[:, None]), -32768, 32767).astype(np.int16).reshape(-1)
 
 
+@pytest.mark.parametrize("kernel", ["by_size", "mid"])
 @pytest.mark.parametrize("case", ["steady", "ratchet", "fade_and_creep", "many_calls", "odd_chunk"])
-def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case):
+def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case, kernel):
+    """kernel = by_size: the 22.8 M-frame single calls run k_front_mid<.., AGC> by the size rule, the ragged ones k_front_s1<.., AGC>;
+    mid: every call on k_front_mid<.., AGC> (IQGPU_FORCE_FAT)"""
+    if kernel == "mid":
+        monkeypatch.setenv("IQGPU_FORCE_FAT", "1")
     n = int(2.4e6 * 9.5)
     kw = dict(NRSC5, agc=True)
     splits = [n]
