@@ -27,20 +27,26 @@
 
 namespace iqgpu {
 
-constexpr int kMidWaves = 12;
+#ifndef IQGPU_MID_WAVES
+#define IQGPU_MID_WAVES 12
+#endif
+constexpr int kMidWaves = IQGPU_MID_WAVES;    // (16 is an experiment: only the shape without a mixer fits LDS and 128 VGPRs then)
 constexpr int kMidThreads = kMidWaves * 64;
 constexpr int kMidHb = 384;                                 // half-band samples per tile
 constexpr int kMidXHist = 24, kMidHHist = 18;               // samples of history in front of a tile: even / odd stream, half-band stream
 constexpr int kMidXBytes = (kMidXHist + kMidHb) * 8;        // 3264: one parity stream, sample at row coordinate r at byte 8 r
 constexpr int kMidSlice = kMidXBytes;                       // XE; the half-band stream lives on top of it (there is no XO stream: see run_mid)
-constexpr int kMidWaveLds = kMidSlice > kWaveLds ? kMidSlice : kWaveLds;     // (an edge wave uses the slice with k_front_s1's layout)
+constexpr int kMidWaveLds = kMidSlice;
+constexpr int kMidEdgeMax = 4;                              // edge waves of a launch (they use k_front_s1's slice layout, in an arena of their own)
+constexpr int kMidEdgeLds = kMidEdgeMax * kWaveLds;
 constexpr int kMidNcoLds = 2 * 1024 * 8;
 constexpr int kMidArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
 constexpr int kMidTabLds = kMidNcoLds + kMidArbLds + kFTapLds;
-static_assert(kMidTabLds + kMidWaves * kMidWaveLds <= 160 * 1024, "LDS");
+static_assert(kMidTabLds + kMidWaves * kMidWaveLds + kMidEdgeLds <= 160 * 1024, "LDS");
 
 int front_mid_waves() { return kMidWaves; }
-size_t front_mid_lds_bytes() { return (size_t)kMidTabLds + (size_t)kMidWaves * kMidWaveLds; }
+int front_mid_max_edge_waves() { return kMidEdgeMax; }
+size_t front_mid_lds_bytes(bool nonco) { return (size_t)kMidTabLds - (nonco ? kMidNcoLds : 0) + (size_t)kMidWaves * kMidWaveLds + kMidEdgeLds; }   // (no NCO tables without a mixer)
 
 struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 
@@ -52,6 +58,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
                                         const int64_t T_begin, const int64_t T_emit0, const int64_t T_emit1)
 {
     constexpr int NL = 6;
+    constexpr bool kLean = kMidWaves > 12;
     constexpr int LO[4] = {0, 1, 3, L3};
     char *XE = w.XE, *HB = w.XE;
     const uint32_t step = a.step;
@@ -268,14 +275,41 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
                 Hw[2 * q] = v2f{v.x, v.y}; Hw[2 * q + 1] = v2f{v.z, v.w};
             }
             keep(Hw[0]);
-            taps(tp[0], trow[0]); taps(tp[1], trow[1]);
+            if (!kLean) { taps(tp[0], trow[0]); taps(tp[1], trow[1]); }
         }
     };
 
+    // 16 waves per CU (experiment, IQGPU_MID_WAVES=16): 128 VGPRs -- nothing is fetched more than one step ahead: the polyphase
+    // first (its taps loaded where they are used, two slots at a time), then the pointwise phase, the windows, the half-band
+    auto tile_lean = [&](const int64_t T, const bool PP, const bool next_pp) {
+        if (PP) {
+            taps(tp[0], trow[0]); taps(tp[1], trow[1]);
+            pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+            FENCE();
+            taps(tp[0], trow[2]); taps(tp[1], trow[3]);
+            pp_slots2<NL, 3, L3>(Hw, own, tp[0], tp[1], y[2], y[3]);
+            keep(y[3]);
+            V_emit();
+        }
+        V_taprows(); FENCE();
+        if (!NONCO) { nco_lookup(T); FENCE(); }
+        VL_point();
+        load_even(T + 1);
+        FENCE();
+        L_xr();
+        V_centre();
+        load_odd(T + 1);
+        FENCE();
+        V_hb(); FENCE();
+        L_hb(next_pp); FENCE();
+    };
     auto tile = [&](const int64_t T, const bool PP, const bool next_pp) {
+        if (kLean) { tile_lean(T, PP, next_pp); return; }
+        __builtin_amdgcn_s_setprio(1);
         VL_point();                                    // (before the polyphase, so that the mixed samples are not held across it)
         if (PP) { taps(tq[0], trow[2]); taps(tq[1], trow[3]); }
         FENCE();
+        __builtin_amdgcn_s_setprio(0);
         if (PP) {
             pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
             pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
@@ -285,18 +319,23 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         V_taprows();
         load_even(T + 1);                              // (tile T_emit1 is readable too: the plan keeps one tile behind every run)
         FENCE();
+        __builtin_amdgcn_s_setprio(1);                 // a wave about to feed the LDS pipe goes ahead of waves in their FMA runs
         L_xr();
         V_centre();
         load_odd(T + 1);
         FENCE();
         if (!NONCO) { nco_lookup(T + 1); FENCE(); }
+        __builtin_amdgcn_s_setprio(0);
         V_hb(); FENCE();
+        __builtin_amdgcn_s_setprio(1);
         L_hb(next_pp); FENCE();
+        __builtin_amdgcn_s_setprio(0);
     };
     for (int64_t T = T_begin; T < T_emit0; ++T) tile(T, false, false);     // warm-up tiles
     tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
     for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true, true);    // steady state
     // the last tile's polyphase
+    if (kLean) { taps(tp[0], trow[0]); taps(tp[1], trow[1]); }
     taps(tq[0], trow[2]); taps(tq[1], trow[3]);
     pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
     pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
@@ -317,11 +356,13 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kNco = NONCO ? 0 : kMidNcoLds;
     cf2   *s_nco = (cf2 *)smem, *s_nco_half = s_nco + 1024;
-    float *s_arb = (float *)(smem + kMidNcoLds);
-    float *s_tap = (float *)(smem + kMidNcoLds + kMidArbLds);
-    char *slice = (char *)smem + kMidTabLds + wave * kMidWaveLds;
-    if (((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
+    float *s_arb = (float *)(smem + kNco);
+    float *s_tap = (float *)(smem + kNco + kMidArbLds);
+    char *slice = (char *)smem + kNco + kMidArbLds + kFTapLds + wave * kMidWaveLds;
+    char *arena = (char *)smem + kNco + kMidArbLds + kFTapLds + kMidWaves * kMidWaveLds;
+    if (!NONCO && ((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
 
     if (!NONCO) {
         const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;               // mix down: conj(phasor)
@@ -338,6 +379,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     }
     fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads, a.tap_fold_mul, a.tap_fold_shift);
     for (int i = lane; i < kMidWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < kMidEdgeLds / 16; i += kMidThreads) ((float4 *)arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     const int64_t gw = (int64_t)blockIdx.x * kMidWaves + wave;
@@ -351,8 +393,9 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        if (gw >= kMidEdgeMax) __builtin_trap();     // (the host keeps launches with more edge runs on k_front_s1)
         WaveLds w;
-        w.XE = slice; w.XO = w.XE + kXRows * kRowB; w.HB = w.XO + kHBOff * kRowB;
+        w.XE = arena + (int)gw * kWaveLds; w.XO = w.XE + kXRows * kRowB; w.HB = w.XO + kHBOff * kRowB;
         w.nco = s_nco; w.arb = s_arb;
         w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
         const int64_t o0 = 3 * t0 / 2, o1 = (3 * t1 + 1) / 2;
@@ -389,7 +432,7 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     const bool nonco = a_in.nco_mode == 0;
     FrontArgs a = a_in;
     if (nonco) for (float &h : a.hb0) h *= 1.0f / 32768.0f;           // the cs16 normaliser rides on the half-band taps (exact: a power of two)
-    const size_t lds = front_mid_lds_bytes();
+    const size_t lds = front_mid_lds_bytes(nonco);
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;

@@ -887,6 +887,13 @@ void Call::plan_geometry()
         if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
         plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves() : front_s1_waves(cplan)),
                       ftpw, warm, mid ? 2 : 1, wtile, mid ? 2 : 1, mid ? kMidLead : 0);
+        if (mid && cplan.w_n_edge > front_mid_max_edge_waves()) {
+            // (an unaligned buffer, a call that is all edges: k_front_mid keeps LDS for a handful of edge waves only)
+            mid = false; wtile = kWTile;
+            cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
+            warm = (int)((c->rp.history_in + wtile - 1) / wtile); if (warm < 1) warm = 1;
+            plan_front_s1(cplan, wave_slots(front_s1_waves(cplan)), fixed_tpw(), warm, 1, wtile);
+        }
     }
 }
 

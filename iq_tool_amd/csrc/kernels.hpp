@@ -174,8 +174,9 @@ hipError_t launch_front_fat(const FrontArgs &a, hipStream_t s);
 constexpr int kMidTile = 768;
 constexpr int kMidLead = 20;                 // a streaming run of k_front_mid reads this many frames in front of its first tile
 int front_mid_waves();
+int front_mid_max_edge_waves();          // launches with more edge runs than this stay on k_front_s1
 bool front_mid_shape(const FrontArgs &a);
-size_t front_mid_lds_bytes();
+size_t front_mid_lds_bytes(bool nonco);
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
 // wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles
