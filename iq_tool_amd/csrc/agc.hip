@@ -205,8 +205,13 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
             if (e > b) {                                           // empty chunks never reach agc_apply
                 const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
                 const float outp = pk * st.gain;
-                if (outp > 1.0f) bad = 1;                          // ratchet
-                else if (outp > a.target * kAgcLower) { k = 1; last_h = c; }
+                const float lower = a.target * kAgcLower;
+                // k_front_mid keeps max |y|^2 in float (1.5 ulp of the exact value the unfused kernels and the reference's cabsf
+                // give): a chunk that close to either threshold is not judged here -- the exact kernels redo the call
+                const float tol = a.peak_approx ? 4.0e-7f : 0.0f;
+                if (outp > 1.0f - tol) bad = 1;                    // ratchet (or too close to call)
+                else if (a.peak_approx && fabsf(outp - lower) <= tol * lower) bad = 1;
+                else if (outp > lower) { k = 1; last_h = c; }
                 else { k = 2; weak = 1; }
             }
         }

@@ -1190,6 +1190,7 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
 {
     AgcArgs va = agc_args();
     va.verify_flag = c->d_agc_flag;
+    va.peak_approx = mid ? 1 : 0;
     KernelTimer kt(c, IQGPU_K_AGC);
     HIP_TRY(launch_agc_verify(va, c->stream));
     FrontArgs fb = spec;

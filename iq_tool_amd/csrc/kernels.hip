@@ -350,7 +350,46 @@ __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
         const int64_t pad = (n_chunks << 10) - len;
         const float c = a.c;
         const float c1024 = (float)exp(1024.0 * a.logc);
-        for (int64_t ch = 0; ch < n_chunks; ++ch) {
+        int64_t ch = 0;
+        // 16-bit formats, 16-byte aligned chunks: four chunks' loads in flight per thread (one at a time left the kernel at
+        // 4.4 TB/s: 32 KiB in flight per CU; same arithmetic, same order)
+        if (vb == 4 && a.raw_aligned && (((beg - pad) * 4) & 15) == 0 && n_chunks > 5) {
+            {   // the first chunk holds the padding: the general path below, once
+                const int64_t u = 4 * tid;
+                float lr = 0.0f, li = 0.0f;
+                const int64_t k0 = beg + u - pad;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    cf2 x{0.0f, 0.0f};
+                    if (u + s >= pad) x = unpack_one(a.raw, k0 + s, a.in_fmt, a.gain);
+                    lr = fmaf(lr, c, x.x); li = fmaf(li, c, x.y);
+                }
+                accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
+                ch = 1;
+            }
+            const float norm = (a.in_fmt == IQGPU_FMT_SC16Q11) ? 1.0f / 2048.0f : 1.0f / 32768.0f;
+            const bool uns = a.in_fmt == IQGPU_FMT_CU16;
+            const char *base = (const char *)a.raw + (beg - pad + 4 * tid) * 4;
+            for (; ch + 4 <= n_chunks; ch += 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = *(const uint4 *)(base + ((ch + i) << 12));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    float lr = 0.0f, li = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float xr, xi;
+                        if (uns) { xr = up_u((float)(w[s] & 0xffffu), 32767.5f, 1.0f / 32768.0f, a.gain); xi = up_u((float)(w[s] >> 16), 32767.5f, 1.0f / 32768.0f, a.gain); }
+                        else { xr = up_s((float)(short)(w[s] & 0xffffu), norm, a.gain); xi = up_s((float)(short)(w[s] >> 16), norm, a.gain); }
+                        lr = fmaf(lr, c, xr); li = fmaf(li, c, xi);
+                    }
+                    accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
+                }
+            }
+        }
+        for (; ch < n_chunks; ++ch) {
             const int64_t u = (ch << 10) + 4 * tid;       // padded position of this thread's 4 samples
             float lr = 0.0f, li = 0.0f;
             const int64_t k0 = beg + u - pad;

@@ -106,11 +106,42 @@ def check_no_read2_b32(lines, what):
     return errors
 
 
+def check_fat_mid(src, kernel, max_vgpr):
+    """k_front_fat / k_front_mid are plain C++ whose speed hangs on what hipcc makes of it: (5) no scratch (a spill inside the
+    tile loop is a memory round trip per tile), (6) the VGPR count that the occupancy they are built for allows (8 waves per CU:
+    256, 12 waves: 168), (7) the tap reads stay single ds_read_b64 -- fused into ds_read2_b64 / ds_read2st64_b64 they run at
+    half rate (the tap planes are 2056 bytes apart so that they cannot be fused: a change of that layout shows up here), (8) no
+    ds_read2_b32 (a trimmed, re-chunked window load)."""
+    lines = compile_isa(src)
+    errors, cur, n = [], None, 0
+    for l in lines:
+        m = re.match(r"(_ZN5iqgpu\d+%sI\w+):" % kernel, l)
+        if m:
+            cur = m.group(1); n += 1
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur:
+            t = l.strip()
+            if re.match(r"ds_read2(st64)?_b(32|64)", t):
+                errors.append("%s: %s holds a %s" % (kernel, cur, t.split()[0])); cur = None
+            elif t.startswith("scratch_"):
+                errors.append("%s: %s spills to scratch" % (kernel, cur)); cur = None
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN5iqgpu\d+%sI\w+)\n(.*?)\.end_amdhsa_kernel" % kernel, "\n".join(lines), re.S):
+        v = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
+        if v and int(v.group(1)) > max_vgpr:
+            errors.append("%s: %s needs %s VGPRs (more than %d: a wave per SIMD lost)" % (kernel, m.group(1), v.group(1), max_vgpr))
+    if n == 0:
+        errors.append("no %s instantiation found" % kernel)
+    return errors
+
+
 def main():
     lines = compile_isa()
     errors, n = check(lines)
     errors += check_no_read2_b32(lines, "front_wave.hip")
     errors += check_no_read2_b32(compile_isa(SRC_CASC), "cascade_wave.hip")
+    errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_mid.hip"), "k_front_mid", 168)
+    errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_fat.hip"), "k_front_fat", 256)
     for e in errors:
         print("FAIL", e)
     print("check_isa: %d tap gathers checked: %s" % (n, "ok" if not errors and n > 0 else "FAILED"))
