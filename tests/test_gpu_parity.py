@@ -777,7 +777,10 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
     (696000.0, -150e3),     # step / 2^24 = 1.724: lo_3 = 5, lo_4 = 6
     (624000.0, 310e3),      # step / 2^24 = 1.923: lo_3 = 5, lo_4 = 7
     (750000.0, 200e3),      # step / 2^24 = 1.6 exactly: the edge of the class
-    (760000.0, 200e3),      # step / 2^24 = 1.579: outside (six outputs per eight samples happen): k_front_s1 runs either way
+    (760000.0, 200e3),      # step / 2^24 = 1.579: outside k_front_fat's classes (six outputs per eight samples happen), inside k_front_mid's
+    (800000.0, 0.0),        # step / 2^24 = 1.5 exactly: the lower edge of k_front_mid's classes
+    (601000.0, -77e3),      # step / 2^24 = 1.9967: just below the upper edge (2.0 = no arbitrary stage at all)
+    (810000.0, 200e3),      # step / 2^24 = 1.481: outside both: k_front_s1 whatever the switches say
 ])
 @pytest.mark.parametrize("variant", ["fat", "mid"])
 def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, target_hz, shift_hz, variant):
