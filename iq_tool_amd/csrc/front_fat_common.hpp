@@ -64,6 +64,13 @@ __device__ __forceinline__ void pp_step(const int wi, const v2f (&Hw)[14], const
     const float tw = (wi & 1) ? t[wi >> 1].y : t[wi >> 1].x;
     y = wi == W - 1 ? mul2(tw, h) : fma2(tw, h, y);
 }
+// one slot by itself (a dependent chain: the other waves of the SIMD fill its issue slots)
+template <int NL, int LA>
+__device__ __forceinline__ void pp_slot1(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], v2f &ya)
+{
+#pragma unroll
+    for (int wi = 15; wi >= 0; --wi) pp_step<NL, LA>(wi, Hw, own, ta, ya);
+}
 // two / three slots side by side: their chains are independent, so that no FMA waits for the one before it
 template <int NL, int LA, int LB>
 __device__ __forceinline__ void pp_slots2(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], const v2f (&tb)[8], v2f &ya, v2f &yb)

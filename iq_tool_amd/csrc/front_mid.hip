@@ -32,21 +32,35 @@ namespace iqgpu {
 #endif
 constexpr int kMidWaves = IQGPU_MID_WAVES;    // (16 is an experiment: only the shape without a mixer fits LDS and 128 VGPRs then)
 constexpr int kMidThreads = kMidWaves * 64;
-constexpr int kMidHb = 384;                                 // half-band samples per tile
-constexpr int kMidXHist = 24, kMidHHist = 18;               // samples of history in front of a tile: even / odd stream, half-band stream
-constexpr int kMidXBytes = (kMidXHist + kMidHb) * 8;        // 3264: one parity stream, sample at row coordinate r at byte 8 r
-constexpr int kMidSlice = kMidXBytes;                       // XE; the half-band stream lives on top of it (there is no XO stream: see run_mid)
-constexpr int kMidWaveLds = kMidSlice;
+// NL = half-band outputs per lane: 6 (768-frame tiles; rows need no padding: 6 cf32 = 48 bytes = 3 slots of 16, an odd number, so a
+// stream is a plain linear array, sample at row coordinate r at byte 8 r) or 8 (1024-frame tiles; rows of 8 cf32 padded to 80 bytes =
+// 5 slots).  Either way a lane's windows are conflict-free ds_read_b128 at constant offsets from the lane's base (ROWB * lane).
+template <int NL> struct MidGeom {
+    static constexpr int NC = NL / 2;                       // 256-frame chunks per tile = 16-byte loads per lane and stream
+    static constexpr int TILE = 128 * NL;                   // input frames per tile
+    static constexpr int HB = 64 * NL;                      // half-band samples per tile
+    static constexpr int XH = 24;                           // samples of history in front of a tile, even stream ...
+    static constexpr int HH = NL == 6 ? 18 : 16;            // ... and half-band stream (whole rows)
+    static constexpr int ROWB = NL == 6 ? 48 : 80;          // bytes from one lane's run to the next
+    static constexpr int NS = NL == 6 ? 4 : 5;              // polyphase slots per lane
+    static constexpr int CHUNKB = NL == 6 ? 1024 : 16 * 80; // bytes from chunk c's write slot to chunk c + 1's
+    static constexpr int XBYTES = NL == 6 ? (XH + HB) * 8 : (XH + HB) / 8 * 80;   // the stream (the half-band stream lives on top of it; no XO stream)
+    __host__ __device__ static constexpr int co(int k) { return NL == 6 ? 8 * k : (k / 8) * 80 + (k % 8) * 8; }   // byte offset of row coordinate k
+};
+constexpr int kMidWaveLds = MidGeom<8>::XBYTES;             // (slices sized for the larger shape)
 constexpr int kMidEdgeMax = 4;                              // edge waves of a launch (they use k_front_s1's slice layout, in an arena of their own)
 constexpr int kMidEdgeLds = kMidEdgeMax * kWaveLds;
 constexpr int kMidNcoLds = 2 * 1024 * 8;
 constexpr int kMidArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
 constexpr int kMidTabLds = kMidNcoLds + kMidArbLds + kFTapLds;
-static_assert(kMidTabLds + kMidWaves * kMidWaveLds + kMidEdgeLds <= 160 * 1024, "LDS");
+static_assert(kMidWaves > 12 || kMidTabLds + kMidWaves * kMidWaveLds + kMidEdgeLds <= 160 * 1024, "LDS");
 
 int front_mid_waves() { return kMidWaves; }
 int front_mid_max_edge_waves() { return kMidEdgeMax; }
-size_t front_mid_lds_bytes(bool nonco) { return (size_t)kMidTabLds - (nonco ? kMidNcoLds : 0) + (size_t)kMidWaves * kMidWaveLds + kMidEdgeLds; }   // (no NCO tables without a mixer)
+static size_t mid_lds_bytes(int nl, bool nonco)
+{
+    return (size_t)kMidTabLds - (nonco ? kMidNcoLds : 0) + (size_t)kMidWaves * (nl == 8 ? MidGeom<8>::XBYTES : MidGeom<6>::XBYTES) + kMidEdgeLds;
+}   // (no NCO tables without a mixer)
 
 __device__ __forceinline__ float wave_max_f(float m)
 {
@@ -60,13 +74,15 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
 // (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
 // L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
-template <bool NONCO, int L3, bool AGC>
+template <int NL, bool NONCO, int L3, int L4, bool AGC>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, const int64_t T_emit1)
 {
-    constexpr int NL = 6;
-    constexpr bool kLean = kMidWaves > 12;
-    constexpr int LO[4] = {0, 1, 3, L3};
+    typedef MidGeom<NL> G;
+    constexpr int NS = G::NS;
+    constexpr bool kLean = kMidWaves > 12 || NL == 8;       // (8 per lane at 3 waves per SIMD: 168 VGPRs leave no room to fetch a phase ahead)
+    constexpr int LO[5] = {0, 1, 3, L3, L4};
+    auto addr_rt = [](int rc) { return NL == 6 ? 8 * rc : (rc >> 3) * 80 + (rc & 7) * 8; };
     char *XE = w.XE, *HB = w.XE;
     const uint32_t step = a.step;
     float hb[20];
@@ -74,7 +90,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     for (int k = 0; k < 20; ++k) hb[k] = a.hb0[k];
 
     // ---- output bookkeeping of the polyphase tile T_emit0 (wave-uniform), then per lane
-    constexpr uint64_t SPAN = (uint64_t)kMidHb << 24;
+    constexpr uint64_t SPAN = (uint64_t)G::HB << 24;
     uint64_t k_tile0 = first_k_at((uint64_t)T_emit0 * SPAN, a.phi0, step);
     uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - (uint64_t)T_emit0 * SPAN);            // < step
     const uint32_t n_est = (uint32_t)(SPAN / step);                      // outputs of a tile: n_est or n_est + 1
@@ -99,15 +115,16 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     const int AS = AGC ? a.agc_shift : 0;
     if (AGC) {
         agc_g = a.agc_state->gain;
-        const int64_t F0 = (((int64_t)kMidHb * T_emit0 + 1) << AS) - 1 - a.agc_rem;
+        const int64_t F0 = (((int64_t)G::HB * T_emit0 + 1) << AS) - 1 - a.agc_rem;
         agc_c = F0 > 0 ? F0 / a.agc_chunk_frames : 0;
         agc_B = (agc_c + 1) * a.agc_chunk_frames;
     }
 
     // ---- per-lane LDS offsets (bytes; a sample at row coordinate r sits at 8 r)
-    const int wq = 8 * kMidXHist + 16 * lane;                           // write slot of chunk 0: even samples 2 lane, 2 lane + 1 (chunk c: 1024 c on)
-    const int sl_src = 8 * kMidHb + 4 * lane, sl_dst = 4 * lane;        // one dword per lane: the stream's tail becomes the next tile's history
-    const char *we = XE + 48 * lane, *wh = HB + 48 * lane;
+    const int wq = addr_rt(G::XH + 2 * lane);                           // write slot of chunk 0: even samples 2 lane, 2 lane + 1 (chunk c: CHUNKB c on)
+    const int sl_src = addr_rt(G::HB + (lane >> 1)) + 4 * (lane & 1);   // one dword per lane: the stream's tail becomes the next tile's history
+    const int sl_dst = addr_rt(lane >> 1) + 4 * (lane & 1);
+    const char *we = XE + G::ROWB * lane, *wh = HB + G::ROWB * lane;
     typedef __attribute__((address_space(3))) const v2f lds_v2f;
 
     // Raw frames: the coalesced stream (lane: frames 256 c + 4 lane .. + 3 of the tile) feeds the EVEN samples, which every lane's
@@ -115,26 +132,26 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // i of the lane takes the odd sample 6 lane + i - 10, frame 12 lane - 19 + 2 i of the tile -- so the lane fetches its own six
     // straight from memory a second time (three more 16-byte loads at frame 12 lane - 20: the lines are in L2 / L1 from the
     // coalesced loads, HBM sees them once) instead of writing them to LDS for another lane to read: no XO stream at all.
-    RawChunk nxt[3], nxo[3];
-    v2f cs_n[3][2], cs_o[NL];
+    RawChunk nxt[G::NC], nxo[G::NC];
+    v2f cs_n[G::NC][2], cs_o[NL];
     auto load_even = [&](int64_t T) {
-        const char *src = (const char *)a.raw + (T * 768 - a.rem0) * 4 + 16 * lane;
+        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * 4 + 16 * lane;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
+        for (int c = 0; c < G::NC; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
     };
     auto load_odd = [&](int64_t T) {
-        const char *src = (const char *)a.raw + (T * 768 - a.rem0) * 4 + 48 * lane - 80;
+        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * 4 + 8 * NL * lane - 80;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_chunk<4>(src + 16 * c, nxo[c]);
+        for (int c = 0; c < G::NC; ++c) load_chunk<4>(src + 16 * c, nxo[c]);
     };
     auto nco_lookup = [&](int64_t T) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t th = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+        for (int c = 0; c < G::NC; ++c) {
+            const uint32_t th = a.nco_theta0 + ((uint32_t)(T * G::TILE) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
             cs_n[c][0] = nco_phasor2(w.nco, th, 0);
             cs_n[c][1] = nco_phasor2(w.nco, th + 2u * a.nco_dtheta, 0);
         }
-        uint32_t tho = a.nco_theta0 + ((uint32_t)(T * 768) + (uint32_t)(12 * lane - 19)) * a.nco_dtheta;
+        uint32_t tho = a.nco_theta0 + ((uint32_t)(T * G::TILE) + (uint32_t)(2 * NL * lane - 19)) * a.nco_dtheta;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             cs_o[i] = nco_phasor2(w.nco, tho, 1);               // the odd stream only meets the centre tap 0.5: half-scaled copy
@@ -148,8 +165,8 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     v2f own[NL];                                       // the lane's own half-band outputs of the tile before
     v2f Hw[14];                                        // the 13 half-band samples in front of them (+ one unused)
     v2f tp[2][8], tq[2][8];                            // taps of slots 0, 1 (issued a phase ahead) and 2, 3
-    unsigned trow[4];
-    v2f E[26], acc[NL], y[4];
+    unsigned trow[NS];
+    v2f E[NL + 20], acc[NL], y[NS];
 #pragma unroll
     for (int i = 0; i < NL; ++i) own[i] = v2f{0.f, 0.f};
 #pragma unroll
@@ -159,7 +176,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #pragma unroll
         for (int i = 0; i < 8; ++i) tp[j][i] = v2f{0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) trow[j] = w.tap_lds;
+    for (int j = 0; j < NS; ++j) trow[j] = w.tap_lds;
 
     // (the empty asm with a memory clobber orders the LDS accesses around it already when the instruction stream is first laid
     //  out -- sched_barrier by itself only stops the machine scheduler, and the loads had floated above it before that)
@@ -172,12 +189,12 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto VL_point = [&]() {
         if (lane < 48) *(float *)(XE + sl_dst) = sl_e;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < G::NC; ++c) {
             v2f x0 = v2f{(float)(short)(nxt[c].w[0] & 0xffffu), (float)(short)(nxt[c].w[0] >> 16)};      // 2^-15: in the table (taps when NONCO)
             v2f x2 = v2f{(float)(short)(nxt[c].w[2] & 0xffffu), (float)(short)(nxt[c].w[2] >> 16)};
             keep(nxt[c].w[1]); keep(nxt[c].w[3]);       // (whole 16-byte loads: unused words declared used, or hipcc narrows them to dword loads)
             if (!NONCO) { x0 = pk_cmul(x0, cs_n[c][0]); x2 = pk_cmul(x2, cs_n[c][1]); }
-            stq(XE + wq + 1024 * c, make_float4(x0.x, x0.y, x2.x, x2.y));
+            stq(XE + wq + G::CHUNKB * c, make_float4(x0.x, x0.y, x2.x, x2.y));
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 48) sl_e = *(const float *)(XE + sl_src);
@@ -185,8 +202,8 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // ---- the half-band window: E[j] = even sample at row coordinate 6 lane + 4 + j, output i uses E[20 + i - k], k = 0 .. 19
     auto L_xr = [&]() {
 #pragma unroll
-        for (int q = 0; q < 13; ++q) {
-            const float4 v = ldq(we + 32 + 16 * q);
+        for (int q = 0; q < (NL + 20) / 2; ++q) {
+            const float4 v = ldq(we + G::co(4 + 2 * q));
             E[2 * q] = v2f{v.x, v.y}; E[2 * q + 1] = v2f{v.z, v.w};
         }
         keep(E[0]);
@@ -194,7 +211,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // ---- centre taps: the lane's own six odd samples (words 1, 3, .. 11 of its second load), mixed with the half-scaled table
     auto V_centre = [&]() {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { keep(nxo[c].w[0]); keep(nxo[c].w[2]); }
+        for (int c = 0; c < G::NC; ++c) { keep(nxo[c].w[0]); keep(nxo[c].w[2]); }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const uint32_t wd = nxo[(2 * i + 1) >> 2].w[(2 * i + 1) & 3];
@@ -206,20 +223,20 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // ---- pack + store of the polyphase tile, on to the next one, its tap rows
     auto V_emit = [&]() {
         if (AGC) {
-            uint32_t agc_qb = (uint32_t)kMidHb;             // half-band samples of this tile below it are in chunk agc_c
-            const int64_t F0 = (((int64_t)kMidHb * agc_T + 1) << AS) - 1 - a.agc_rem;   // last input frame that sample 0 of the tile needs
+            uint32_t agc_qb = (uint32_t)G::HB;              // half-band samples of this tile below it are in chunk agc_c
+            const int64_t F0 = (((int64_t)G::HB * agc_T + 1) << AS) - 1 - a.agc_rem;    // last input frame that sample 0 of the tile needs
             if (F0 >= agc_B) {                              // the boundary fell between two tiles
                 const double m = (double)wave_max_f(agc_m0);
                 if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
                 agc_m0 = 0.0f; agc_c += 1; agc_B += a.agc_chunk_frames;
             }
             const int64_t d = agc_B - F0;
-            if (d < ((int64_t)kMidHb << AS)) agc_qb = (uint32_t)((d + ((int64_t)1 << AS) - 1) >> AS);
+            if (d < ((int64_t)G::HB << AS)) agc_qb = (uint32_t)((d + ((int64_t)1 << AS) - 1) >> AS);
             uint32_t P = Pl;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t pos = P >> 24;               // the output's half-band sample among the lane's six (slot 3: may be past them)
-                if (j < 3 || pos < (uint32_t)NL) {
+            for (int j = 0; j < NS; ++j) {
+                const uint32_t pos = P >> 24;               // the output's half-band sample among the lane's own (last slot: may be past them)
+                if (j < NS - 1 || pos < (uint32_t)NL) {
                     // agc_apply: peak of the chunk over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
                     const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
                     if ((uint32_t)(NL * lane) + pos < agc_qb) agc_m0 = fmaxf(agc_m0, m2); else agc_m1 = fmaxf(agc_m1, m2);
@@ -227,21 +244,23 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
                 y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
                 P += step;
             }
-            if (agc_qb < (uint32_t)kMidHb) {                // the tile held a boundary: chunk agc_c is complete for this run
+            if (agc_qb < (uint32_t)G::HB) {                 // the tile held a boundary: chunk agc_c is complete for this run
                 const double m = (double)wave_max_f(agc_m0);
                 if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
                 agc_m0 = agc_m1; agc_m1 = 0.0f; agc_c += 1; agc_B += a.agc_chunk_frames;
             }
             agc_T += 1;
         }
-        uint32_t pk[4];
+        uint32_t pk[NS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
-        // the lane's 3 or 4 outputs are consecutive: one 12-byte store and at most one dword
+        for (int j = 0; j < NS; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
+        // the lane's NS - 1 or NS outputs are consecutive: one 12- or 16-byte store and at most one dword
         typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
         char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 4;
-        *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
-        if (Pl + 3u * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 12) = pk[3];
+        if constexpr (NS == 4) *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
+        else *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 4 * (NS - 1)) = pk[NS - 1];
         const uint32_t nt = n_est + (((uint64_t)delta0 + c_est) < SPAN ? 1u : 0u);
         k_tile0 += nt;
         const int32_t e = (int32_t)((int64_t)((uint64_t)nt * step) - (int64_t)SPAN);           // |e| < step
@@ -254,7 +273,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto V_taprows = [&]() {
         uint32_t P = Pl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j], a.tap_fold_mul, a.tap_fold_shift); P += step; }
+        for (int j = 0; j < NS; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j], a.tap_fold_mul, a.tap_fold_shift); P += step; }
     };
     auto V_hb = [&]() {
 #pragma unroll
@@ -269,18 +288,18 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     //      the polyphase window of this tile: Hw[i] = half-band sample at row coordinate 6 lane + 4 + i (m = i - 14), and the
     //      taps of its first two slots
     auto L_hb = [&](const bool with_pp_reads) {
-        if (lane < 36) *(float *)(HB + sl_dst) = sl_h;
+        if (lane < 2 * G::HH) *(float *)(HB + sl_dst) = sl_h;
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            stq(HB + 8 * kMidHHist + 48 * lane + 16 * q, make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y));
+        for (int q = 0; q < NL / 2; ++q)
+            stq(HB + G::ROWB * lane + G::co(G::HH + 2 * q), make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y));
         __builtin_amdgcn_wave_barrier();
-        if (lane < 36) sl_h = *(const float *)(HB + sl_src);
+        if (lane < 2 * G::HH) sl_h = *(const float *)(HB + sl_src);
 #pragma unroll
         for (int i = 0; i < NL; ++i) own[i] = acc[i];
         if (with_pp_reads) {
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
-                const float4 v = ldq(wh + 32 + 16 * q);
+                const float4 v = ldq(wh + G::co(G::HH - 14 + 2 * q));
                 Hw[2 * q] = v2f{v.x, v.y}; Hw[2 * q + 1] = v2f{v.z, v.w};
             }
             keep(Hw[0]);
@@ -288,18 +307,22 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         }
     };
 
-    // 16 waves per CU (experiment, IQGPU_MID_WAVES=16): 128 VGPRs -- nothing is fetched more than one step ahead: the polyphase
-    // first (its taps loaded where they are used, two slots at a time), then the pointwise phase, the windows, the half-band
+    // the polyphase of a tile with its taps loaded where they are used, two slots at a time
+    auto V_pp_lean = [&]() {
+        taps(tp[0], trow[0]); taps(tp[1], trow[1]);
+        pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+        FENCE();
+        taps(tp[0], trow[2]); taps(tp[1], trow[3]);
+        if constexpr (NS == 5) taps(tq[0], trow[4]);
+        pp_slots2<NL, 3, L3>(Hw, own, tp[0], tp[1], y[2], y[3]);
+        if constexpr (NS == 5) pp_slot1<NL, L4>(Hw, own, tq[0], y[4]);
+        keep(y[NS - 1]);                               // (computed by every lane beside the others, not as a chain of its own under the store's branch)
+        V_emit();
+    };
+    // lean order (8 per lane; or 16 waves per CU, IQGPU_MID_WAVES=16): nothing is fetched more than one step ahead: the polyphase
+    // first, then the pointwise phase, the windows, the half-band
     auto tile_lean = [&](const int64_t T, const bool PP, const bool next_pp) {
-        if (PP) {
-            taps(tp[0], trow[0]); taps(tp[1], trow[1]);
-            pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
-            FENCE();
-            taps(tp[0], trow[2]); taps(tp[1], trow[3]);
-            pp_slots2<NL, 3, L3>(Hw, own, tp[0], tp[1], y[2], y[3]);
-            keep(y[3]);
-            V_emit();
-        }
+        if (PP) V_pp_lean();
         V_taprows(); FENCE();
         if (!NONCO) { nco_lookup(T); FENCE(); }
         VL_point();
@@ -344,12 +367,14 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
     for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true, true);    // steady state
     // the last tile's polyphase
-    if (kLean) { taps(tp[0], trow[0]); taps(tp[1], trow[1]); }
-    taps(tq[0], trow[2]); taps(tq[1], trow[3]);
-    pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
-    pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
-    keep(y[3]);
-    V_emit();
+    if (kLean) V_pp_lean();
+    else {
+        taps(tq[0], trow[2]); taps(tq[1], trow[3]);
+        pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
+        pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
+        keep(y[3]);
+        V_emit();
+    }
     if (AGC) {
         const double m = (double)wave_max_f(agc_m0);
         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
@@ -358,9 +383,10 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
-template <bool NONCO, int L3, bool AGC>
+template <int NL, bool NONCO, int L3, int L4, bool AGC>
 __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 {
+    typedef MidGeom<NL> G;
     if (a.run_if && *a.run_if == 0) return;         // (a fallback launch whose fused predecessor stood: never the case today, kept for symmetry)
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -369,8 +395,8 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     cf2   *s_nco = (cf2 *)smem, *s_nco_half = s_nco + 1024;
     float *s_arb = (float *)(smem + kNco);
     float *s_tap = (float *)(smem + kNco + kMidArbLds);
-    char *slice = (char *)smem + kNco + kMidArbLds + kFTapLds + wave * kMidWaveLds;
-    char *arena = (char *)smem + kNco + kMidArbLds + kFTapLds + kMidWaves * kMidWaveLds;
+    char *slice = (char *)smem + kNco + kMidArbLds + kFTapLds + wave * G::XBYTES;
+    char *arena = (char *)smem + kNco + kMidArbLds + kFTapLds + kMidWaves * G::XBYTES;
     if (!NONCO && ((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
 
     if (!NONCO) {
@@ -387,7 +413,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
     fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads, a.tap_fold_mul, a.tap_fold_shift);
-    for (int i = lane; i < kMidWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < G::XBYTES / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < kMidEdgeLds / 16; i += kMidThreads) ((float4 *)arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
@@ -397,8 +423,8 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         for (int i = lane; i < keep_n; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
     }
     if (gw < a.w_n_edge) {
-        // edge work in 768-frame tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles), runs of w_edge_tpw = 2 of them from an even
-        // tile: three 512-frame tiles of run_tiles each
+        // edge work in tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) of G::TILE frames, runs of w_edge_tpw of them (768-frame
+        // tiles: two, from an even tile = three 512-frame tiles of run_tiles; 1024-frame tiles: one = two of them)
         int64_t t0, t1;
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
@@ -407,7 +433,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         w.XE = arena + (int)gw * kWaveLds; w.XO = w.XE + kXRows * kRowB; w.HB = w.XO + kHBOff * kRowB;
         w.nco = s_nco; w.arb = s_arb;
         w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
-        const int64_t o0 = 3 * t0 / 2, o1 = (3 * t1 + 1) / 2;
+        const int64_t o0 = t0 * G::TILE / 512, o1 = (t1 * G::TILE + 511) / 512;
         run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
@@ -416,52 +442,71 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         MidLds w;
         w.XE = slice; w.nco = s_nco;
         w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_mid<NONCO, L3, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        run_mid<NL, NONCO, L3, L4, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
     }
 }
 
-// step class of the four-slot polyphase: 1.5 <= s < 2 (a lane's 6 samples hold 3 or 4 outputs), lo_3 = floor(3 s)
-static int mid_step_class(uint32_t step)
+// step classes: lo_3 = floor(3 s), lo_4 = floor(4 s) with s = step / 2^24.  Six per lane (four slots) takes 1.5 <= s < 2, eight per
+// lane (five slots) 1.6 <= s < 2
+static bool mid_class(uint32_t step, int nl, int *l3, int *l4)
 {
     const uint64_t one = (uint64_t)1 << 24;
-    if ((uint64_t)step * 2 < 3 * one || (uint64_t)step >= 2 * one) return 0;      // s < 1.5 or s >= 2
-    const int l3 = (int)(((uint64_t)step * 3) >> 24);
-    return l3 == 4 ? 1 : l3 == 5 ? 2 : 0;
+    if ((uint64_t)step >= 2 * one) return false;
+    if (nl == 6 ? (uint64_t)step * 2 < 3 * one : (uint64_t)step * 5 < 8 * one) return false;
+    *l3 = (int)(((uint64_t)step * 3) >> 24); *l4 = (int)(((uint64_t)step * 4) >> 24);
+    if (nl == 6) { *l4 = 0; return *l3 == 4 || *l3 == 5; }
+    return (*l3 == 4 && *l4 == 6) || (*l3 == 5 && *l4 == 6) || (*l3 == 5 && *l4 == 7);
 }
 
-bool front_mid_shape(const FrontArgs &a)
+// outputs per lane of the k_front_mid instantiation for these arguments: 6 (8 on request); 0 = not this kernel's shape
+int front_mid_nl(const FrontArgs &a)
 {
-    return a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
-           a.pnco_mode == 0 && (!a.agc_fused || (a.agc_shift == 1 && a.agc_chunk_frames >= kMidTile)) &&
-           !(a.dbg & (kDbgNoFast | kDbgNoFat)) && mid_step_class(a.step) != 0;
+    if (!(a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
+          a.pnco_mode == 0 && !(a.dbg & (kDbgNoFast | kDbgNoFat)))) return 0;
+    int l3, l4;
+    for (int nl : {8, 6}) {
+        // 8 per lane is an experiment (IQGPU_MID8=1): in 168 VGPRs it has no room to fetch a phase ahead, and without that it runs
+        // 0.440 ms against 0.384 for 6 per lane on the NRSC-5 chain; with the fused AGC it does not fit at all
+        if (nl == 8 && (!(a.dbg & kDbgMid8) || a.agc_fused)) continue;
+        if (!mid_class(a.step, nl, &l3, &l4)) continue;
+        if (a.agc_fused && !(a.agc_shift == 1 && a.agc_chunk_frames >= 128 * nl)) continue;
+        return nl;
+    }
+    return 0;
 }
+int front_mid_tile(int nl) { return 128 * nl; }
 
 hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
 {
     const bool nonco = a_in.nco_mode == 0;
     FrontArgs a = a_in;
     if (nonco) for (float &h : a.hb0) h *= 1.0f / 32768.0f;           // the cs16 normaliser rides on the half-band taps (exact: a power of two)
-    const size_t lds = front_mid_lds_bytes(nonco);
+    const int nl = front_mid_nl(a);
+    int l3 = 0, l4 = 0;
+    if (nl == 0 || !mid_class(a.step, nl, &l3, &l4)) return hipErrorInvalidValue;
+    const size_t lds = mid_lds_bytes(nl, nonco);
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_MID(NONCO, L3, AGC)                                                                             \
+#define IQGPU_LAUNCH_MID(NL, NONCO, L3, L4, AGC)                                                                    \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_mid<NONCO, L3, AGC>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_mid<NONCO, L3, AGC>), dim3(grid), dim3(kMidThreads), lds, s, a);                \
+        { const hipError_t e = cache.ensure((const void *)k_front_mid<NL, NONCO, L3, L4, AGC>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC>), dim3(grid), dim3(kMidThreads), lds, s, a);        \
     } while (0)
-    switch (mid_step_class(a.step) * 4 + (nonco ? 1 : 0) + (a.agc_fused ? 2 : 0)) {
-    case 4: IQGPU_LAUNCH_MID(false, 4, false); break;
-    case 5: IQGPU_LAUNCH_MID(true, 4, false); break;
-    case 6: IQGPU_LAUNCH_MID(false, 4, true); break;
-    case 7: IQGPU_LAUNCH_MID(true, 4, true); break;
-    case 8: IQGPU_LAUNCH_MID(false, 5, false); break;
-    case 9: IQGPU_LAUNCH_MID(true, 5, false); break;
-    case 10: IQGPU_LAUNCH_MID(false, 5, true); break;
-    case 11: IQGPU_LAUNCH_MID(true, 5, true); break;
-    default: return hipErrorInvalidValue;
-    }
+#define IQGPU_LAUNCH_MID2(NL, L3, L4)                                                                               \
+    do {                                                                                                              \
+        if (nonco && a.agc_fused) IQGPU_LAUNCH_MID(NL, true, L3, L4, (NL == 6));                                    \
+        else if (nonco) IQGPU_LAUNCH_MID(NL, true, L3, L4, false);                                                  \
+        else if (a.agc_fused) IQGPU_LAUNCH_MID(NL, false, L3, L4, (NL == 6));                                       \
+        else IQGPU_LAUNCH_MID(NL, false, L3, L4, false);                                                            \
+    } while (0)
+    if (nl == 6 && l3 == 4) IQGPU_LAUNCH_MID2(6, 4, 0);
+    else if (nl == 6) IQGPU_LAUNCH_MID2(6, 5, 0);
+    else if (l3 == 4) IQGPU_LAUNCH_MID2(8, 4, 6);
+    else if (l4 == 6) IQGPU_LAUNCH_MID2(8, 5, 6);
+    else IQGPU_LAUNCH_MID2(8, 5, 7);
+#undef IQGPU_LAUNCH_MID2
 #undef IQGPU_LAUNCH_MID
     return hipGetLastError();
 }

@@ -287,7 +287,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
         c->dbg = (getenv("IQGPU_NO_FAST") ? kDbgNoFast : 0u) | (getenv("IQGPU_AGC_NOFUSE") ? kDbgAgcNoFuse : 0u) |
                  (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
                  (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
-                 (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u);
+                 (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8") ? kDbgMid8 : 0u);
         if (const char *tf = getenv("IQGPU_TAP_FOLD")) { unsigned m = 1, k = 5; if (sscanf(tf, "%u,%u", &m, &k) == 2 && (m & 1u) && k >= 1 && k <= 8) { c->tap_fold_mul = m; c->tap_fold_shift = k; } }
     }
 
@@ -872,21 +872,23 @@ void Call::plan_geometry()
         // (shorter calls keep k_front_s1's 16 x CUs waves of 512-frame tiles: what counts for them is latency; same bytes either way)
         const bool fat_ok = !casc && !fast_s0 && front_fat_shape(cplan) &&
               ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * kFatTile * wave_slots(front_fat_waves()));
-        const bool mid_ok = !casc && !fast_s0 && front_mid_shape(cplan) &&
-              ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * kMidTile * wave_slots(front_mid_waves()));
-        // (measured on one box, 2^28 frames: k_front_s1 0.437 ms, k_front_fat 0.404, k_front_mid 0.389: the 12-wave kernel is the
+        const int mid_nl = (!casc && !fast_s0) ? front_mid_nl(cplan) : 0;
+        const bool mid_ok = mid_nl != 0 &&
+              ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * front_mid_tile(mid_nl) * wave_slots(front_mid_waves()));
+        // (measured on one box, 2^28 frames: k_front_s1 0.437 ms, k_front_fat 0.404, k_front_mid 0.381: the 12-wave kernel is the
         //  default; IQGPU_FAT=1 selects the 8-wave one where its step class applies)
         fat = fat_ok && ((c->dbg & kDbgUseFat) || !mid_ok);
         mid = mid_ok && !fat;
         if (fat) wtile = kFatTile;
-        if (mid) wtile = kMidTile;
+        if (mid) wtile = front_mid_tile(mid_nl);
+        const int mid_align = (mid && mid_nl == 6) ? 2 : 1;      // 768-frame tiles: edge runs of two = three 512-frame tiles
         cplan.w_total_tiles = ((int64_t)rem_k + (int64_t)frames_in + wtile - 1) / wtile;
         int warm = casc ? c->casc_warm : (int)((c->rp.history_in + wtile - 1) / wtile);
         if (warm < 1) warm = 1;
         int ftpw = fixed_tpw();
         if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
         plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves() : front_s1_waves(cplan)),
-                      ftpw, warm, mid ? 2 : 1, wtile, mid ? 2 : 1, mid ? kMidLead : 0);
+                      ftpw, warm, mid_align, wtile, mid_align, mid ? kMidLead : 0);
         if (mid && cplan.w_n_edge > front_mid_max_edge_waves()) {
             // (an unaligned buffer, a call that is all edges: k_front_mid keeps LDS for a handful of edge waves only)
             mid = false; wtile = kWTile;

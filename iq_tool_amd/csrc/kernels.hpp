@@ -62,7 +62,7 @@ struct cd2 { double x, y; };
 // ---------------------------------------------------------------------------------------------
 // diagnostic switches (IQGPU_NO_FAST, IQGPU_AGC_NOFUSE, IQGPU_NO_RAW0, IQGPU_NO_KT, IQGPU_FFT_NO_R16): read from the
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
-enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u };
+enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u };
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
@@ -171,12 +171,11 @@ bool front_fat_shape(const FrontArgs &a);  // needs S, formats, gain, iq / dc / 
 size_t front_fat_lds_bytes();
 hipError_t launch_front_fat(const FrontArgs &a, hipStream_t s);
 // ... and with 6 half-band outputs per lane, 12 waves per CU, 768-frame tiles (front_mid.hip)
-constexpr int kMidTile = 768;
 constexpr int kMidLead = 20;                 // a streaming run of k_front_mid reads this many frames in front of its first tile
 int front_mid_waves();
 int front_mid_max_edge_waves();          // launches with more edge runs than this stay on k_front_s1
-bool front_mid_shape(const FrontArgs &a);
-size_t front_mid_lds_bytes(bool nonco);
+int front_mid_nl(const FrontArgs &a);    // half-band outputs per lane of the instantiation for these arguments (8, 6; 0 = not its shape)
+int front_mid_tile(int nl);              // its tile: 128 nl frames
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
 // wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles
