@@ -812,6 +812,45 @@ def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, tar
     int_close(ref, run_oracle(oracle, raw, **kw))
 
 
+@pytest.mark.parametrize("seed", range(int(_os_agc.environ.get("IQGPU_FUZZ_SEEDS", "24"))))
+def test_mid_kernel_random_schedules(gpu, monkeypatch, seed):
+    """k_front_mid (forced onto calls of any length) against k_front_s1 on random preset-shaped chains: output rate anywhere in
+    the kernel's step range, shift or none, AGC or none, random call splits (ragged, one-frame, unaligned-in-time) and run
+    lengths.  The two kernels share every product and its order: the bytes, the AGC state and the frame counts must be equal."""
+    rng = np.random.default_rng(9000 + seed)
+    target = float(rng.uniform(602e3, 798e3))                  # step / 2^24 between 1.503 and 1.993
+    if seed % 6 == 0:
+        target = 744187.5
+    shift = float(rng.choice([0.0, 200e3, -123456.0, float(rng.uniform(-9e5, 9e5))]))
+    agc = bool(rng.integers(0, 2))
+    n = int(rng.integers(400_000, 2_400_000))
+    raw = synth.raw_stream(n, 2.4e6, 700 + seed, "cs16")
+    kw = dict(NRSC5, target_rate_hz=target, shift_hz=shift, agc=agc)
+    if rng.integers(0, 3) == 0:
+        kw["block_samples"] = int(rng.choice([4096, 32768, 262144]))
+    cuts = sorted(set(int(v) for v in rng.integers(0, n, int(rng.integers(0, 5)))) | {0, n})
+    if agc:
+        cuts = sorted(set((v // 16384) * 16384 for v in cuts) | {0, n})       # AGC chunks follow the call boundaries
+        raw = _enveloped_stream(n, 700 + seed, [(0.0, 0.5), (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9)))])
+    splits = [b - a for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+    def run():
+        ch = gpu.Chain(**kw)
+        outs, pos = [], 0
+        for k in splits:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        return np.concatenate(outs), (ch.agc_state() if agc else None)
+
+    monkeypatch.setenv("IQGPU_NO_FAT", "1")
+    ref, st_ref = run()
+    monkeypatch.delenv("IQGPU_NO_FAT")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")
+    got, st_got = run()
+    assert got.size == ref.size, (kw, splits)
+    assert np.array_equal(got, ref), (kw, splits, int((got != ref).sum()))
+    assert st_got == st_ref
+
+
 def test_fat_kernel_takes_long_calls_by_itself(gpu):
     """without any switch: a 2^25-frame call runs k_front_fat (the profile names the kernel), a 2^20-frame one k_front_s1, and
     the stream continues across the change of kernel"""
