@@ -489,7 +489,7 @@ def main():
                                    + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(case["log2_frames"]) if args.config == 2 else None,
-                         "kernel": "k_front_mid<false, 4, false> (front_mid.hip; IQGPU_FAT=1: k_front_fat, IQGPU_NO_FAT=1: k_front_s1)" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
+                         "kernel": "k_front_mid<6, false, 4, 0, false> (front_mid.hip; IQGPU_FAT=1: k_front_fat, IQGPU_NO_FAT=1: k_front_s1)" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
             "host_end_to_end": host,
@@ -501,7 +501,7 @@ def main():
             line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
                                           "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "
                                           + ", ".join("%s %.3f" % (k, v["ms"] / max(args.steps, 1)) for k, v in prof.items() if v["launches"]))
-            line["roofline"]["kernel"] = "k_front_mid<false, 4, agc> + k_agc_classify / k_agc_verify"
+            line["roofline"]["kernel"] = "k_front_mid<6, false, 4, 0, agc> + k_agc_classify / k_agc_verify"
             line["roofline"]["traffic"] = None
         if world == 1 and not args.no_cpu_baseline and args.config == 2 and not args.preset:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
