@@ -21,28 +21,34 @@ namespace iqgpu {
 // include/constants.h:184-192
 constexpr float kAgcLockTime = 2.0f, kAgcHangTime = 4.0f, kAgcRecovery = 1.0005f, kAgcLower = 0.75f;
 
+// (k_agc_peak / k_agc_apply walk their (chunk, split) pairs with a grid stride: as conditional fallback launches behind a fused
+//  front kernel they are started with a small grid, so that the launch that finds nothing to do costs a couple of microseconds and
+//  not the dispatch of 16384 x splits empty workgroups)
 __global__ __launch_bounds__(kThreads) void k_agc_peak(const AgcArgs a)
 {
     if (a.run_if && *a.run_if == 0) return;
-    const int c = blockIdx.x;
-    const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
-    const int64_t len = e - b;
-    // the scan walks the chunk lengths from this table instead of redoing the 64-bit divisions of the closed form
-    if (blockIdx.y == 0 && threadIdx.x == 0) a.chunk_len[c] = (int32_t)(len > 0 ? len : 0);
-    if (len <= 0) return;
-    const int64_t per = (len + a.splits - 1) / a.splits;
-    const int64_t lo = b + (int64_t)blockIdx.y * per;
-    int64_t hi = lo + per; if (hi > e) hi = e;
-    double m = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-        const cf2 v = a.x[i];
-        const double d = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
-        m = d > m ? d : m;
-    }
+    const int64_t n_items = (int64_t)a.geom.n_chunks * a.splits;
+    for (int64_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+        const int c = (int)(w / a.splits), sy = (int)(w % a.splits);
+        const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+        const int64_t len = e - b;
+        // the scan walks the chunk lengths from this table instead of redoing the 64-bit divisions of the closed form
+        if (sy == 0 && threadIdx.x == 0) a.chunk_len[c] = (int32_t)(len > 0 ? len : 0);
+        if (len <= 0) continue;
+        const int64_t per = (len + a.splits - 1) / a.splits;
+        const int64_t lo = b + (int64_t)sy * per;
+        int64_t hi = lo + per; if (hi > e) hi = e;
+        double m = 0.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const cf2 v = a.x[i];
+            const double d = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+            m = d > m ? d : m;
+        }
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(m, k); m = o > m ? o : m; }
-    // non-negative doubles order like their bit patterns
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(a.peak2 + c, (unsigned long long)__double_as_longlong(m));
+        for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(m, k); m = o > m ? o : m; }
+        // non-negative doubles order like their bit patterns
+        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(a.peak2 + c, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
@@ -166,17 +172,20 @@ __global__ __launch_bounds__(64) void k_agc_scan(const AgcArgs a)
 __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
 {
     if (a.run_if && *a.run_if == 0) return;
-    const int c = blockIdx.x;
-    const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
-    const int64_t len = e - b;
-    if (len <= 0) return;
-    const int64_t per = (len + a.splits - 1) / a.splits;
-    const int64_t lo = b + (int64_t)blockIdx.y * per;
-    int64_t hi = lo + per; if (hi > e) hi = e;
-    const float g = a.gain[c];
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-        const cf2 v = a.x[i];
-        pack_store(a.out, i, a.out_fmt, cf2{v.x * g, v.y * g});   // samples[i] *= gain (complex * real)
+    const int64_t n_items = (int64_t)a.geom.n_chunks * a.splits;
+    for (int64_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+        const int c = (int)(w / a.splits), sy = (int)(w % a.splits);
+        const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+        const int64_t len = e - b;
+        if (len <= 0) continue;
+        const int64_t per = (len + a.splits - 1) / a.splits;
+        const int64_t lo = b + (int64_t)sy * per;
+        int64_t hi = lo + per; if (hi > e) hi = e;
+        const float g = a.gain[c];
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const cf2 v = a.x[i];
+            pack_store(a.out, i, a.out_fmt, cf2{v.x * g, v.y * g});   // samples[i] *= gain (complex * real)
+        }
     }
 }
 
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
         }
         a.chunk_len[c] = k;                                        // scratch: 0 empty, 1 healthy, 2 weak
         a.peak2[c] = 0ull;                                         // handed back zeroed: the next fused launch accumulates into it (no fill on the hot path)
+        if (a.peak2_fallback) a.peak2_fallback[c] = 0ull;          // ... and the fallback's own array, which its k_agc_peak accumulates into
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 1, 1);
     if (__ballot(weak) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 2, 1);
@@ -283,12 +293,18 @@ hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s)
 hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
 {
     if (a.geom.n_chunks <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(a.peak2, 0, (size_t)a.geom.n_chunks * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)a.geom.n_chunks, (unsigned)a.splits);
-    hipLaunchKernelGGL(k_agc_peak, grid, dim3(kThreads), 0, s, a);                     // also fills chunk_len[]
+    const int64_t n_items = (int64_t)a.geom.n_chunks * a.splits;
+    unsigned grid = (unsigned)n_items;
+    if (a.run_if) {
+        // conditional fallback behind a fused launch: k_agc_classify has zeroed peak2 already; small grids (see k_agc_peak)
+        if (grid > 2048u) grid = 2048u;
+    } else {
+        const hipError_t e = hipMemsetAsync(a.peak2, 0, (size_t)a.geom.n_chunks * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_agc_peak, dim3(grid), dim3(kThreads), 0, s, a);                     // also fills chunk_len[]
     hipLaunchKernelGGL(k_agc_scan, dim3(1), dim3(64), 0, s, a);
-    if (a.n_out > 0) hipLaunchKernelGGL(k_agc_apply, grid, dim3(kThreads), 0, s, a);
+    if (a.n_out > 0) hipLaunchKernelGGL(k_agc_apply, dim3(grid), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

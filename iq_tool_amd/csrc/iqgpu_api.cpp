@@ -1193,6 +1193,7 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     AgcArgs va = agc_args();
     va.verify_flag = c->d_agc_flag;
     va.peak_approx = mid ? 1 : 0;
+    va.peak2_fallback = (unsigned long long *)c->agc_peak_b.p;
     KernelTimer kt(c, IQGPU_K_AGC);
     HIP_TRY(launch_agc_verify(va, c->stream));
     FrontArgs fb = spec;
@@ -1208,6 +1209,7 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     }
     HIP_TRY(launch_front_s1(fb, c->stream));
     AgcArgs ga = va;
+    ga.peak2_fallback = nullptr;
     ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
     ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
     HIP_TRY(launch_agc(ga, c->stream));
