@@ -130,7 +130,7 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
     auto taps = [&](v2f (&t)[8], unsigned row) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + (unsigned)kFTapPlaneB * i);
+        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + tap_pair_off(i));
     };
     // The tile loop as a fixed sequence of small batches, LDS batches (at most ~16 operations: a wave can have 15 in flight)
     // alternating with the FMA runs that cover them; every batch of reads is issued at least one FMA run before its first use.
@@ -218,7 +218,7 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     auto V_taprows = [&]() {
         uint32_t P = Pl;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j], a.tap_fold_mul, a.tap_fold_shift); P += step; }
+        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
     };
     auto V_hb = [&](const int q0, const int q1) {
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kFatThreads) void k_front_fat(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads, a.tap_fold_mul, a.tap_fold_shift);
+    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads);
     for (int i = lane; i < kFatWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 

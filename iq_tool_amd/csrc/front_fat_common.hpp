@@ -6,39 +6,37 @@
 
 namespace iqgpu {
 
-// polyphase taps: per arm R = 0 0 tap13 .. tap0 0 0 (18 floats).  Pair p of R (R[2p], R[2p+1]) of EVERY arm lives in plane p
-// (8 bytes per arm, arm a at slot a ^ (a >> 5)), planes 0 .. 8; the pairs one float on (R[2p+1], R[2p+2]) in planes 9 .. 16.  A
-// slot reads its 8 pairs from 8 consecutive planes: planes 2056 bytes apart cannot be fused into (half-rate) ds_read2_b64.
+// polyphase taps: per arm R = 0 0 tap13 .. tap0 0 0 (18 floats); a slot whose output sits d in {0, 1, 2} samples past the slot's
+// first possible one multiplies its 16-sample window by T_d[w] = R[w + 2 - d].  17 planes of 8 bytes per arm, 2056 bytes apart
+// (reads of one slot are 4112 apart: neither ds_read2_b64 nor ds_read2st64_b64 can fuse them into a half-rate instruction);
+// plane pi holds (R[16 - pi], R[17 - pi]) of every arm, so that pair q of T_d sits in plane d + 14 - 2 q: the address is LINEAR in
+// (position, arm) = the top bits of the phase -- tap_row() is a shift, an add and a shift-add.
+// (Rounds 2 - 3 placed arm a at slot a ^ (a >> 5) and picked planes by the parity of d: a third fewer bank conflicts in the
+// gather, but 11 VALU instructions per slot, one of them a quarter-rate integer multiply; a build without ANY conflict in the
+// gather measured -2.4 %, profiles/r03_ab.md, and the address arithmetic cost more than that.)
 constexpr int kFTapPlaneB = 2048 + 8;
 constexpr int kFTapPlanes = 17;
 constexpr int kFTapLds = (kFTapPlanes * kFTapPlaneB + 15) / 16 * 16;
+__host__ __device__ constexpr unsigned tap_pair_off(int q) { return (unsigned)((14 - 2 * q) * kFTapPlaneB); }   // pair q of a slot, from tap_row()
 
 // fills the planes from the [256][16] table of the chain (all threads of the workgroup)
-__device__ __forceinline__ uint32_t tap_fold(const uint32_t arm, const uint32_t mul, const uint32_t shift)
-{
-    const uint32_t m = (arm * mul) & 255u;
-    return m ^ (m >> shift);
-}
-__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads, const uint32_t mul, const uint32_t shift)
+__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads)
 {
     for (int i = tid; i < 256 * kFTapPlanes; i += nthreads) {           // R[k] = tap[15 - k] for k = 2 .. 15, else 0
-        const int arm = i & 255, pl = i >> 8, row = (int)tap_fold((uint32_t)arm, mul, shift);
-        const int k0 = pl < 9 ? 2 * pl : 2 * (pl - 9) + 1;
+        const int arm = i & 255, pl = i >> 8;
+        const int k0 = 16 - pl;
         const float r0 = (k0 >= 2 && k0 < 16) ? arb_table[arm * 16 + 15 - k0] : 0.0f;
         const float r1 = (k0 + 1 >= 2 && k0 + 1 < 16) ? arb_table[arm * 16 + 14 - k0] : 0.0f;
-        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + row * 8);
+        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + arm * 8);
         d[0] = r0; d[1] = r1;
     }
 }
-// LDS address of the (shifted) tap pairs of an output with phase P from the lane's first sample, in the slot whose first
-// possible sample is LOJ: position p = P >> 24, arm = the next 8 bits, shift d = p - LOJ in {0, 1, 2}:
-// d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
-__device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ, const uint32_t mul, const uint32_t shift)
+// LDS address of plane 0's entry for an output with phase P from the lane's first sample, in the slot whose first possible sample
+// is LOJ: position p = P >> 24, arm = the next 8 bits, d = p - LOJ in {0, 1, 2}; entry = d * 2056 + arm * 8 =
+// 8 * ((P >> 16) + (P >> 24)) - 2056 * LOJ  (unsigned arithmetic: the constant part may wrap, the sum does not)
+__device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ)
 {
-    const uint32_t arm = (P >> 16) & 255u;
-    const uint32_t d = (P >> 24) - (uint32_t)LOJ;
-    const uint32_t off = (d & 1u) ? 9u * (uint32_t)kFTapPlaneB : (uint32_t)kFTapPlaneB - (uint32_t)(kFTapPlaneB / 2) * d;
-    return tap_lds + tap_fold(arm, mul, shift) * 8u + off;
+    return (((P >> 16) + (P >> 24)) << 3) + (tap_lds - (unsigned)(LOJ * kFTapPlaneB));
 }
 
 __device__ __forceinline__ v2f fma2(float t, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{t, t}, x, acc); }

@@ -183,7 +183,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #define FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     auto taps = [&](v2f (&t)[8], unsigned row) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + (unsigned)kFTapPlaneB * i);
+        for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + tap_pair_off(i));
     };
     // ---- pointwise, chunk by chunk: unpack, mix, -> XE / XO (on top of the half-band stream: its window reads are issued)
     auto VL_point = [&]() {
@@ -273,7 +273,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto V_taprows = [&]() {
         uint32_t P = Pl;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j], a.tap_fold_mul, a.tap_fold_shift); P += step; }
+        for (int j = 0; j < NS; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
     };
     auto V_hb = [&]() {
 #pragma unroll
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads, a.tap_fold_mul, a.tap_fold_shift);
+    fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads);
     for (int i = lane; i < G::XBYTES / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < kMidEdgeLds / 16; i += kMidThreads) ((float4 *)arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();

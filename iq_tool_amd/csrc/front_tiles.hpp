@@ -34,10 +34,11 @@ __device__ __forceinline__ uint32_t ceil_div_small(uint32_t x, uint32_t d, float
 // way), truncation then int16 saturation equals float clamp then truncation.
 __device__ __forceinline__ uint32_t pack_cs16(cf2 v)
 {
-    float p = v.x * 32767.0f, q = v.y * 32767.0f;
-    p += copysignf(0.5f, p); q += copysignf(0.5f, q);
+    typedef float f2 __attribute__((ext_vector_type(2)));           // (both components in one packed multiply and one packed add)
+    f2 s = f2{v.x, v.y} * f2{32767.0f, 32767.0f};
+    s = s + f2{copysignf(0.5f, s.x), copysignf(0.5f, s.y)};
     typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)p, (int)q);
+    const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)s.x, (int)s.y);
     return __builtin_bit_cast(uint32_t, pk);
 }
 // cu8 / cs8: one frame as 16 bits (src/sample_convert.c:40-73, the arithmetic of pack_store)

@@ -177,7 +177,6 @@ struct iqgpu_chain {
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     uint32_t dbg = 0;             // kDbg* diagnostic switches, read from the environment once at create
-    uint32_t tap_fold_mul = 1, tap_fold_shift = 5;      // placement of the arms in the tap planes of k_front_fat / k_front_mid
     // profiling
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
@@ -288,7 +287,6 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
                  (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
                  (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8") ? kDbgMid8 : 0u);
-        if (const char *tf = getenv("IQGPU_TAP_FOLD")) { unsigned m = 1, k = 5; if (sscanf(tf, "%u,%u", &m, &k) == 2 && (m & 1u) && k >= 1 && k <= 8) { c->tap_fold_mul = m; c->tap_fold_shift = k; } }
     }
 
     // ---- ratio (src/setup.c:91-122) ----
@@ -986,7 +984,6 @@ int Call::stage_front()
 {
     FrontArgs a{};
     a.dbg = c->dbg;
-    a.tap_fold_mul = c->tap_fold_mul; a.tap_fold_shift = c->tap_fold_shift;
     a.raw = d_raw_in;
     a.hist_in = c->d_hist[c->hist_cur]; a.hist_out = c->d_hist[c->hist_cur ^ 1];
     a.frames_in = (int64_t)frames_in; a.hist_cap = c->hist_cap; a.rem0 = c->rem;

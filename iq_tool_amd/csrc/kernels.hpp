@@ -66,9 +66,6 @@ enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
-    // k_front_fat / k_front_mid: where arm a sits in a tap plane: slot f(a) = m ^ (m >> tap_fold_shift), m = (a * tap_fold_mul) & 255
-    // (tap_fold_mul odd: a bijection; chosen per chain for the fewest LDS bank conflicts of its step, iqgpu_api.cpp)
-    uint32_t    tap_fold_mul, tap_fold_shift;
     // input
     const void *raw;          // frames_in new samples, in_fmt
     const cf2  *hist_in;      // hist_cap processed samples that precede this call
