@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 CHAIN = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+DIAG_TARGET_HZ = os.environ.get("IQGPU_BENCH_TARGET_HZ")      # diagnostic runs of tools/ only: another output rate for the headline chain
+if DIAG_TARGET_HZ:
+    CHAIN = dict(CHAIN, target_rate_hz=float(DIAG_TARGET_HZ))
 # the other single-GPU BASELINE.json configs (parity-test cases; timed only with --config 3 / 4, never the default line)
 OTHER = {
     3: dict(chain=dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True,
@@ -497,6 +500,8 @@ def main():
         if args.config != 2:
             line["config"]["workload"] = workload
             line["roofline"] = fp32_roofline(case)
+        if DIAG_TARGET_HZ:
+            line["config"]["workload"] = "DIAGNOSTIC (IQGPU_BENCH_TARGET_HZ=%s), not a BASELINE config: " % DIAG_TARGET_HZ + str(line["config"]["workload"])
         if args.preset:
             line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
                                           "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "

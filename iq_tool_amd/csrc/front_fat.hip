@@ -217,8 +217,13 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     // d = 2 -> planes 0 .. 7, d = 0 -> planes 1 .. 8, d = 1 -> the planes that start one float on (9 .. 16)
     auto V_taprows = [&]() {
         uint32_t P = Pl;
+        if (a.tap_fold) {       // (wave-uniform: a scalar branch)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
+            for (int j = 0; j < 5; ++j) { trow[j] = tap_row<true>(w.tap_lds, P, LO[j]); P += step; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { trow[j] = tap_row<false>(w.tap_lds, P, LO[j]); P += step; }
+        }
     };
     auto V_hb = [&](const int q0, const int q1) {
 #pragma unroll
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kFatThreads) void k_front_fat(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads);
+    fill_tap_planes(s_tap, a.arb_table, tid, kFatThreads, a.tap_fold != 0);
     for (int i = lane; i < kFatWaveLds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 

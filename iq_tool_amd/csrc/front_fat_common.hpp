@@ -9,34 +9,40 @@ namespace iqgpu {
 // polyphase taps: per arm R = 0 0 tap13 .. tap0 0 0 (18 floats); a slot whose output sits d in {0, 1, 2} samples past the slot's
 // first possible one multiplies its 16-sample window by T_d[w] = R[w + 2 - d].  17 planes of 8 bytes per arm, 2056 bytes apart
 // (reads of one slot are 4112 apart: neither ds_read2_b64 nor ds_read2st64_b64 can fuse them into a half-rate instruction);
-// plane pi holds (R[16 - pi], R[17 - pi]) of every arm, so that pair q of T_d sits in plane d + 14 - 2 q: the address is LINEAR in
-// (position, arm) = the top bits of the phase -- tap_row() is a shift, an add and a shift-add.
-// (Rounds 2 - 3 placed arm a at slot a ^ (a >> 5) and picked planes by the parity of d: a third fewer bank conflicts in the
-// gather, but 11 VALU instructions per slot, one of them a quarter-rate integer multiply; a build without ANY conflict in the
-// gather measured -2.4 %, profiles/r03_ab.md, and the address arithmetic cost more than that.)
+// plane pi holds (R[16 - pi], R[17 - pi]) of every arm, so that pair q of T_d sits in plane d + 14 - 2 q: the address is linear
+// in the position and, with arm a in slot a of a plane, in the arm too -- tap_row() is then a shift, an add and a shift-add on
+// the top bits of the phase.  Which lanes of a half-wave meet in a bank pair depends on the step alone, so the placement is
+// chosen per chain (front_tap_fold(), front_mid.hip): slot a, or slot a ^ (a >> 5) (two more instructions) for steps whose
+// lanes would otherwise walk the arms in strides of 16 or 32 (s = 1.625: 15.5 modelled cycles per read against 4.0).
+// (Rounds 2 - 3 always folded, and picked planes by the parity of d: 11 VALU instructions per slot, one of them a quarter-rate
+// integer multiply; a build without ANY conflict in the gather measured -2.4 %, profiles/r03_ab.md.)
 constexpr int kFTapPlaneB = 2048 + 8;
 constexpr int kFTapPlanes = 17;
 constexpr int kFTapLds = (kFTapPlanes * kFTapPlaneB + 15) / 16 * 16;
 __host__ __device__ constexpr unsigned tap_pair_off(int q) { return (unsigned)((14 - 2 * q) * kFTapPlaneB); }   // pair q of a slot, from tap_row()
 
 // fills the planes from the [256][16] table of the chain (all threads of the workgroup)
-__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads)
+__device__ __forceinline__ void fill_tap_planes(float *s_tap, const float *arb_table, const int tid, const int nthreads, const bool fold)
 {
     for (int i = tid; i < 256 * kFTapPlanes; i += nthreads) {           // R[k] = tap[15 - k] for k = 2 .. 15, else 0
-        const int arm = i & 255, pl = i >> 8;
+        const int arm = i & 255, pl = i >> 8, row = fold ? (arm ^ (arm >> 5)) : arm;
         const int k0 = 16 - pl;
         const float r0 = (k0 >= 2 && k0 < 16) ? arb_table[arm * 16 + 15 - k0] : 0.0f;
         const float r1 = (k0 + 1 >= 2 && k0 + 1 < 16) ? arb_table[arm * 16 + 14 - k0] : 0.0f;
-        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + arm * 8);
+        float *d = (float *)((char *)s_tap + pl * kFTapPlaneB + row * 8);
         d[0] = r0; d[1] = r1;
     }
 }
 // LDS address of plane 0's entry for an output with phase P from the lane's first sample, in the slot whose first possible sample
-// is LOJ: position p = P >> 24, arm = the next 8 bits, d = p - LOJ in {0, 1, 2}; entry = d * 2056 + arm * 8 =
-// 8 * ((P >> 16) + (P >> 24)) - 2056 * LOJ  (unsigned arithmetic: the constant part may wrap, the sum does not)
+// is LOJ: position p = P >> 24, arm = the next 8 bits, d = p - LOJ in {0, 1, 2}; entry = d * 2056 + slot(arm) * 8 =
+// 8 * (x + p) - 2056 * LOJ with x = P >> 16 = 256 p + arm  (unsigned arithmetic: the constant part may wrap, the sum does not);
+// folded: x ^ bits 5 .. 7 of the arm in x's place
+template <bool FOLD>
 __device__ __forceinline__ unsigned tap_row(const unsigned tap_lds, const uint32_t P, const int LOJ)
 {
-    return (((P >> 16) + (P >> 24)) << 3) + (tap_lds - (unsigned)(LOJ * kFTapPlaneB));
+    uint32_t x = P >> 16;
+    if (FOLD) x ^= (P >> 21) & 7u;
+    return ((x + (P >> 24)) << 3) + (tap_lds - (unsigned)(LOJ * kFTapPlaneB));
 }
 
 __device__ __forceinline__ v2f fma2(float t, v2f x, v2f acc) { return __builtin_elementwise_fma(v2f{t, t}, x, acc); }

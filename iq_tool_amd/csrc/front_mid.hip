@@ -272,8 +272,13 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     };
     auto V_taprows = [&]() {
         uint32_t P = Pl;
+        if (a.tap_fold) {       // (wave-uniform: a scalar branch)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) { trow[j] = tap_row(w.tap_lds, P, LO[j]); P += step; }
+            for (int j = 0; j < NS; ++j) { trow[j] = tap_row<true>(w.tap_lds, P, LO[j]); P += step; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { trow[j] = tap_row<false>(w.tap_lds, P, LO[j]); P += step; }
+        }
     };
     auto V_hb = [&]() {
 #pragma unroll
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         const int arm = i / 14, k = i % 14;
         s_arb[(arm ^ (arm >> 5)) * 14 + k] = a.arb_table[arm * 16 + k];
     }
-    fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads);
+    fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads, a.tap_fold != 0);
     for (int i = lane; i < G::XBYTES / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < kMidEdgeLds / 16; i += kMidThreads) ((float4 *)arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -444,6 +449,53 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
         run_mid<NL, NONCO, L3, L4, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
     }
+}
+
+// Placement of the arms in the tap planes (front_fat_common.hpp).  A slot's 8-byte tap reads are served a half-wave at a time, 32
+// lanes over 32 bank pairs, and take as many cycles as the fullest bank pair has DISTINCT entries.  Which entries meet is a
+// function of the step alone: lane l's slot j reads entry slot(arm) + 257 d of the lane's phase.  Model both placements over a
+// spread of tile phases and keep the linear one unless the fold wins by more than its two extra VALU instructions per slot are
+// worth (8 reads per slot: 1.5 cycles per read).  NRSC-5's step at 6 per lane: 6.0 against 5.8 -> linear; the same step at 8 per
+// lane walks the arms in strides of 16: 15.2 against 5.4 -> folded; s = 1.625 at 6 per lane 15.5 against 4.0.
+static double tap_gather_cycles(const uint32_t step, const int nl, const bool fold)
+{
+    const int ns = nl == 6 ? 4 : 5;
+    int lo[5];
+    for (int j = 0; j < 5; ++j) lo[j] = (int)(((uint64_t)step * (uint64_t)j) >> 24);
+    uint64_t total = 0, reads = 0;
+    for (int t = 0; t < 48; ++t) {
+        const uint64_t base = (uint64_t)64 * nl * t * 7;            // first half-band sample of the tile
+        uint32_t P[64];
+        for (int l = 0; l < 64; ++l) {
+            const uint64_t g = (base + (uint64_t)nl * l) << 24;
+            const uint64_t k = (g + step - 1) / step;               // first output at or behind the lane's first sample
+            P[l] = (uint32_t)(k * step - g);
+        }
+        for (int j = 0; j < ns; ++j) {
+            for (int h = 0; h < 2; ++h) {
+                uint32_t ent[32]; int n_ent = 0, cnt[32] = {0};
+                for (int l = 32 * h; l < 32 * h + 32; ++l) {
+                    const uint32_t Pj = P[l] + (uint32_t)j * step;
+                    uint32_t x = Pj >> 16;
+                    if (fold) x ^= (Pj >> 21) & 7u;
+                    const uint32_t e = x + (Pj >> 24) - 257u * (uint32_t)lo[j];
+                    bool seen = false;
+                    for (int i = 0; i < n_ent; ++i) if (ent[i] == e) { seen = true; break; }
+                    if (!seen) { ent[n_ent++] = e; cnt[e & 31u] += 1; }
+                }
+                int mx = 0;
+                for (int b = 0; b < 32; ++b) if (cnt[b] > mx) mx = cnt[b];
+                total += (uint64_t)mx;
+            }
+            reads += 1;
+        }
+    }
+    return (double)total / (double)reads;
+}
+int front_tap_fold(const uint32_t step, const int nl)
+{
+    if (nl != 6 && nl != 8) return 0;
+    return tap_gather_cycles(step, nl, true) + 1.5 < tap_gather_cycles(step, nl, false) ? 1 : 0;
 }
 
 // step classes: lo_3 = floor(3 s), lo_4 = floor(4 s) with s = step / 2^24.  Six per lane (four slots) takes 1.5 <= s < 2, eight per

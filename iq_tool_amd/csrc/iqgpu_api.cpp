@@ -177,6 +177,7 @@ struct iqgpu_chain {
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     uint32_t dbg = 0;             // kDbg* diagnostic switches, read from the environment once at create
+    int tap_fold6 = 0, tap_fold8 = 0, tap_fold_env = -1;    // placement of the arms in the tap planes of k_front_mid / k_front_fat for this chain's step (front_tap_fold); IQGPU_TAP_FOLD=0|1 overrides
     // profiling
     bool profiling = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
@@ -287,6 +288,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
                  (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
                  (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8") ? kDbgMid8 : 0u);
+        if (const char *tf = getenv("IQGPU_TAP_FOLD")) c->tap_fold_env = atoi(tf) != 0 ? 1 : 0;
     }
 
     // ---- ratio (src/setup.c:91-122) ----
@@ -328,6 +330,8 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     if (c->resample) {
         if (!make_resample_plan(c->ratio, 60.0f, c->rp, err)) return fail(IQGPU_ERATIO, "%s", err.c_str());
         if (c->rp.S >= kMaxS) return fail(IQGPU_ERATIO, "too many half-band stages");
+        c->tap_fold6 = c->tap_fold_env >= 0 ? c->tap_fold_env : front_tap_fold(c->rp.step, 6);
+        c->tap_fold8 = c->tap_fold_env >= 0 ? c->tap_fold_env : front_tap_fold(c->rp.step, 8);
     }
 
     // ---- user filter (src/filter.c:138-393) ----
@@ -1074,6 +1078,7 @@ int Call::stage_front()
             a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
             HIP_TRY(clean_agc_peaks());
         }
+        a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (front_mid_nl(a) == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream) : launch_front_s1(a, c->stream)); }
         if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
     } else {

@@ -66,6 +66,7 @@ enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
+    uint32_t    tap_fold;                  // k_front_fat / k_front_mid: arm a in slot a ^ (a >> 5) of a tap plane instead of slot a (front_tap_fold())
     // input
     const void *raw;          // frames_in new samples, in_fmt
     const cf2  *hist_in;      // hist_cap processed samples that precede this call
@@ -173,6 +174,9 @@ int front_mid_waves();
 int front_mid_max_edge_waves();          // launches with more edge runs than this stay on k_front_s1
 int front_mid_nl(const FrontArgs &a);    // half-band outputs per lane of the instantiation for these arguments (8, 6; 0 = not its shape)
 int front_mid_tile(int nl);              // its tile: 128 nl frames
+// placement of the arms in the tap planes for a chain's step and nl outputs per lane: 1 = folded, 0 = linear (whichever a model of
+// the half-wave's bank pairs prices lower, the fold's two extra instructions per slot counted)
+int front_tap_fold(uint32_t step, int nl);
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
 // wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles

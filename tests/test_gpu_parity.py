@@ -782,6 +782,8 @@ def test_preset_shape_without_a_shift_has_its_own_instantiation(gpu, oracle, mon
     (800000.0, 0.0),        # step / 2^24 = 1.5 exactly: the lower edge of k_front_mid's classes
     (601000.0, -77e3),      # step / 2^24 = 1.9967: just below the upper edge (2.0 = no arbitrary stage at all)
     (810000.0, 200e3),      # step / 2^24 = 1.481: outside both: k_front_s1 whatever the switches say
+    (2.4e6 / 3.25, 200e3),  # step / 2^24 = 1.625: six-sample lanes walk the arms in strides of 32: the folded tap placement is chosen
+    (2.4e6 / 3.5, 0.0),     # step / 2^24 = 1.75: the same with strides of 64
 ])
 @pytest.mark.parametrize("variant", ["fat", "mid"])
 def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, target_hz, shift_hz, variant):
@@ -811,6 +813,26 @@ def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, tar
     assert np.array_equal(run(splits[0], block_samples=4096), ref)
     monkeypatch.delenv("IQGPU_FORCE_FAT")
     int_close(ref, run_oracle(oracle, raw, **kw))
+
+
+@pytest.mark.parametrize("target_hz", [744187.5, 2.4e6 / 3.25, 696000.0])
+@pytest.mark.parametrize("variant", ["fat", "mid"])
+def test_tap_placement_does_not_change_a_bit(gpu, monkeypatch, target_hz, variant):
+    """The arms of the polyphase table sit in the tap planes either in order or folded (a ^ (a >> 5)), whichever a model of the
+    LDS bank pairs prices lower for the chain's step (front_tap_fold, front_mid.hip); IQGPU_TAP_FOLD=0|1 forces one.  Where a tap
+    sits cannot change what is computed: the bytes of both placements are equal to the chooser's."""
+    if variant == "fat":
+        monkeypatch.setenv("IQGPU_FAT", "1")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")
+    n = 1_500_001
+    raw = synth.raw_stream(n, 2.4e6, 32, "cs16")
+    kw = dict(NRSC5, target_rate_hz=target_hz, shift_hz=200e3)
+    ref = run_gpu(gpu, raw, splits=[n], **kw)
+    for fold in ("0", "1"):
+        monkeypatch.setenv("IQGPU_TAP_FOLD", fold)
+        got = run_gpu(gpu, raw, splits=[700_001, n - 700_001], **kw)
+        assert np.array_equal(got, ref), (fold, int((got != ref).sum()))
+    monkeypatch.delenv("IQGPU_TAP_FOLD")
 
 
 @pytest.mark.parametrize("seed", range(int(_os_agc.environ.get("IQGPU_FUZZ_SEEDS", "24"))))
