@@ -278,8 +278,8 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
     };
     if (!EDGE) {
         const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * VB + 4 * VB * lane;
-        load_chunk<VB>(src, nxt[0]);
-        load_chunk<VB>(src + 256 * VB, nxt[1]);
+        load_chunk<VB, IQGPU_NT_CASC != 0>(src, nxt[0]);
+        load_chunk<VB, IQGPU_NT_CASC != 0>(src + 256 * VB, nxt[1]);
         if (nco_on) nco_lookup(t_begin * kWTile);
     }
 
@@ -302,16 +302,16 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
             rw[0] = nxt[0].w[0]; rw[1] = nxt[0].w[1]; rw[2] = nxt[1].w[0]; rw[3] = nxt[1].w[1];
             if (fresh) {
                 const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
-                load_chunk<VB>(src, nxt[0]);
-                load_chunk<VB>(src + 256 * VB, nxt[1]);
+                load_chunk<VB, IQGPU_NT_CASC != 0>(src, nxt[0]);
+                load_chunk<VB, IQGPU_NT_CASC != 0>(src + 256 * VB, nxt[1]);
             }
         } else if (!EDGE) {
             unpack_chunk<VB>(nxt[0], a.in_fmt, a.gain, unit_gain, x[0]);
             unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             if (fresh) {
                 const char *src = (const char *)a.raw + (j0 + kWTile) * VB + 4 * VB * lane;
-                load_chunk<VB>(src, nxt[0]);
-                load_chunk<VB>(src + 256 * VB, nxt[1]);
+                load_chunk<VB, IQGPU_NT_CASC != 0>(src, nxt[0]);
+                load_chunk<VB, IQGPU_NT_CASC != 0>(src + 256 * VB, nxt[1]);
             }
             if (a.dc_enable) {
                 if (!dc_started) { const cd2 cv = a.dc_carry[seg]; dc_vr = (float)cv.x; dc_vi = (float)cv.y; dc_started = true; }

@@ -308,10 +308,22 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void k_fftconv16(const FftConvAr
     {
         cf2 *dst = X + sw(tid);
         const cf2 *srcg = a.fbuf + o0 + tid;
+        const bool nt = 4 * L1 <= N;
         const int64_t room = a.fbuf_len - o0 - tid;                  // window samples this thread may read: p = tid + i T < room
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            dst[i * T + ((i * T) >> 5)] = ((int64_t)(i * T) < room) ? srcg[i * T] : cf2{0.0f, 0.0f};
+        {
+            // a window shares its first ntaps - 1 samples with the block in front: where that is a small part of it (nt: at most
+            // a quarter) the stream is as good as read once and takes the non-temporal hint (config 3: step 0.767 -> 0.744 ms;
+            // with half of every window shared -- config 4 -- the hint costs 1.5 %)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            cf2 vin{0.0f, 0.0f};
+            if ((int64_t)(i * T) < room) {
+                if (nt) { const f2v q = __builtin_nontemporal_load((const f2v *)(srcg + i * T)); vin = cf2{q.x, q.y}; }
+                else vin = srcg[i * T];
+            }
+            dst[i * T + ((i * T) >> 5)] = vin;
+        }
     }
     __syncthreads();
     fft16_lds<LOG2N>(X, a.twiddle, tid);

@@ -90,7 +90,7 @@ __device__ __forceinline__ void run_fat(const FrontArgs &a, const FatLds &w, con
     auto load_tile = [&](int64_t T) {
         const char *src = (const char *)a.raw + (T * 1024 - a.rem0) * 4 + 16 * lane;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
+        for (int c = 0; c < 4; ++c) load_chunk<4, IQGPU_NT_FAT != 0>(src + 1024 * c, nxt[c]);
     };
     auto nco_lookup = [&](int64_t T) {
 #pragma unroll

@@ -216,8 +216,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     };
     if (!EDGE) {
         const char *src = (const char *)a.raw + (t_begin * TILE - a.rem0) * VB + 4 * VB * lane;
-        load_chunk<VB>(src, nxt[0]);
-        if (NC == 2) load_chunk<VB>(src + 256 * VB, nxt[1]);
+        load_chunk<VB, IQGPU_NT_S1 != 0>(src, nxt[0]);
+        if (NC == 2) load_chunk<VB, IQGPU_NT_S1 != 0>(src + 256 * VB, nxt[1]);
         if (nco_on) nco_lookup(t_begin * TILE);
     }
 
@@ -227,14 +227,31 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     // ... and the 2-byte formats (cu8 / cs8: the cu8-nrsc5 presets) likewise: one store per slot was a third of that shape's time
     const bool out_b8 = !FAST && (a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8);
     const bool defer = !EDGE && (FAST || a.out_fmt == IQGPU_FMT_CS16 || out_b8);
+    // ... and cf32 (the last stage in front of a user filter): the lane's 2 .. 4 frames as one 16-byte store + at most one more, a tile late --
+    // stored where they were computed, the wait for the next tile's frames (vmcnt(0)) stood behind four fresh 8-byte stores every tile
+    // (cf32 input only: the last stage behind k_cascade; the 8-bit-input kernels have no eight registers to spare at 16 waves)
+    const bool defer_f = !EDGE && !FAST && BPS == 8 && a.out_fmt == IQGPU_FMT_CF32;
     // A lane's outputs of a tile are consecutive (2 to 4 of them: one per 1 .. 2 half-band samples), so
     // they are compacted and leave as one 8-byte store plus at most one more, instead of four predicated
     // dword stores -- the CU's vector-memory issue path is one of the three pipes this kernel loads.
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
     uint32_t pend_c[4] = {0, 0, 0, 0}, pend_n0 = 0, pend_cnt = 0;
+    cf2 pend_f[4] = {cf2{0.f, 0.f}, cf2{0.f, 0.f}, cf2{0.f, 0.f}, cf2{0.f, 0.f}};
+    typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
     char *pend_base = (char *)a.out;
     typedef uint32_t u32a2 __attribute__((aligned(2)));
     auto flush_pending = [&]() {
+        if (defer_f) {
+            if (pend_cnt != 0) {
+                char *b = pend_base + 8u * pend_n0;
+                if (pend_cnt == 1) *(cf2 *)b = pend_f[0];
+                else *(f32x4a8 *)b = f32x4a8{pend_f[0].x, pend_f[0].y, pend_f[1].x, pend_f[1].y};
+                if (pend_cnt == 3) *(cf2 *)(b + 16) = pend_f[2];
+                if (pend_cnt == 4) *(f32x4a8 *)(b + 16) = f32x4a8{pend_f[2].x, pend_f[2].y, pend_f[3].x, pend_f[3].y};
+                pend_cnt = 0;
+            }
+            return;
+        }
         if (out_b8) {
             // 2-byte frames: the lane's 2 .. 4 outputs as one or two dwords at a 2-byte-aligned address, an odd one as a short
             if (pend_cnt != 0) {
@@ -298,11 +315,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 if (NC == 2) unpack_chunk<VB>(nxt[1], a.in_fmt, a.gain, unit_gain, x[1]);
             }
             STAMP(0);
-            if (defer) flush_pending();
+            if (defer || defer_f) flush_pending();
             {
                 const char *src = (const char *)a.raw + (j0 + TILE) * VB + 4 * VB * lane;
-                load_chunk<VB>(src, nxt[0]);
-                if (NC == 2) load_chunk<VB>(src + 256 * VB, nxt[1]);
+                load_chunk<VB, IQGPU_NT_S1 != 0>(src, nxt[0]);
+                if (NC == 2) load_chunk<VB, IQGPU_NT_S1 != 0>(src + 256 * VB, nxt[1]);
             }
             if (!FAST && a.dc_enable) {
                 if (!dc_started) { const cd2 cv = a.dc_carry[seg]; dc_vr = (float)cv.x; dc_vi = (float)cv.y; dc_started = true; }
@@ -516,6 +533,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                 if (!EDGE) __builtin_amdgcn_s_setprio(0);
                 uint32_t kk = n0;
                 uint32_t pk[4] = {0, 0, 0, 0};
+                cf2 pf[4] = {cf2{0.f, 0.f}, cf2{0.f, 0.f}, cf2{0.f, 0.f}, cf2{0.f, 0.f}};
                 uint32_t agc_qb = 256u;                           // half-band samples of this tile below it are in chunk agc_c
                 if (AGC) {
                     const int64_t F0 = (((int64_t)256 * t + 1) << AS) - 1 - a.agc_rem;   // last input frame that polyphase-input sample 0 of the tile needs
@@ -547,9 +565,19 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                             yy = v2f{yy.x * agc_g, yy.y * agc_g};
                         }
                         if (defer) pk[r] = out_b8 ? pack_b8(cf2{yy.x, yy.y}, a.out_fmt == IQGPU_FMT_CU8) : pack_cs16(cf2{yy.x, yy.y});
+                        else if (defer_f) pf[r] = cf2{yy.x, yy.y};
                         else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
+                }
+                if (defer_f) {
+                    const bool h01 = hit[0] && hit[1];
+                    pend_f[0] = hit[0] ? pf[0] : pf[1];
+                    pend_f[1] = h01 ? pf[1] : (hit[2] ? pf[2] : pf[3]);
+                    pend_f[2] = (h01 && hit[2]) ? pf[2] : pf[3];
+                    pend_f[3] = pf[3];
+                    pend_n0 = n0;
+                    pend_cnt = kk - n0;
                 }
                 if (defer) {
                     // compact the hit slots (gaps between hits are 1 or 2 samples, so a streaming lane has >= 2)
@@ -603,7 +631,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
     }
-    if (defer) flush_pending();
+    if (defer || defer_f) flush_pending();
     if (AGC && agc_any) {
         const double m = wave_max_d(agc_m0);
         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));

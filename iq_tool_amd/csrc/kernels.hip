@@ -16,6 +16,10 @@
 #include "dsp_device.hpp"
 #include "kernels.hpp"
 
+#ifndef IQGPU_NT_DC
+#define IQGPU_NT_DC 1      // k_dc_prefix reads the call's frames once, with the non-temporal hint (0.116 -> 0.105 ms on config 3)
+#endif
+
 namespace iqgpu {
 
 __device__ __forceinline__ int lvl_hist(const FrontArgs &a, int i) { return (i < a.S) ? 4 * a.m[i] : kArbHist; }
@@ -373,7 +377,15 @@ __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
             for (; ch + 4 <= n_chunks; ch += 4) {
                 uint4 v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = *(const uint4 *)(base + ((ch + i) << 12));
+                for (int i = 0; i < 4; ++i) {
+#if IQGPU_NT_DC
+                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                    const u4v q = __builtin_nontemporal_load((const u4v *)(base + ((ch + i) << 12)));
+                    v[i] = make_uint4(q.x, q.y, q.z, q.w);
+#else
+                    v[i] = *(const uint4 *)(base + ((ch + i) << 12));
+#endif
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
