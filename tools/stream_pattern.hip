@@ -46,6 +46,39 @@ __global__ __launch_bounds__(kWaves * 64) void k_stream(const char *in, char *ou
     if (acc.w == 0x12345678u) out[0] = 1;
 }
 
+// the same with TWO tiles in flight per wave (6 KB): is mode 0 bound by bytes in flight or by the memory side?
+__global__ __launch_bounds__(kWaves * 64) void k_stream2(const char *in, char *out, int64_t n_tiles, int mode, int64_t total_waves)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * kWaves + wave;
+    const bool wr = !(mode & 4);
+    const int64_t q = n_tiles / total_waves, t0 = gw * q, t1 = t0 + q;
+    uint4 a[3], b[3], acc = make_uint4(0, 0, 0, 0);
+    const char *p = in + t0 * kTileB + lane * 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] = *(const uint4 *)(p + c * 1024); b[c] = *(const uint4 *)(p + kTileB + c * 1024); }
+    for (int64_t t = t0; t < t1; t += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 (&cur)[3] = h ? b : a;
+            uint4 v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = cur[c];
+            const int64_t tn = t + h + 2 < t1 ? t + h + 2 : t + h;
+            p = in + tn * kTileB + lane * 16;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cur[c] = *(const uint4 *)(p + c * 1024);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { acc.x += v[c].x; acc.y ^= v[c].y; acc.z += v[c].z; acc.w ^= v[c].w; }
+            if (wr) {
+                typedef uint32_t u3 __attribute__((ext_vector_type(3), aligned(4)));
+                *(u3 *)(out + (t + h) * 768 + lane * 12) = u3{acc.x, acc.y, acc.z};
+            }
+        }
+    }
+    if (acc.w == 0x12345678u) out[0] = 1;
+}
+
 int main(int argc, char **argv)
 {
     const int lg = argc > 1 ? atoi(argv[1]) : 28;
@@ -67,6 +100,17 @@ int main(int argc, char **argv)
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         const double rd = (double)n_tiles * kTileB, wrb = (mode & 4) ? 0.0 : (double)n_tiles * 768;
         printf("mode %d: %.4f ms  read %.2f TB/s  read+write %.2f TB/s\n", mode, ms, rd / ms / 1e9, (rd + wrb) / ms / 1e9);
+    }
+    for (int mode : {0, 4}) {
+        for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_stream2, dim3(cus), dim3(kWaves * 64), 0, 0, in, out, n_tiles, mode, total_waves);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        const int reps = 40;
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream2, dim3(cus), dim3(kWaves * 64), 0, 0, in, out, n_tiles, mode, total_waves);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        const double rd = (double)n_tiles * kTileB, wrb = (mode & 4) ? 0.0 : (double)n_tiles * 768;
+        printf("two tiles in flight, mode %d: %.4f ms  read %.2f TB/s  read+write %.2f TB/s\n", mode, ms, rd / ms / 1e9, (rd + wrb) / ms / 1e9);
     }
     return 0;
 }
