@@ -183,6 +183,50 @@ def test_hand_written_asm_static_check():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def _gather_model(step, nl, fold):
+    """numpy restatement of tap_gather_cycles (front_mid.hip): cycles per 8-byte tap read of a half-wave = the fullest of the 32
+    bank pairs, counted in distinct entries"""
+    ns = 4 if nl == 6 else 5
+    lo = [(step * j) >> 24 for j in range(5)]
+    total = reads = 0
+    for t in range(48):
+        base = 64 * nl * t * 7
+        lanes = np.arange(64, dtype=np.int64)
+        g = (base + nl * lanes) << 24
+        k = (g + step - 1) // step
+        P = (k * step - g).astype(np.int64)
+        for j in range(ns):
+            Pj = (P + j * step) & 0xFFFFFFFF
+            x = Pj >> 16
+            if fold:
+                x = x ^ ((Pj >> 21) & 7)
+            e = (x + (Pj >> 24) - 257 * lo[j]) & 0xFFFFFFFF
+            for h in (slice(0, 32), slice(32, 64)):
+                total += int(np.bincount(np.unique(e[h]) & 31, minlength=32).max())
+            reads += 1
+    return total / reads
+
+
+@pytest.mark.parametrize("step_over_2_24,nl", [(27053208 / 2 ** 24, 6), (27053208 / 2 ** 24, 8), (1.625, 6), (1.75, 6), (1.5, 6), (1.724, 6),
+                                               (1.9967, 6), (1.579, 6), (1.8, 8), (1.923, 8)])
+def test_tap_placement_chooser_follows_its_bank_model(lib, step_over_2_24, nl):
+    """front_tap_fold (front_mid.hip): the arms of the polyphase table sit in the tap planes in order unless the folded placement
+    saves more than 1.5 modelled LDS cycles per tap read for the chain's step -- checked against a numpy restatement of the model,
+    and on the two cases the design notes quote (NRSC-5: in order at 6 per lane, folded at 8)."""
+    from iq_tool_amd import _lib
+    so = C.CDLL(_lib.LIB_PATH)
+    f = getattr(so, "_ZN5iqgpu14front_tap_foldEji")
+    f.argtypes = [C.c_uint32, C.c_int]; f.restype = C.c_int
+    step = int(round(step_over_2_24 * 2 ** 24))
+    plain, folded = _gather_model(step, nl, False), _gather_model(step, nl, True)
+    want = 1 if folded + 1.5 < plain else 0
+    assert f(step, nl) == want, (plain, folded)
+    if step == 27053208:
+        assert want == (0 if nl == 6 else 1)
+    if step_over_2_24 == 1.625:
+        assert want == 1 and plain > 12 and folded < 5
+
+
 def test_next_out_frames_closed_form_matches_oracle_counts(oracle):
     """the count law the host uses: K(Q) = ceil(Q 2^24 / step), Q = floor(N / 2^S)"""
     r = np.float32(744187.5 / 2.4e6)
