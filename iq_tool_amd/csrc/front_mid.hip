@@ -82,6 +82,8 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     constexpr int NS = G::NS;
     constexpr bool kLean = kMidWaves > 12 || NL == 8;       // (8 per lane at 3 waves per SIMD: 168 VGPRs leave no room to fetch a phase ahead)
     constexpr int LO[5] = {0, 1, 3, L3, L4};
+    constexpr bool EDGE = false;                             // (for CLOCK_END: the diagnostic -DIQGPU_CLOCKSTAMP build, tools/clock.py)
+    CLOCK_BEGIN;
     auto addr_rt = [](int rc) { return NL == 6 ? 8 * rc : (rc >> 3) * 80 + (rc & 7) * 8; };
     char *XE = w.XE, *HB = w.XE;
     const uint32_t step = a.step;
@@ -384,6 +386,8 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         const double m = (double)wave_max_f(agc_m0);
         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
     }
+    CLOCK_END(a.sink);
+    (void)EDGE;
 #undef FENCE
 }
 
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
-        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        const int64_t t0 = w_run_start_weighted(a, r), t1 = w_run_start_weighted(a, r + 1);
         MidLds w;
         w.XE = slice; w.nco = s_nco;
         w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;

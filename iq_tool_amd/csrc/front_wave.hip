@@ -251,6 +251,7 @@ void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_til
     }
     a.w_warm_tiles = warm_tiles;
     a.w_edge_tpw = edge_tpw;
+    a.w_wsum = 0; a.w_wpw = 0;                       // equal runs unless the caller weights them afterwards (weight_runs)
     int64_t ta = total, tb = total;
     // (cs24 output takes six byte stores per frame: the streaming loop counts on one)
     if (vb != 0 && a.out_fmt != IQGPU_FMT_CS24 && a.raw_aligned && (((int64_t)a.rem0 * vb) & 15) == 0) {

@@ -177,6 +177,7 @@ struct iqgpu_chain {
     bool poisoned = false;        // a call failed after device state had been touched: reset() clears it
     bool force_generic = false;   // IQGPU_FORCE_GENERIC=1: always use the workgroup-tiled k_front
     uint32_t dbg = 0;             // kDbg* diagnostic switches, read from the environment once at create
+    int32_t run_wt[4] = {1300, 1000, 700, 0};      // weights of the runs of the first / second / third wave of a SIMD in k_front_mid (IQGPU_RUN_WEIGHTS=a,b,c; 0 = equal runs)
     int tap_fold6 = 0, tap_fold8 = 0, tap_fold_env = -1;    // placement of the arms in the tap planes of k_front_mid / k_front_fat for this chain's step (front_tap_fold); IQGPU_TAP_FOLD=0|1 overrides
     // profiling
     bool profiling = false;
@@ -289,6 +290,7 @@ static int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
                  (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8") ? kDbgMid8 : 0u);
         if (const char *tf = getenv("IQGPU_TAP_FOLD")) c->tap_fold_env = atoi(tf) != 0 ? 1 : 0;
+        if (const char *rw = getenv("IQGPU_RUN_WEIGHTS")) { int x = 0, y = 0, z = 0; if (sscanf(rw, "%d,%d,%d", &x, &y, &z) == 3 && x >= 0 && y >= 0 && z >= 0) { c->run_wt[0] = x; c->run_wt[1] = y; c->run_wt[2] = z; } }
     }
 
     // ---- ratio (src/setup.c:91-122) ----
@@ -803,6 +805,8 @@ struct Call {
         dst.w_n_stream = cplan.w_n_stream; dst.w_run_q = cplan.w_run_q; dst.w_run_r = cplan.w_run_r;
         dst.w_edge_ta = cplan.w_edge_ta; dst.w_edge_tb = cplan.w_edge_tb;
         dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
+        dst.w_wpw = cplan.w_wpw; dst.w_wsum = cplan.w_wsum;
+        for (int i = 0; i < 4; ++i) dst.w_wt[i] = cplan.w_wt[i];
     }
     int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
     // the per-chunk peaks a fused front launch accumulates into start from zero: k_agc_verify zeroes what it has read, so only
@@ -891,6 +895,8 @@ void Call::plan_geometry()
         if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
         plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves() : front_s1_waves(cplan)),
                       ftpw, warm, mid_align, wtile, mid_align, mid ? kMidLead : 0);
+        // k_front_mid: the three waves of a SIMD get runs in proportion to the speed their age buys them (kernels.hpp, weight_runs)
+        if (mid && ftpw == 0 && cplan.w_n_edge <= front_mid_max_edge_waves() && c->run_wt[0] > 0) weight_runs(cplan, front_mid_waves(), c->run_wt);
         if (mid && cplan.w_n_edge > front_mid_max_edge_waves()) {
             // (an unaligned buffer, a call that is all edges: k_front_mid keeps LDS for a handful of edge waves only)
             mid = false; wtile = kWTile;

@@ -116,6 +116,14 @@ struct FrontArgs {
     // streaming runs: run w (0 <= w < w_n_stream) covers tiles [w_run_start(w), w_run_start(w + 1)) of
     // [w_edge_ta, w_edge_tb): w_run_q tiles each, one more for the first w_run_r runs
     int64_t     w_n_stream, w_run_q, w_run_r;
+    // ... or, with w_wsum != 0, runs WEIGHTED by the wave's slot in its workgroup: global wave g (edge runs first) sits in slot
+    // g % w_wpw, slots come in classes of four (the first / second / third wave of each SIMD) and class c weighs w_wt[c].  The
+    // oldest wave of a SIMD wins every arbitration: of three equal runs it finishes the first at 260 us, the second at 312, the
+    // third at 357 (profiles/r03_wave_timeline.txt), and the SIMD spends the last quarter of the launch with one or two waves.
+    // Runs of 1.3 : 1 : 0.7 bring the three ends within 15 % of each other (more skew turns the order around): -2 % of kernel time.
+    // w_wsum = the weight of all streaming waves.
+    int32_t     w_wpw, w_wt[4];
+    int64_t     w_wsum;
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
@@ -144,9 +152,43 @@ struct FrontArgs {
     void       *out;
 };
 
+// weight of the global waves [0, g) of a launch with wpw waves per workgroup (slot classes of four: the first / second / ... wave
+// of each SIMD)
+IQGPU_HD inline int64_t w_cum_weight(const int32_t *wt, int wpw, int64_t g)
+{
+    const int nc = wpw / 4;
+    int64_t per = 0;
+    for (int c = 0; c < nc; ++c) per += 4 * (int64_t)wt[c];
+    const int64_t b = g / wpw;
+    int64_t s = g % wpw, cw = b * per;
+    for (int c = 0; c < nc; ++c) { const int64_t n = s < 4 ? s : 4; cw += n * wt[c]; s -= n; }
+    return cw;
+}
 IQGPU_HD inline int64_t w_run_start(const FrontArgs &a, int64_t w)
 {
     return a.w_edge_ta + w * a.w_run_q + (w < a.w_run_r ? w : a.w_run_r);
+}
+// ... of a launch whose plan may be weighted (k_front_mid only: the 64-bit division below costs the other kernels registers they
+// do not have -- with it inlined the last-stage instantiation of k_front_s1 spilled 968 bytes and ran at half its speed)
+IQGPU_HD inline int64_t w_run_start_weighted(const FrontArgs &a, int64_t w)
+{
+    if (a.w_wsum != 0) {
+        if (w >= a.w_n_stream) return a.w_edge_tb;
+        const int64_t cw = w_cum_weight(a.w_wt, a.w_wpw, w + a.w_n_edge) - w_cum_weight(a.w_wt, a.w_wpw, a.w_n_edge);
+        return a.w_edge_ta + cw * (a.w_edge_tb - a.w_edge_ta) / a.w_wsum;
+    }
+    return w_run_start(a, w);
+}
+// switches a plan (plan_front_s1) to weighted runs; wt[c] > 0 for the wpw / 4 slot classes.  Every run keeps at least two tiles.
+inline void weight_runs(FrontArgs &a, int wpw, const int32_t *wt)
+{
+    a.w_wsum = 0;
+    if (a.w_n_stream < 16 * wpw || wpw % 4 != 0 || wpw > 16) return;
+    int32_t lo = wt[0], hi = wt[0];
+    for (int c = 0; c < wpw / 4; ++c) { a.w_wt[c] = wt[c]; if (wt[c] < lo) lo = wt[c]; if (wt[c] > hi) hi = wt[c]; }
+    if (lo <= 0 || (a.w_edge_tb - a.w_edge_ta) / a.w_n_stream * lo / hi < 2) return;      // (short runs: leave them equal)
+    a.w_wpw = wpw;
+    a.w_wsum = w_cum_weight(a.w_wt, wpw, a.w_n_stream + a.w_n_edge) - w_cum_weight(a.w_wt, wpw, a.w_n_edge);
 }
 
 size_t front_lds_bytes(const FrontArgs &a);

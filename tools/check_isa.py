@@ -135,9 +135,41 @@ def check_fat_mid(src, kernel, max_vgpr):
     return errors
 
 
+# the instantiations the bench configs run, with the register budget of their launch bounds: a spill in one of them halves its speed
+# without failing a single parity test (round 3: a 64-bit division inlined into every kernel's prologue cost the last-stage
+# instantiation 968 bytes of scratch and config 3 a quarter of its throughput before a profile showed it)
+HOT = {
+    "front_wave.hip": [("_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0ELi0EEEvNS_9FrontArgsE", 128),      # headline fallback (16 waves)
+                       ("_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0ELi1EEEvNS_9FrontArgsE", 128),      # ... without a mixer
+                       ("_ZN5iqgpu10k_front_s1ILi8ELb0ELb0ELb0ELi4EEEvNS_9FrontArgsE", 128),      # last stage behind k_cascade (configs 3, 4)
+                       ("_ZN5iqgpu10k_front_s1ILi2ELb0ELb1ELb0ELi2EEEvNS_9FrontArgsE", 128),      # cu8-nrsc5 preset shapes
+                       ("_ZN5iqgpu10k_front_s1ILi4ELb0ELb1ELb0ELi3EEEvNS_9FrontArgsE", 128)],
+    "cascade_wave.hip": [("_ZN5iqgpu9k_cascadeILi4ELb0ELi1EEEvNS_9FrontArgsE", 168),               # config 3 (12 waves)
+                         ("_ZN5iqgpu9k_cascadeILi2ELb1ELi4EEEvNS_9FrontArgsE", 128)],              # config 4 (16 waves)
+}
+
+
+def check_hot(lines_by_src):
+    errors = []
+    for src, kernels in HOT.items():
+        text = "\n".join(lines_by_src[src])
+        for name, max_vgpr in kernels:
+            m = re.search(r"\.amdhsa_kernel %s\n(.*?)\.end_amdhsa_kernel" % re.escape(name), text, re.S)
+            if not m:
+                errors.append("%s: no instantiation %s" % (src, name)); continue
+            v = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(1)).group(1))
+            sc = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(1)).group(1))
+            if sc != 0:
+                errors.append("%s: %s spills %d bytes to scratch" % (src, name, sc))
+            if v > max_vgpr:
+                errors.append("%s: %s needs %d VGPRs (budget %d)" % (src, name, v, max_vgpr))
+    return errors
+
+
 def main():
     lines = compile_isa()
     errors, n = check(lines)
+    errors += check_hot({"front_wave.hip": lines, "cascade_wave.hip": compile_isa(SRC_CASC)})
     errors += check_no_read2_b32(lines, "front_wave.hip")
     errors += check_no_read2_b32(compile_isa(SRC_CASC), "cascade_wave.hip")
     errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_mid.hip"), "k_front_mid", 168)

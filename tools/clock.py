@@ -68,10 +68,24 @@ for x in range(8):
     if m.any():
         print("  XCD %d: %4d waves, start p50 %.1f, end p50 %.1f max %.1f, run p50 %.1f max %.1f us"
               % (x, m.sum(), np.median(s_us[m]), np.median(e_us[m]), e_us[m].max(), np.median((e_us - s_us)[m]), (e_us - s_us)[m].max()))
+# per wave slot of a workgroup (WPW = IQGPU_CLOCK_WPW waves per workgroup: 12 for k_front_mid, 16 for k_front_s1): is the spread systematic?
+WPW = int(os.environ.get("IQGPU_CLOCK_WPW", "12"))
+idx_all = np.nonzero(ok)[0]
+slot = idx_all % WPW
+print("per wave slot (end time, us): " + "  ".join("%d: p50 %.0f p95 %.0f" % (k, *np.percentile(e_us[(slot == k) & ~edge], [50, 95])) for k in range(WPW) if ((slot == k) & ~edge).any()))
+wg = idx_all // WPW
+within = []
+for g in np.unique(wg):
+    m = (wg == g) & ~edge
+    if m.sum() >= 2:
+        within.append((e_us[m].min(), np.median(e_us[m]), e_us[m].max()))
+within = np.array(within)
+print("within a workgroup: first wave ends p50 %.1f, median wave p50 %.1f, last wave p50 %.1f us; last - first p50 %.1f p95 %.1f us"
+      % (np.median(within[:, 0]), np.median(within[:, 1]), np.median(within[:, 2]), *np.percentile(within[:, 2] - within[:, 0], [50, 95])))
 # per workgroup (16 consecutive waves share a CU): spread of workgroup end times
 idx = np.nonzero(ok)[0]
 wg_end = {}
 for i, e in zip(idx, e_us):
-    wg_end.setdefault(i // 16, []).append(e)
+    wg_end.setdefault(i // WPW, []).append(e)
 ends = np.array([max(v) for v in wg_end.values()])
 print("workgroups: %d, end time min %.1f p50 %.1f p95 %.1f max %.1f us" % (len(ends), ends.min(), *np.percentile(ends, [50, 95]), ends.max()))
