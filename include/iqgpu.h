@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IQGPU_ABI_VERSION 3
+#define IQGPU_ABI_VERSION 4
 
 /* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
 enum {
@@ -144,6 +144,9 @@ typedef struct {
 int         iqgpu_abi_version(void);
 const char *iqgpu_last_error(void);              /* thread-local message of the last failure        */
 int         iqgpu_device_count(void);            /* number of HIP devices, 0 if none / no runtime   */
+/* PCI bus id ("0000:05:00.0") of device `ordinal` (hipDeviceGetPCIBusId): what a multi-GPU launcher logs to show that its
+ * ranks sit on distinct devices (bench.py `config.devices`; the reference has no counterpart: it runs on the host) */
+int         iqgpu_device_pci_bus_id(int ordinal, char *buf, size_t cap);
 
 /* ---- chain lifecycle: replaces _create_dsp_components/_destroy_dsp_components (src/pipeline.c:138-157) ---- */
 void   iqgpu_chain_desc_init(iqgpu_chain_desc *d);                 /* reference defaults: gain 1, cs16->cs16, no ops */
@@ -270,6 +273,9 @@ void  *iqgpu_chain_get_stream(const iqgpu_chain *c);
 int    iqgpu_chain_synchronize(iqgpu_chain *c);
 int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets every launch with HIP events  */
 int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
+/* name of the front kernel the LAST process call launched ("k_front_mid<6,nco>", "k_front_s1", "k_front_fat",
+ * "k_cascade+k_front_s1", "k_front", "k_front+k_interp"; "" before the first call): diagnostics, bench.py's roofline.kernel */
+const char *iqgpu_chain_front_kernel(const iqgpu_chain *c);
 
 /* diagnostic hook: copies the chain's 64 KiB scratch (per-phase cycle counters in builds
  * made with -DIQGPU_STAMPS) to the host and clears it */

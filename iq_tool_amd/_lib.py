@@ -90,6 +90,7 @@ SYMBOLS = [
     ("iqgpu_abi_version", C.c_int, []),
     ("iqgpu_last_error", C.c_char_p, []),
     ("iqgpu_device_count", C.c_int, []),
+    ("iqgpu_device_pci_bus_id", C.c_int, [C.c_int, C.c_char_p, _sz]),
     ("iqgpu_chain_desc_init", None, [C.POINTER(ChainDesc)]),
     ("iqgpu_chain_create", C.c_int, [C.POINTER(ChainDesc), C.POINTER(_vp)]),
     ("iqgpu_chain_destroy", None, [_vp]),
@@ -130,6 +131,7 @@ SYMBOLS = [
     ("iqgpu_chain_synchronize", C.c_int, [_vp]),
     ("iqgpu_chain_set_profiling", C.c_int, [_vp, C.c_int]),
     ("iqgpu_chain_get_profile", C.c_int, [_vp, C.POINTER(Profile)]),
+    ("iqgpu_chain_front_kernel", C.c_char_p, [_vp]),
     ("iqgpu_chain_debug_read_scratch", C.c_int, [_vp, _vp]),
     ("iqgpu_get_bytes_per_sample", _sz, [C.c_int]),
     ("iqgpu_convert_block_to_cf32", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_float, C.c_int]),

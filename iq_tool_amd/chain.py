@@ -201,6 +201,10 @@ class Chain:
     def set_profiling(self, on=True):
         check(self._lib.iqgpu_chain_set_profiling(self._h, int(on)))
 
+    def front_kernel(self):
+        """name of the front kernel the last process call launched (iqgpu_chain_front_kernel)"""
+        return self._lib.iqgpu_chain_front_kernel(self._h).decode()
+
     def profile(self):
         p = Profile()
         check(self._lib.iqgpu_chain_get_profile(self._h, C.byref(p)))

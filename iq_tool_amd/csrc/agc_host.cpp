@@ -1,0 +1,110 @@
+// agc_host.cpp -- host side of the output AGC (src/agc.c, src/post_processor.c:55-57): the chunk map of a call, which part of it
+// runs fused in the front kernel, the verifier and the conditional fallback launches behind a fused launch.
+#include "chain.hpp"
+
+// output AGC: agc_apply per reference chunk (src/post_processor.c:55-57)
+AgcGeom Call::agc_geom() const
+{
+    AgcGeom g{};
+    g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
+    g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
+    g.mode = c->late ? 2 : (c->decim ? 1 : 0);
+    g.rem = c->rem; g.S = c->late ? c->ia.S : c->S; g.phi = c->phi; g.step = c->rp.step;
+    g.block = (filt && c->fp.block) ? c->fp.block : 0; g.fpending = fpending0;
+    return g;
+}
+
+AgcArgs Call::agc_args() const
+{
+    AgcArgs ga{};
+    ga.geom = agc_geom();
+    const AgcGeom &g = ga.geom;
+    ga.x = (const cf2 *)c->abuf.p; ga.n_out = p.n_emit;
+    ga.peak2 = (unsigned long long *)c->agc_peak.p; ga.gain = (float *)c->agc_gain.p;
+    ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
+    ga.target = c->agc_target; ga.rate = c->target_rate;
+    ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
+    ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;
+    const int64_t avg = p.n_emit / g.n_chunks + 1;
+    int64_t splits = (avg + 16383) / 16384; if (splits > 1024) splits = 1024;
+    ga.splits = (int)splits;
+    ga.out_fmt = c->desc.out_format; ga.out = d_out;
+    return ga;
+}
+
+int Call::stage_agc()
+{
+    if (c->agc_rms_alpha > 0.0f) {
+        AgcRmsArgs ra{};
+        ra.x = (const cf2 *)c->abuf.p; ra.n = p.n_emit; ra.alpha = c->agc_rms_alpha; ra.state = c->d_agc_state;
+        agc_rms_geometry(ra.alpha, ra.n, &ra.chunk, &ra.warm, &ra.n_chunks);
+        int rc = c->agc_gain.ensure((size_t)(ra.n_chunks > 0 ? ra.n_chunks : 1) * 4 * sizeof(float)); if (rc) return rc;
+        ra.st = (float *)c->agc_gain.p;
+        ra.out_fmt = c->desc.out_format; ra.out = d_out;
+        KernelTimer kt(c, IQGPU_K_AGC);
+        HIP_TRY(launch_agc_rms(ra, c->stream));
+        return IQGPU_OK;
+    }
+    const AgcArgs ga = agc_args();
+    KernelTimer kt(c, IQGPU_K_AGC);
+    c->agc_peak_clean = false;                       // (k_agc_peak leaves its maxima in agc_peak)
+    HIP_TRY(launch_agc(ga, c->stream));
+    return IQGPU_OK;
+}
+
+// behind a fused front launch: the verifier, then the unfused kernels as launches that do nothing unless the
+// verifier raised its flag (same input, same history buffers, the untouched AGC state)
+int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
+{
+    AgcArgs va = agc_args();
+    va.verify_flag = c->d_agc_flag;
+    va.peak_approx = mid ? 1 : 0;
+    va.peak2_fallback = (unsigned long long *)c->agc_peak_b.p;
+    KernelTimer kt(c, IQGPU_K_AGC);
+    HIP_TRY(launch_agc_verify(va, c->stream));
+    FrontArgs fb = spec;
+    fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr; fb.w_steal = nullptr;
+    fb.out_fmt = IQGPU_FMT_CF32; fb.out = c->abuf.p;
+    fb.run_if = c->d_agc_flag;
+    if (fat || mid) {
+        // the fused launch ran on k_front_fat / k_front_mid with its own tile geometry: the fallback is k_front_s1's (512-frame tiles)
+        fb.w_total_tiles = ((int64_t)fb.rem0 + fb.frames_in + kWTile - 1) / kWTile;
+        int warm = (int)((c->rp.history_in + kWTile - 1) / kWTile);
+        if (warm < 1) warm = 1;
+        plan_front_s1(fb, wave_slots(front_s1_waves(fb)), fixed_tpw(), warm, 1, kWTile);
+    }
+    HIP_TRY(launch_front_s1(fb, c->stream));
+    AgcArgs ga = va;
+    ga.peak2_fallback = nullptr;
+    ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
+    ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
+    HIP_TRY(launch_agc(ga, c->stream));
+    return IQGPU_OK;
+}
+
+// first frame count (a multiple of the AGC chunk, or the whole call) that must take the unfused AGC path: everything
+// while the stream has not locked.  agc_apply locks on the first chunk that STARTS after AGC_DIGITAL_LOCK_TIME of
+// output (src/agc.c:151-155: elapsed = samples_seen / rate before this chunk is counted), a closed form of the
+// stream position; sets *locks when that chunk lies in this call.
+size_t agc_unfused_head(const iqgpu_chain *c, size_t frames_in, bool *locks)
+{
+    *locks = false;
+    if (c->agc_locked_host) return 0;
+    AgcGeom g{};
+    g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
+    g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
+    g.mode = 1; g.rem = c->rem; g.S = c->S; g.phi = c->phi; g.step = c->rp.step;
+    int64_t lo = 0, hi = g.n_chunks;                        // first chunk whose start time exceeds the lock time
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        const uint64_t seen = c->agc_seen_host + (uint64_t)agc_out_end(g, mid - 1);
+        if ((double)seen / c->target_rate > (double)2.0f) hi = mid; else lo = mid + 1;
+    }
+    // (empty chunks never reach agc_apply; a decimating chain with chunks of at least a tile has none but a possible
+    //  first one, which the search passes over because its successor starts at the same time)
+    while (lo < g.n_chunks && agc_out_end(g, lo) == agc_out_end(g, lo - 1)) ++lo;
+    if (lo >= g.n_chunks) return frames_in;
+    *locks = true;
+    const int64_t head = (lo + 1) * c->agc_chunk;
+    return head < (int64_t)frames_in ? (size_t)head : frames_in;
+}

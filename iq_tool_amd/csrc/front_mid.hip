@@ -74,19 +74,20 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
 // (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
 // L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
+// Run stealing (kernels.hpp): the run's end is whatever the wave's descriptor `desc` says when a tile is claimed -- one returning
+// agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
 template <int NL, bool NONCO, int L3, int L4, bool AGC>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
-                                        const int64_t T_begin, const int64_t T_emit0, const int64_t T_emit1)
+                                        const int64_t T_begin, const int64_t T_emit0, int64_t T_emit1, unsigned long long *const desc)
 {
     typedef MidGeom<NL> G;
     constexpr int NS = G::NS;
     constexpr bool kLean = kMidWaves > 12 || NL == 8;       // (8 per lane at 3 waves per SIMD: 168 VGPRs leave no room to fetch a phase ahead)
     constexpr int LO[5] = {0, 1, 3, L3, L4};
-    constexpr bool EDGE = false;                             // (for CLOCK_END: the diagnostic -DIQGPU_CLOCKSTAMP build, tools/clock.py)
-    CLOCK_BEGIN;
     auto addr_rt = [](int rc) { return NL == 6 ? 8 * rc : (rc >> 3) * 80 + (rc & 7) * 8; };
     char *XE = w.XE, *HB = w.XE;
-    const uint32_t step = a.step;
+    uint32_t step = a.step;
+    asm volatile("" : "+s"(step));                    // (opaque per run: the reciprocals of the prologue's divisions are not held across the caller's loop)
     float hb[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) hb[k] = a.hb0[k];
@@ -96,7 +97,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     uint64_t k_tile0 = first_k_at((uint64_t)T_emit0 * SPAN, a.phi0, step);
     uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - (uint64_t)T_emit0 * SPAN);            // < step
     const uint32_t n_est = (uint32_t)(SPAN / step);                      // outputs of a tile: n_est or n_est + 1
-    const uint64_t c_est = (uint64_t)n_est * step;
+    const uint32_t span_rem = (uint32_t)(SPAN - (uint64_t)n_est * step);   // < step: a tile holds n_est + 1 outputs iff its first one starts below this
     uint32_t n0, Pl;                                   // the lane's first output of the tile: index in the tile, phase from sample 6 lane
     {
         const uint64_t tgt = (uint64_t)(NL * lane) << 24;
@@ -263,9 +264,10 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         if constexpr (NS == 4) *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
         else *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
         if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 4 * (NS - 1)) = pk[NS - 1];
-        const uint32_t nt = n_est + (((uint64_t)delta0 + c_est) < SPAN ? 1u : 0u);
-        k_tile0 += nt;
-        const int32_t e = (int32_t)((int64_t)((uint64_t)nt * step) - (int64_t)SPAN);           // |e| < step
+        // (all in 32 bits: delta0 + n_est step < SPAN <=> delta0 < span_rem, and nt step - SPAN is step - span_rem or -span_rem)
+        const bool more = delta0 < span_rem;
+        k_tile0 += n_est + (more ? 1u : 0u);
+        const int32_t e = more ? (int32_t)(step - span_rem) : -(int32_t)span_rem;               // |e| < step
         delta0 = (uint32_t)((int32_t)delta0 + e);
         int32_t pl = (int32_t)Pl + e;
         if (pl < 0) { pl += (int32_t)step; n0 += 1u; }
@@ -370,9 +372,20 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         L_hb(next_pp); FENCE();
         __builtin_amdgcn_s_setprio(0);
     };
+    // claim(): next += 1 in the wave's descriptor (lane 0); claimed_end(): the `end` that add saw.  A thief only ever lowers `end`
+    // to a tile behind the one being claimed (steal_run), so the tile in hand always stays this wave's.
+    unsigned long long cv = 0;
+    auto claim = [&]() { if (lane == 0) cv = __hip_atomic_fetch_add(desc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto claimed_end = [&]() { return a.w_edge_ta + (int64_t)__builtin_amdgcn_readfirstlane((int)(cv >> 32)); };
     for (int64_t T = T_begin; T < T_emit0; ++T) tile(T, false, false);     // warm-up tiles
+    claim();
     tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
-    for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) tile(T, true, true);    // steady state
+    T_emit1 = claimed_end();
+    for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) {                       // steady state
+        claim();
+        tile(T, true, true);
+        T_emit1 = claimed_end();
+    }
     // the last tile's polyphase
     if (kLean) V_pp_lean();
     else {
@@ -386,9 +399,63 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         const double m = (double)wave_max_f(agc_m0);
         if (lane == 0 && m > 0.0) atomicMax(a.agc_peak2 + agc_c, (unsigned long long)__double_as_longlong(m));
     }
-    CLOCK_END(a.sink);
-    (void)EDGE;
 #undef FENCE
+}
+
+// A wave out of tiles looks for more: every lane loads one descriptor (64 of the launch's, spread evenly over its workgroups and so
+// over the XCDs, a different set every round), the lane that saw the longest unclaimed run halves it -- compare-and-swap on the
+// whole {end | next} word, retried on the value that comes back while the owner's claims keep moving `next` -- and the wave takes
+// tiles [mid, end) with mid = next + ceil(rem / 2) >= next + 1: the owner is at most in tile next - 1 and about to claim `next`,
+// which stays its own.  The taken run is published in the wave's own descriptor, so it can be split again.  Bounded: w_steal_rounds
+// samples without a run of w_steal_min tiles anywhere and the wave retires.
+__device__ __forceinline__ bool steal_run(const FrontArgs &a, const int64_t gw, const int lane, int64_t &t0, int64_t &t1)
+{
+    unsigned long long *const D = a.w_steal;
+    const int n = (int)(a.w_n_edge + a.w_n_stream);
+    const int stride = n / a.w_steal_lanes;                             // (n >= 64 >= lanes: the host leaves short launches static)
+    for (int round = 0; round < a.w_steal_rounds; ++round) {
+        const int v = (int)((gw + 1 + (int64_t)lane * stride + (int64_t)round * 17) % n);
+        unsigned long long *const Dv = D + (size_t)v * (size_t)a.w_steal_stride;
+        // (a read-modify-write, not a load: atomics execute at the memory side, while an sc1 load may be served by this XCD's L2
+        //  with what the line held a launch ago -- the L2s of different XCDs are not coherent -- and an exhausted descriptor hides
+        //  the run; adding a zero the compiler cannot see through: it turns an idempotent read-modify-write back into that load)
+        unsigned long long cur = 0, zero = 0;
+        asm volatile("" : "+v"(zero));
+        if (lane < a.w_steal_lanes) cur = __hip_atomic_fetch_add(Dv, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t rem = (int32_t)(uint32_t)(cur >> 32) - (int32_t)(uint32_t)cur;
+        uint32_t best = rem >= a.w_steal_min ? ((uint32_t)rem << 6) | (uint32_t)lane : 0u;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, k); best = o > best ? o : best; }
+        best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);     // (every lane holds the maximum: tell the compiler it is uniform)
+        if (best == 0u) continue;
+        const int win = (int)(best & 63u);
+        int32_t got_mid = -1, got_end = 0;
+        if (lane == win) {
+            for (int tries = 0; tries < 4; ++tries) {
+                const int32_t e = (int32_t)(uint32_t)(cur >> 32), p = (int32_t)(uint32_t)cur;
+                if (e - p < a.w_steal_min) break;
+                const int32_t mid = p + ((e - p + 1) >> 1);
+                const unsigned long long nd = ((unsigned long long)(uint32_t)mid << 32) | (unsigned long long)(uint32_t)p;
+                if (__hip_atomic_compare_exchange_strong(Dv, &cur, nd, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    got_mid = mid; got_end = e;
+                    break;
+                }
+            }
+        }
+        got_mid = __builtin_amdgcn_readfirstlane(__shfl(got_mid, win)); got_end = __builtin_amdgcn_readfirstlane(__shfl(got_end, win));
+        if (got_mid < 0) continue;
+        // (pinned to SGPRs: hipcc otherwise sinks their widening into both arms of the branch below, and the join of a divergent
+        //  branch counts as divergent -- the whole tile loop then runs on vector compares and EXEC masks)
+        asm volatile("" : "+s"(got_mid), "+s"(got_end));
+        if (lane == 0) {
+            __hip_atomic_store(D + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)got_end << 32) | (unsigned long long)(uint32_t)got_mid,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd((unsigned long long *)((char *)a.sink + 32768 + 128) + 3, 1ull);      // runs taken, over the chain's life (iqgpu_chain_debug_read_scratch)
+        }
+        t0 = a.w_edge_ta + got_mid; t1 = a.w_edge_ta + got_end;
+        return true;
+    }
+    return false;
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
@@ -431,28 +498,52 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         const int keep_n = a.hist_cap - (int)a.frames_in;
         for (int i = lane; i < keep_n; i += 64) a.hist_out[i] = a.hist_in[i + (int)a.frames_in];
     }
+    constexpr bool EDGE = false;                      // (for CLOCK_END: the diagnostic -DIQGPU_CLOCKSTAMP build, tools/clock.py)
+    CLOCK_BEGIN;
+    int64_t t0 = 0, t1 = 0;
+    bool have = false;
     if (gw < a.w_n_edge) {
         // edge work in tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) of G::TILE frames, runs of w_edge_tpw of them (768-frame
         // tiles: two, from an even tile = three 512-frame tiles of run_tiles; 1024-frame tiles: one = two of them)
-        int64_t t0, t1;
-        if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
-        else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        int64_t e0, e1;
+        if (gw < a.w_n_edge1) { e0 = gw * a.w_edge_tpw; e1 = e0 + a.w_edge_tpw; if (e1 > a.w_edge_ta) e1 = a.w_edge_ta; }
+        else { e0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; e1 = e0 + a.w_edge_tpw; if (e1 > a.w_total_tiles) e1 = a.w_total_tiles; }
         if (gw >= kMidEdgeMax) __builtin_trap();     // (the host keeps launches with more edge runs on k_front_s1)
         WaveLds w;
         w.XE = arena + (int)gw * kWaveLds; w.XO = w.XE + kXRows * kRowB; w.HB = w.XO + kHBOff * kRowB;
         w.nco = s_nco; w.arb = s_arb;
         w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
-        const int64_t o0 = t0 * G::TILE / 512, o1 = (t1 * G::TILE + 511) / 512;
+        const int64_t o0 = e0 * G::TILE / 512, o1 = (e1 * G::TILE + 511) / 512;
         run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
-        const int64_t t0 = w_run_start_weighted(a, r), t1 = w_run_start_weighted(a, r + 1);
-        MidLds w;
-        w.XE = slice; w.nco = s_nco;
-        w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_mid<NL, NONCO, L3, L4, AGC>(a, w, lane, t0 - a.w_warm_tiles, t0, t1);
+        t0 = w_run_start_weighted(a, r); t1 = w_run_start_weighted(a, r + 1);
+        have = true;
+        if (lane == 0)                               // the static run, open to thieves from here on
+            __hip_atomic_store(a.w_steal + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)(t1 - a.w_edge_ta) << 32) | (unsigned long long)(uint32_t)(t0 - a.w_edge_ta),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the wave's static run, then whatever it can take from the waves that are behind (an edge wave starts here); one copy of the
+    // tile routine, the claim / steal logic all outside it
+    MidLds w;
+    w.XE = slice; w.nco = s_nco;
+    w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
+    unsigned n_stolen = 0;
+    for (;;) {
+        // (the lane index made opaque per run: nothing a run derives from it is then hoisted out of this loop and held -- spilled --
+        //  across the tile loop of every run)
+        int ln = (int)__lane_id();
+        asm volatile("" : "+v"(ln));
+        if (have) run_mid<NL, NONCO, L3, L4, AGC>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
+        if (!steal_run(a, gw, ln, t0, t1)) break;
+        have = true; n_stolen += 1;
+    }
+    CLOCK_END(a.sink);
+#ifdef IQGPU_CLOCKSTAMP
+    if (lane == 0 && gw < 4032) ((unsigned *)((char *)a.sink + 49408))[gw] = n_stolen;
+#endif
+    (void)EDGE; (void)n_stolen;
 }
 
 // Placement of the arms in the tap planes (front_fat_common.hpp).  A slot's 8-byte tap reads are served a half-wave at a time, 32

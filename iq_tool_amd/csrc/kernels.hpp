@@ -124,6 +124,16 @@ struct FrontArgs {
     // w_wsum = the weight of all streaming waves.
     int32_t     w_wpw, w_wt[4];
     int64_t     w_wsum;
+    // run stealing (k_front_mid, front_mid.hip): one 8-byte descriptor per wave of the launch, {end : 32 | next : 32} in tiles from
+    // w_edge_ta.  The owner claims tile `next` with a returning agent-scope add at the start of every tile and learns its current
+    // `end` from the value that comes back; a wave out of work halves the longest remaining run among 64 sampled descriptors by a
+    // compare-and-swap on the whole word (so a tile is handed to exactly one wave) and re-runs one warm-up tile.  NULL = static runs.
+    // All descriptors are exhausted (next >= end) when a launch ends, which is the state the next launch needs.
+    unsigned long long *w_steal;
+    int32_t     w_steal_min, w_steal_rounds;   // a run is split only while it has at least w_steal_min unclaimed tiles; sampling rounds before a wave gives up
+    int32_t     w_steal_stride, w_steal_lanes; // descriptor w sits at w_steal[w * w_steal_stride] (spread over the memory channels: the claims of
+                                               // 3072 waves and the thieves' samples otherwise all land on the few channels that hold 24 KB);
+                                               // lanes that sample per round (<= 64)
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access

@@ -257,6 +257,7 @@ extern "C" int iqgpu_wav_probe(const char *path, iqgpu_wav_info *md)
     std::vector<unsigned char> auxi;
     if (fread(hdr, 1, 12, f) == 12 && (memcmp(hdr, "RIFF", 4) == 0 || memcmp(hdr, "RF64", 4) == 0) && memcmp(hdr + 8, "WAVE", 4) == 0) {
         rf64 = memcmp(hdr, "RF64", 4) == 0;
+        const uint32_t riff_size = rd32(hdr + 4);
         uint64_t pos = 12;
         for (;;) {
             unsigned char ch[8];
@@ -280,11 +281,14 @@ extern "C" int iqgpu_wav_probe(const char *path, iqgpu_wav_info *md)
                 if (fread(auxi.data(), 1, (size_t)size, f) != (size_t)size) auxi.clear();
             } else if (memcmp(ch, "data", 4) == 0) {
                 if (rf64 && size == 0xFFFFFFFFu) size = ds64_data;
-                // a capture whose recorder was killed leaves 0 or 0xFFFFFFFF (or any size beyond the file) in the data header:
-                // libsndfile -- what the reference opens the file with (src/input_wav.c:556) -- then takes the data to run to
-                // the end of the file ("wasn't closed properly"; datalength clamped to filelength - dataoffset)
+                // libsndfile -- what the reference opens the file with (src/input_wav.c:556) -- repairs a capture whose recorder
+                // was killed in two ways: a data size of 0 under the 8-byte RIFF size a writer leaves until it closes the file
+                // (and more than a bare header on disk) means "to the end of the file" ("wasn't closed properly"), and ANY size
+                // beyond the file (0xFFFFFFFF included) is clamped to filelength - dataoffset.  A data chunk that says 0 under
+                // a finalised RIFF header is an empty chunk and stays empty: the chunks behind it are not samples.
                 const uint64_t avail = file_size > body ? file_size - body : 0;
-                if ((!rf64 && (size == 0 || size == 0xFFFFFFFFu)) || size > avail) size = avail;
+                if (!rf64 && size == 0 && riff_size == 8 && file_size > 44) size = avail;
+                if (size > avail) size = avail;
                 md->data_offset = body; md->data_bytes = size; have_data = true;
             }
             pos = body + size + (size & 1);

@@ -19,12 +19,12 @@ def fmt(channels, rate, bits, tag=1):
     return chunk(b"fmt ", struct.pack("<HHIIHH", tag, channels, rate, rate * ba, ba, bits))
 
 
-def wav(name, chunks, rf64=False, data_len=None):
+def wav(name, chunks, rf64=False, data_len=None, riff_size=None):
     body = b"WAVE" + b"".join(chunks)
     if rf64:
         head = b"RF64" + struct.pack("<I", 0xFFFFFFFF)
     else:
-        head = b"RIFF" + struct.pack("<I", len(body))
+        head = b"RIFF" + struct.pack("<I", len(body) if riff_size is None else riff_size)
     with open(os.path.join(HERE, name), "wb") as fh:
         fh.write(head + body)
 
@@ -55,9 +55,12 @@ def main():
     wav("mono.wav", [fmt(1, 48000, 16), chunk(b"data", pcm16)])
     wav("pcm24.wav", [fmt(2, 2400000, 24), chunk(b"data", pcm16 + pcm16[:64])])
     wav("float32_extensible.wav", [chunk(b"fmt ", struct.pack("<HHIIHH", 0xFFFE, 2, 2400000, 2400000 * 8, 8, 32) + struct.pack("<HHIH", 22, 32, 3, 3) + bytes(14)), chunk(b"data", pcm16)])
-    # 7. a recorder that was killed: the data header says 0 / 0xFFFFFFFF / more than the file holds -- libsndfile reads to the end of the file
-    for name, claimed in (("killed_size0_97900000Hz.wav", 0), ("killed_sizeff_97900000Hz.wav", 0xFFFFFFFF), ("killed_toolong_97900000Hz.wav", 4 * 64 + 4000)):
-        wav(name, [fmt(2, 2400000, 16), b"data" + struct.pack("<I", claimed) + pcm16])
+    # 7. a recorder that was killed: the data header says 0 (under the 8-byte RIFF size of a file never finalised) / 0xFFFFFFFF /
+    #    more than the file holds -- libsndfile reads to the end of the file
+    for name, claimed, riff in (("killed_size0_97900000Hz.wav", 0, 8), ("killed_sizeff_97900000Hz.wav", 0xFFFFFFFF, None), ("killed_toolong_97900000Hz.wav", 4 * 64 + 4000, None)):
+        wav(name, [fmt(2, 2400000, 16), b"data" + struct.pack("<I", claimed) + pcm16], riff_size=riff)
+    # 8. a legitimately EMPTY data chunk under a finalised RIFF header, a LIST chunk behind it: zero frames, and the LIST bytes are not samples
+    wav("empty_data_97900000Hz.wav", [fmt(2, 2400000, 16), chunk(b"data", b""), chunk(b"LIST", bytes(range(64)))])
     print(sorted(os.listdir(HERE)))
 
 

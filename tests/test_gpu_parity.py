@@ -874,6 +874,52 @@ def test_mid_kernel_random_schedules(gpu, monkeypatch, seed):
     assert st_got == st_ref
 
 
+def _runs_taken(ch):
+    """runs that waves of k_front_mid took from each other since the last read (the chain's diagnostic scratch, front_mid.hip steal_run)"""
+    import ctypes as C
+    buf = np.zeros(65536, np.uint8)
+    ch._lib.iqgpu_chain_debug_read_scratch(ch._h, buf.ctypes.data_as(C.c_void_p))
+    return int(buf[32768 + 128 + 24:32768 + 128 + 32].view(np.uint64)[0])
+
+
+@pytest.mark.parametrize("weights,steal_min", [("1300,1000,700", "6"), ("3000,1000,100", "2"), ("100,1000,3000", "3"), ("0,0,0", "2")])
+def test_mid_kernel_run_stealing_keeps_the_bytes(gpu, monkeypatch, weights, steal_min):
+    """Run stealing in k_front_mid (front_mid.hip: a wave out of tiles halves the longest unclaimed run it finds by a compare-and-swap
+    on that wave's descriptor and re-runs one warm-up tile): a tile's bytes do not depend on who computes it, every tile is claimed
+    exactly once -- so the output equals the static launch's (IQGPU_STEAL=0) and k_front_s1's, byte for byte, over several calls
+    of one stream (the descriptors are left exhausted by every launch), with and without the fused AGC.  Skewed static runs and
+    a low threshold make thousands of runs change hands; the chain's counter proves that they did."""
+    n = 3 * (1 << 24) + 4321
+    raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 77, "cs16"), 13)[:2 * n]
+    splits = [(1 << 25) + 777, n - (1 << 25) - 777]
+
+    def run(agc):
+        ch = gpu.Chain(**dict(NRSC5, agc=agc))
+        outs, pos = [], 0
+        for k in (splits if not agc else [(1 << 25), n - (1 << 25)]):
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        return np.concatenate(outs), _runs_taken(ch), (ch.agc_state() if agc else None)
+
+    for agc in (False, True):
+        monkeypatch.setenv("IQGPU_STEAL", "0")
+        ref, taken0, st_ref = run(agc)
+        assert taken0 == 0
+        monkeypatch.setenv("IQGPU_STEAL", "1")
+        monkeypatch.setenv("IQGPU_RUN_WEIGHTS", weights)
+        monkeypatch.setenv("IQGPU_STEAL_MIN", steal_min)
+        got, taken, st_got = run(agc)
+        monkeypatch.delenv("IQGPU_RUN_WEIGHTS"); monkeypatch.delenv("IQGPU_STEAL_MIN")
+        assert taken > 0, "no run changed hands: the test does not exercise the stealing path"
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (agc, taken, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+        assert st_got == st_ref
+        if not agc:
+            monkeypatch.setenv("IQGPU_NO_FAT", "1")
+            s1, _, _ = run(agc)
+            monkeypatch.delenv("IQGPU_NO_FAT")
+            assert np.array_equal(got, s1)
+
+
 def test_fat_kernel_takes_long_calls_by_itself(gpu):
     """without any switch: a 2^25-frame call runs k_front_fat (the profile names the kernel), a 2^20-frame one k_front_s1, and
     the stream continues across the change of kernel"""

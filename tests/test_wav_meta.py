@@ -92,6 +92,15 @@ def test_unclosed_capture_runs_to_the_end_of_the_file(wm, name):
     assert md.center_freq_hz == 97900000.0
 
 
+def test_empty_data_chunk_stays_empty(wm):
+    """a data size of 0 is only "to the end of the file" under the 8-byte RIFF size of a file that was never finalised
+    (libsndfile wav.c: chunk_size == 0 && RIFFsize == 8 && filelength > 44); under a finalised header it is an empty chunk,
+    and the LIST chunk behind it is not sample data"""
+    md = wm.probe(os.path.join(WAV, "empty_data_97900000Hz.wav"))
+    assert md.frames == 0 and md.data_bytes == 0
+    assert md.center_freq_hz == 97900000.0
+
+
 def test_rejected_files(wm):
     import iq_tool_amd
     for name in ("mono.wav", "pcm24.wav", "float32_extensible.wav"):

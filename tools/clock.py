@@ -89,3 +89,8 @@ for i, e in zip(idx, e_us):
     wg_end.setdefault(i // WPW, []).append(e)
 ends = np.array([max(v) for v in wg_end.values()])
 print("workgroups: %d, end time min %.1f p50 %.1f p95 %.1f max %.1f us" % (len(ends), ends.min(), *np.percentile(ends, [50, 95]), ends.max()))
+# run stealing (k_front_mid): runs a wave took from others, and how close the last wave ends to the median
+st = buf[49408:49408 + 4 * 4032].view(np.uint32)[ok[:4032]]
+if st.size:
+    print("steals per wave: total %d, mean %.2f, max %d, waves with none %d; last wave end / median wave end = %.3f"
+          % (st.sum(), st.mean(), st.max(), (st == 0).sum(), e_us.max() / np.median(e_us[~edge])))
