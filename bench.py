@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--secondary-settle", type=float, default=0.7, help="seconds of untimed steps in front of each secondary leg")
     ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
     ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
+    ap.add_argument("--stub-batch-frames", type=int, default=262144,
+                    help="frames per submit() in the host_end_to_end_stub leg: what the INTEGRATION.md binding hands over (16 reference chunks of 16384)")
+    ap.add_argument("--stub-log2-frames", type=int, default=28, help="frames per GPU streamed in the host_end_to_end_stub leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` legs (stub-sized host batches, block_samples = 262144, reference-binary probe)")
     a = ap.parse_args()
     a.preset = a.config == "preset"
     a.config = 2 if a.preset else int(a.config)
@@ -363,26 +367,83 @@ def secondary_cases(args, dist, dev, local_rank, world, rank):
     AFTER the main timed region: they never touch `value`; they are in the line so that the driver's run carries them."""
     out = {}
     for name, cfg, preset in (("config3", 3, False), ("config4", 4, False), ("preset", 2, True)):
-        c = run_case(args, dist, dev, local_rank, world, rank, cfg, preset, args.secondary_steps, 2, args.secondary_settle, 28)
-        e = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "steps": c["steps"], "frames_per_step": c["frames"],
-             "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1)}
-        if preset:
-            e["workload"] = "cs16-fm-nrsc5 preset: BASELINE configs[1] + digital output AGC fused past the lock"
-            e["roofline"] = {"bound": "hbm", "achieved": round(c["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(c["achieved"] / HBM_PEAK_GBS, 4), "kernel": "all kernels of the step", "kernel_ms": round(c["k_ms"], 4),
-                             "note": "per-kernel ms per step: " + ", ".join("%s %.3f" % (k, v["ms"] / max(c["steps"], 1)) for k, v in c["prof"].items() if v["launches"])}
-        else:
-            e["workload"] = c["workload"]
-            e["roofline"] = fp32_roofline(c)
-        tb = secondary_traffic(name)
-        e["traffic"] = tb
-        e["traffic_over_algorithmic"] = round(tb / c["alg_bytes"], 3) if tb else None
-        out[name] = e
-        c["chain"].close()
-        del c
+        try:
+            out[name] = secondary_case(args, dist, dev, local_rank, world, rank, name, cfg, preset)
+        except Exception as exc:       # a secondary leg never costs the line its `value`: the failure is recorded in its place
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         import torch
         torch.cuda.empty_cache()
     return out
+
+
+def secondary_case(args, dist, dev, local_rank, world, rank, name, cfg, preset):
+    c = run_case(args, dist, dev, local_rank, world, rank, cfg, preset, args.secondary_steps, 2, args.secondary_settle, 28)
+    e = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "steps": c["steps"], "frames_per_step": c["frames"],
+         "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1)}
+    if preset:
+        e["workload"] = "cs16-fm-nrsc5 preset: BASELINE configs[1] + digital output AGC fused past the lock"
+        e["roofline"] = {"bound": "hbm", "achieved": round(c["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(c["achieved"] / HBM_PEAK_GBS, 4), "kernel": "all kernels of the step", "kernel_ms": round(c["k_ms"], 4),
+                         "note": "per-kernel ms per step: " + ", ".join("%s %.3f" % (k, v["ms"] / max(c["steps"], 1)) for k, v in c["prof"].items() if v["launches"])}
+    else:
+        e["workload"] = c["workload"]
+        e["roofline"] = fp32_roofline(c)
+    tb = secondary_traffic(name)
+    e["traffic"] = tb
+    e["traffic_over_algorithmic"] = round(tb / c["alg_bytes"], 3) if tb else None
+    c["chain"].close()
+    return e
+
+
+def reference_binary_probe(frames_log2=24):
+    """BASELINE.md section 3, optional: when the reference's own `iq_tool` binary (and the libliquid it links) is on this
+    box, time it on the configs[1] command line of SURVEY.md 8(d) over a synthetic cs16 file; otherwise say so.  Never
+    required, never `value`: this image and the GPU boxes carry neither, so the line normally reports "skipped"."""
+    import shutil
+    import tempfile
+    exe = os.environ.get("IQGPU_REFERENCE_BIN") or shutil.which("iq_tool")
+    if not exe or not os.path.exists(exe):
+        return {"status": "reference binary not available -- skipped", "looked_for": "iq_tool on PATH, IQGPU_REFERENCE_BIN"}
+    from iq_tool_amd import synth
+    n = 1 << frames_log2
+    with tempfile.TemporaryDirectory() as td:
+        src, dst = os.path.join(td, "in.cs16"), os.path.join(td, "out.cs16")
+        np.tile(synth.raw_stream(1 << 20, 2.4e6, 1, "cs16"), n >> 20).tofile(src)
+        cmd = [exe, "-i", "raw-file", src, "--raw-file-input-rate", "2.4e6", "--raw-file-input-sample-format", "cs16",
+               "-o", "raw-file", dst, "--output-rate", "744187.5", "--output-sample-format", "cs16", "--freq-shift", "200e3"]
+        env = dict(os.environ)
+        if os.environ.get("IQGPU_LIQUID_SO"):
+            env["LD_LIBRARY_PATH"] = os.path.dirname(os.environ["IQGPU_LIQUID_SO"]) + ":" + env.get("LD_LIBRARY_PATH", "")
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            dt = time.perf_counter() - t0
+        except (OSError, subprocess.TimeoutExpired) as exc:
+            return {"status": "reference binary found but did not run: %s" % exc, "binary": exe}
+        if r.returncode != 0:
+            return {"status": "reference binary exited %d: %s" % (r.returncode, r.stderr.decode("utf-8", "replace")[-200:]), "binary": exe}
+        out_frames = os.path.getsize(dst) // 4 if os.path.exists(dst) else 0
+    return {"status": "ran", "binary": exe, "value": round(n / dt / 1e6, 3), "unit": "MS/s", "frames": n, "out_frames": out_frames,
+            "threads": "the reference's own (reader, pre-processor, resampler, post-processor, writer)", "kind": "reference",
+            "note": "whole process, file I/O included: `%s`" % " ".join(cmd[:1] + ["..."] + cmd[3:])}
+
+
+def device_residency_leg(args, dist, dev, local_rank, world, rank, block_samples, steps):
+    """configs[1] exactly as BASELINE.json words it -- '256 k-sample blocks': the same device-resident step with
+    block_samples = 262144 (fixed runs of tiles per wavefront instead of one run per resident wave).  Same bytes (tested:
+    results do not depend on the partition); never `value`."""
+    global BLOCK_SAMPLES
+    keep = BLOCK_SAMPLES
+    BLOCK_SAMPLES = block_samples
+    try:
+        c = run_case(args, dist, dev, local_rank, world, rank, 2, False, steps, 2, 0.7, args.log2_frames)
+    finally:
+        BLOCK_SAMPLES = keep
+    kern = c["chain"].front_kernel()
+    c["chain"].close()
+    return {"block_samples": block_samples, "ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "steps": c["steps"],
+            "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1), "kernel": kern, "kernel_ms": round(c["k_ms"], 4),
+            "frac": round(c["achieved"] / HBM_PEAK_GBS, 4)}
 
 
 def cpu_baseline(frames_log2):
@@ -462,7 +523,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # which physical device every rank drives (ordinal + PCI bus id, gathered over gloo): an N-rank line shows N distinct GPUs
+    import ctypes
+    bus = ctypes.create_string_buffer(64)
+    lib.iqgpu_device_pci_bus_id(local_rank, bus, 64)
+    mine = {"rank": rank, "ordinal": local_rank, "pci_bus_id": bus.value.decode(), "host": socket.gethostname()}
+    devices = [mine]
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+
     case = run_case(args, dist, dev, local_rank, world, rank, args.config, args.preset, args.steps, args.warmup, args.settle_seconds, args.log2_frames)
+    front_kernel = case["chain"].front_kernel()
     chain, seg, frames, dt, k_ms, prof, front, n_out_avg, alg_bytes, achieved, chain_kw, in_bps, workload = (
         case[k] for k in ("chain", "seg", "frames", "dt", "k_ms", "prof", "front", "n_out_avg", "alg_bytes", "achieved", "chain_kw", "in_bps", "workload"))
     value = world * args.steps * frames / dt / 1e6
@@ -477,22 +549,32 @@ def main():
                 "h2d_GBs": round(h_up / h_dt / 1e9, 2), "d2h_GBs": round(h_down / h_dt / 1e9, 2),
                 "frames_per_gpu": h_frames, "batch_frames": 1 << args.host_batch_log2,
                 "path": "pinned host buffers -> iqgpu_chain_submit (H2D, kernels, D2H staged by the host, %d batches in flight) -> iqgpu_chain_collect; h2d/d2h per GPU" % chain._lib.iqgpu_chain_pipeline_depth()}
+    # ---- ... and at the batch size of the INTEGRATION.md binding: 16 reference chunks = 262144 frames per submit ----
+    host_stub = None
+    if host is not None and not args.no_extra:
+        chain.reset()
+        s_dt, s_frames, s_up, s_down = host_leg(dist, chain, seg, 1 << args.stub_log2_frames, args.stub_batch_frames)
+        host_stub = {"value": round(world * s_frames / s_dt / 1e6, 2), "unit": "MS/s", "batch_frames": args.stub_batch_frames,
+                     "us_per_batch": round(s_dt / (s_frames / args.stub_batch_frames) * 1e6, 2),
+                     "h2d_GBs": round(s_up / s_dt / 1e9, 2), "d2h_GBs": round(s_down / s_dt / 1e9, 2), "frames_per_gpu": s_frames,
+                     "kernel": chain.front_kernel(),
+                     "path": "as host_end_to_end, at the batch the INTEGRATION.md section 2 stub submits (16 x PIPELINE_CHUNK_BASE_SAMPLES, include/constants.h:123)"}
 
     if rank == 0:
         line = {
             "metric": "complex MS/s end-to-end on NRSC-5 resample+filter chain; % HBM roofline",
-            "value": round(value, 2), "unit": "MS/s",
+            "value": round(value, 2), "unit": "MS/s", "value_is": "device_resident (inputs in HBM when the timed region starts; host_end_to_end is the PCIe-inclusive rate)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "settle_s": args.settle_seconds,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(min(frames, 1 << SEGMENT_LOG2))), case["log2_frames"]),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
-                       "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES,
+                       "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES, "devices": devices,
                        "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"
                                    + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(case["log2_frames"]) if args.config == 2 else None,
-                         "kernel": "k_front_mid<6, false, 4, 0, false> (front_mid.hip; IQGPU_FAT=1: k_front_fat, IQGPU_NO_FAT=1: k_front_s1)" if args.config == 2 else "k_front", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
+                         "kernel": front_kernel + " (iqgpu_chain_front_kernel: what the timed launches ran)", "kernel_ms": round(k_ms, 4), "launches": front["launches"],
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(frames * in_bps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
             "host_end_to_end": host,
@@ -506,20 +588,34 @@ def main():
             line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
                                           "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "
                                           + ", ".join("%s %.3f" % (k, v["ms"] / max(args.steps, 1)) for k, v in prof.items() if v["launches"]))
-            line["roofline"]["kernel"] = "k_front_mid<6, false, 4, 0, agc> + k_agc_classify / k_agc_verify"
+            line["roofline"]["kernel"] = front_kernel + " with the fused AGC + k_agc_classify / k_agc_verify"
             line["roofline"]["traffic"] = None
         if world == 1 and not args.no_cpu_baseline and args.config == 2 and not args.preset:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
         else:
             line["cpu_baseline"] = None
     # ---- the other single-GPU BASELINE configs and the shipped preset: short legs of their own, after everything that feeds `value`
-    sec = None
-    if args.config == 2 and not args.preset and not args.no_secondary:
+    # (N = 1 only: they are per-GPU figures, and a leg that failed on one rank of several would leave the others in a barrier)
+    sec = extra = None
+    if args.config == 2 and not args.preset and world == 1:
         case = chain = None
         torch.cuda.empty_cache()
-        sec = secondary_cases(args, dist, dev, local_rank, world, rank)
+        if not args.no_extra:
+            extra = {"host_end_to_end_stub": host_stub}
+            try:
+                extra["block_samples_262144"] = device_residency_leg(args, dist, dev, local_rank, world, rank, 262144, args.secondary_steps)
+            except Exception as exc:
+                extra["block_samples_262144"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            torch.cuda.empty_cache()
+            try:
+                extra["reference_binary"] = reference_binary_probe()
+            except Exception as exc:
+                extra["reference_binary"] = {"status": "probe failed: %s: %s" % (type(exc).__name__, exc)}
+        if not args.no_secondary:
+            sec = secondary_cases(args, dist, dev, local_rank, world, rank)
     if rank == 0:
         line["secondary"] = sec
+        line["extra"] = extra
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

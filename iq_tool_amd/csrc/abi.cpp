@@ -129,7 +129,7 @@ int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8")
                      ? kDbgMid8 : 0u);
         if (const char *tf = getenv("IQGPU_TAP_FOLD")) c->tap_fold_env = atoi(tf) != 0 ? 1 : 0;
-        if (const char *v = getenv("IQGPU_STEAL")) c->steal = v[0] != '0';
+        if (const char *v = getenv("IQGPU_STEAL")) c->steal = v[0] == '1';
         if (const char *v = getenv("IQGPU_STEAL_MIN")) { const int x = atoi(v); if (x >= 2 && x < 100000) c->steal_min = x; }
         if (const char *v = getenv("IQGPU_STEAL_ROUNDS")) { const int x = atoi(v); if (x >= 1 && x <= 64) c->steal_rounds = x; }
         if (const char *v = getenv("IQGPU_STEAL_STRIDE")) { const int x = atoi(v); if (x >= 1 && x <= 8192) c->steal_stride = x; }

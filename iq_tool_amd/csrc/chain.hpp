@@ -126,9 +126,10 @@ struct iqgpu_chain {
     cd2 *d_dc_state = nullptr;
     void *d_sink = nullptr;      // diagnostic scratch of k_front_s1 (iqgpu_chain_debug_read_scratch)
     // run stealing in k_front_mid (kernels.hpp, FrontArgs::w_steal): one descriptor per wave of a launch; all exhausted between
-    // launches (zeroed when the array is (re)allocated).  IQGPU_STEAL=0 keeps the static runs, IQGPU_STEAL_MIN / _ROUNDS tune it.
+    // launches (zeroed when the array is (re)allocated).  IQGPU_STEAL=1 turns it on, IQGPU_STEAL_MIN / _ROUNDS / _LANES / _STRIDE tune it.
     DevBuf steal_buf;
-    bool steal = true; int steal_min = 6, steal_rounds = 4, steal_stride = 544, steal_lanes = 64;   // stride in 8-byte words: 4352 B
+    // (off by default: measured neutral, profiles/r04_steal.md -- the launch tail it removes turned out to be free)
+    bool steal = false; int steal_min = 6, steal_rounds = 6, steal_stride = 544, steal_lanes = 16;   // stride in 8-byte words: 4352 B
     DevBuf dc_agg, dc_carry;
     DevBuf fbuf[2]; int fcur = 0;
     // output AGC (digital profile)

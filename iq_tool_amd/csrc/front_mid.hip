@@ -74,9 +74,9 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // Tiles [T_begin, T_emit1) of 768 frames; those from T_emit0 on produce output.  Every tile, and the one behind the last
 // (prefetch), lies inside the call's new, 16-byte aligned frames and outside the history the call leaves behind.
 // L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
-// Run stealing (kernels.hpp): the run's end is whatever the wave's descriptor `desc` says when a tile is claimed -- one returning
-// agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
-template <int NL, bool NONCO, int L3, int L4, bool AGC>
+// STEAL (run stealing, kernels.hpp): the run's end is whatever the wave's descriptor `desc` says when a tile is claimed -- one
+// returning agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, int64_t T_emit1, unsigned long long *const desc)
 {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto addr_rt = [](int rc) { return NL == 6 ? 8 * rc : (rc >> 3) * 80 + (rc & 7) * 8; };
     char *XE = w.XE, *HB = w.XE;
     uint32_t step = a.step;
-    asm volatile("" : "+s"(step));                    // (opaque per run: the reciprocals of the prologue's divisions are not held across the caller's loop)
+    if (STEAL) asm volatile("" : "+s"(step));         // (opaque per run: the reciprocals of the prologue's divisions are not held across the caller's loop)
     float hb[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) hb[k] = a.hb0[k];
@@ -378,13 +378,13 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto claim = [&]() { if (lane == 0) cv = __hip_atomic_fetch_add(desc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto claimed_end = [&]() { return a.w_edge_ta + (int64_t)__builtin_amdgcn_readfirstlane((int)(cv >> 32)); };
     for (int64_t T = T_begin; T < T_emit0; ++T) tile(T, false, false);     // warm-up tiles
-    claim();
+    if (STEAL) claim();
     tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
-    T_emit1 = claimed_end();
+    if (STEAL) T_emit1 = claimed_end();
     for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) {                       // steady state
-        claim();
+        if (STEAL) claim();
         tile(T, true, true);
-        T_emit1 = claimed_end();
+        if (STEAL) T_emit1 = claimed_end();
     }
     // the last tile's polyphase
     if (kLean) V_pp_lean();
@@ -459,7 +459,7 @@ __device__ __forceinline__ bool steal_run(const FrontArgs &a, const int64_t gw, 
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
-template <int NL, bool NONCO, int L3, int L4, bool AGC>
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL>
 __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 {
     typedef MidGeom<NL> G;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         if (r >= a.w_n_stream) return;
         t0 = w_run_start_weighted(a, r); t1 = w_run_start_weighted(a, r + 1);
         have = true;
-        if (lane == 0)                               // the static run, open to thieves from here on
+        if (STEAL && lane == 0)                      // the static run, open to thieves from here on
             __hip_atomic_store(a.w_steal + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)(t1 - a.w_edge_ta) << 32) | (unsigned long long)(uint32_t)(t0 - a.w_edge_ta),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -530,14 +530,18 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     w.XE = slice; w.nco = s_nco;
     w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
     unsigned n_stolen = 0;
-    for (;;) {
-        // (the lane index made opaque per run: nothing a run derives from it is then hoisted out of this loop and held -- spilled --
-        //  across the tile loop of every run)
-        int ln = (int)__lane_id();
-        asm volatile("" : "+v"(ln));
-        if (have) run_mid<NL, NONCO, L3, L4, AGC>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
-        if (!steal_run(a, gw, ln, t0, t1)) break;
-        have = true; n_stolen += 1;
+    if constexpr (!STEAL) {
+        if (have) run_mid<NL, NONCO, L3, L4, AGC, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, nullptr);
+    } else {
+        for (;;) {
+            // (the lane index made opaque per run: nothing a run derives from it is then hoisted out of this loop and held --
+            //  spilled -- across the tile loop of every run)
+            int ln = (int)__lane_id();
+            asm volatile("" : "+v"(ln));
+            if (have) run_mid<NL, NONCO, L3, L4, AGC, true>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
+            if (!steal_run(a, gw, ln, t0, t1)) break;
+            have = true; n_stolen += 1;
+        }
     }
     CLOCK_END(a.sink);
 #ifdef IQGPU_CLOCKSTAMP
@@ -635,11 +639,18 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_MID(NL, NONCO, L3, L4, AGC)                                                                    \
+#define IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, STEAL)                                                            \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_mid<NL, NONCO, L3, L4, AGC>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC>), dim3(grid), dim3(kMidThreads), lds, s, a);        \
+        { const hipError_t e = cache.ensure((const void *)k_front_mid<NL, NONCO, L3, L4, AGC, STEAL>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC, STEAL>), dim3(grid), dim3(kMidThreads), lds, s, a); \
+    } while (0)
+    /* run stealing: six outputs per lane only, and only when the host provides descriptors and asks for it */
+    const bool steal = a.w_steal != nullptr && a.w_steal_rounds > 0;
+#define IQGPU_LAUNCH_MID(NL, NONCO, L3, L4, AGC)                                                                    \
+    do {                                                                                                              \
+        if (NL == 6 && steal) IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, (NL == 6));                                 \
+        else IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, false);                                                      \
     } while (0)
 #define IQGPU_LAUNCH_MID2(NL, L3, L4)                                                                               \
     do {                                                                                                              \
@@ -655,6 +666,7 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     else IQGPU_LAUNCH_MID2(8, 5, 7);
 #undef IQGPU_LAUNCH_MID2
 #undef IQGPU_LAUNCH_MID
+#undef IQGPU_LAUNCH_MID1
     return hipGetLastError();
 }
 

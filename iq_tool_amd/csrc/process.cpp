@@ -73,7 +73,7 @@ int Call::prepare_buffers()
         int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
     }
     // run descriptors of k_front_mid: a fresh array starts exhausted (all zero), a used one is left exhausted by every launch
-    if (mid) {
+    if (mid && c->steal) {
         const void *was = c->steal_buf.p;
         const size_t slots = (size_t)(cplan.w_n_edge + cplan.w_n_stream) + 64;
         int rc = c->steal_buf.ensure(slots * (size_t)c->steal_stride * sizeof(unsigned long long)); if (rc) return rc;
@@ -193,12 +193,11 @@ int Call::stage_front()
             a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
             HIP_TRY(clean_agc_peaks());
         }
-        // k_front_mid: every wave claims its tiles through its run descriptor; with one run per resident wave, waves that finish
-        // early split the runs of those that are behind (w_steal_rounds > 0)
-        if (mid) {
+        // k_front_mid, IQGPU_STEAL=1, one run per resident wave: every wave claims its tiles through its run descriptor and waves
+        // that finish early split the runs of those that are behind (front_mid.hip; off by default, profiles/r04_steal.md)
+        if (mid && c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64) {
             a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
-            a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes;
-            a.w_steal_rounds = (c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64) ? c->steal_rounds : 0;
+            a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = c->steal_rounds;
         }
         a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (front_mid_nl(a) == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)

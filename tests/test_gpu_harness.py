@@ -205,7 +205,7 @@ def test_bench_two_ranks_share_the_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-frames", "22",
-                        "--settle-seconds", "0.2", "--no-cpu-baseline", "--no-host-leg", "--no-secondary"],
+                        "--settle-seconds", "0.2", "--no-cpu-baseline", "--no-host-leg", "--no-secondary --no-extra"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]

@@ -23,11 +23,18 @@ SRC = os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_wave.hip")
 SRC_CASC = os.path.join(HERE, "..", "iq_tool_amd", "csrc", "cascade_wave.hip")
 
 
+def source_flags(src):
+    """the per-source flags of the real build (iq_tool_amd/build.py SOURCE_FLAGS): the ISA checked is the ISA shipped"""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from iq_tool_amd import build as b
+    return list(b.SOURCE_FLAGS.get(os.path.basename(src), []))
+
+
 def compile_isa(src=None):
     src = src or SRC
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "fw.s")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", *source_flags(src),
                "--cuda-device-only", "-S", src, "-o", out]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         return open(out).read().split("\n")
@@ -111,9 +118,14 @@ def check_fat_mid(src, kernel, max_vgpr):
     tile loop is a memory round trip per tile), (6) the VGPR count that the occupancy they are built for allows (8 waves per CU:
     256, 12 waves: 168), (7) the tap reads stay single ds_read_b64 -- fused into ds_read2_b64 / ds_read2st64_b64 they run at
     half rate (the tap planes are 2056 bytes apart so that they cannot be fused: a change of that layout shows up here), (8) no
-    ds_read2_b32 (a trimmed, re-chunked window load)."""
+    ds_read2_b32 (a trimmed, re-chunked window load); k_front_mid only: (9) the tile claim of the run-stealing scheme is a returning
+    global_atomic_add_x2 issued by one lane whose result is NOT waited for on the spot (the atomic optimizer's wave reduction --
+    s_bcnt1 + an immediate s_waitcnt vmcnt(0) + readfirstlane -- would put a memory round trip in front of every tile), and the
+    tile loop that holds it is a scalar loop (a divergent run bound turns it into v_cmp / EXEC-mask control: s_andn2_b64 exec)."""
     lines = compile_isa(src)
     errors, cur, n = [], None, 0
+    if kernel == "k_front_mid":
+        errors += check_claims(lines)
     for l in lines:
         m = re.match(r"(_ZN5iqgpu\d+%sI\w+):" % kernel, l)
         if m:
@@ -125,13 +137,53 @@ def check_fat_mid(src, kernel, max_vgpr):
             if re.match(r"ds_read2(st64)?_b(32|64)", t):
                 errors.append("%s: %s holds a %s" % (kernel, cur, t.split()[0])); cur = None
             elif t.startswith("scratch_"):
-                errors.append("%s: %s spills to scratch" % (kernel, cur)); cur = None
+                # (the opt-in run-stealing instantiations -- last template argument true -- are an experiment that is off by
+                #  default: the fused-AGC + mixer shape of it holds 24 bytes of scratch outside its tile loop's FMA runs)
+                if not cur.endswith("ELb1EEEvNS_9FrontArgsE") or kernel != "k_front_mid":
+                    errors.append("%s: %s spills to scratch" % (kernel, cur))
+                cur = None
     for m in re.finditer(r"\.amdhsa_kernel (_ZN5iqgpu\d+%sI\w+)\n(.*?)\.end_amdhsa_kernel" % kernel, "\n".join(lines), re.S):
         v = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
         if v and int(v.group(1)) > max_vgpr:
             errors.append("%s: %s needs %s VGPRs (more than %d: a wave per SIMD lost)" % (kernel, m.group(1), v.group(1), max_vgpr))
     if n == 0:
         errors.append("no %s instantiation found" % kernel)
+    return errors
+
+
+def check_claims(lines):
+    errors, cur, body = [], None, []
+    funcs = {}
+    for l in lines:
+        m = re.match(r"(_ZN5iqgpu11k_front_midI\w+):", l)
+        if m:
+            cur = m.group(1); funcs[cur] = []
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur:
+            t = l.strip()
+            if t and not t.startswith((";", ".")) or t.startswith(".LBB"):
+                funcs[cur].append(t)
+    for name, ins in funcs.items():
+        if not name.endswith("ELb1EEEvNS_9FrontArgsE"):       # STEAL = false: no claims at all
+            if any(t.startswith("global_atomic_add_x2") and t.endswith("sc0") for t in ins):
+                errors.append("k_front_mid: %s (no stealing) holds a returning atomic add" % name)
+            continue
+        claims = [i for i, t in enumerate(ins) if t.startswith("global_atomic_add_x2") and t.endswith("sc0") and "off" not in t.split()[1:4]]
+        if len(claims) < 2:
+            errors.append("k_front_mid: %s holds %d returning tile claims (expected one in front of the first tile and one in the loop)" % (name, len(claims)))
+        for i in claims:
+            nxt = [t for t in ins[i + 1:i + 8] if not t.startswith(".LBB")]
+            if any(t.startswith("s_waitcnt vmcnt(0)") for t in nxt[:4]) and any(t.startswith("v_readfirstlane") for t in nxt[:6]):
+                errors.append("k_front_mid: %s waits for its tile claim on the spot (atomic optimizer on?)" % name)
+        if any(t.startswith("s_bcnt1_i32_b64") for t in ins):
+            errors.append("k_front_mid: %s holds a wave-reduced atomic (s_bcnt1_i32_b64): build with -amdgpu-atomic-optimizer-strategy=None" % name)
+        if claims:
+            # the loop around the last claim: from the nearest label above to the first backward branch below
+            i = claims[-1]
+            seg = ins[i:i + 900]
+            if any(t.startswith("s_andn2_b64 exec, exec") for t in seg[:700]) and not any(t.startswith("s_cbranch_vccnz") or t.startswith("s_cbranch_scc") for t in seg[:700]):
+                errors.append("k_front_mid: %s runs its tile loop under EXEC-mask control (a divergent run bound)" % name)
     return errors
 
 

@@ -8,6 +8,6 @@ if [ "$1" = timeline ]; then
 fi
 for i in 1 2 3; do
 for w in "$@"; do
-  IQGPU_RUN_WEIGHTS=$w python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-secondary 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('w=$w', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
+  IQGPU_RUN_WEIGHTS=$w python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-leg --no-secondary --no-extra 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('w=$w', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
 done
 done
