@@ -123,11 +123,12 @@ int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
     c->device = d->device_ordinal;
     {   // every IQGPU_* switch is read HERE, once per chain: process() and the launch functions never touch the environment
         const char *fg = getenv("IQGPU_FORCE_GENERIC"); c->force_generic = fg && fg[0] == '1';
-        c->dbg = (getenv("IQGPU_NO_FAST") ? kDbgNoFast : 0u) | (getenv("IQGPU_AGC_NOFUSE") ? kDbgAgcNoFuse : 0u) |
-                 (getenv("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (getenv("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
-                 (getenv("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (getenv("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
-                 (getenv("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (getenv("IQGPU_FAT") ? kDbgUseFat : 0u) | (getenv("IQGPU_MID8")
-                     ? kDbgMid8 : 0u);
+        // (booleans: only "1..." switches one on -- IQGPU_NO_FAT=0 or an empty value leaves the default kernel selection alone)
+        auto on = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
+        c->dbg = (on("IQGPU_NO_FAST") ? kDbgNoFast : 0u) | (on("IQGPU_AGC_NOFUSE") ? kDbgAgcNoFuse : 0u) |
+                 (on("IQGPU_NO_RAW0") ? kDbgNoRaw0 : 0u) | (on("IQGPU_NO_KT") ? kDbgNoKT : 0u) |
+                 (on("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (on("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
+                 (on("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (on("IQGPU_FAT") ? kDbgUseFat : 0u) | (on("IQGPU_MID8") ? kDbgMid8 : 0u);
         if (const char *tf = getenv("IQGPU_TAP_FOLD")) c->tap_fold_env = atoi(tf) != 0 ? 1 : 0;
         if (const char *v = getenv("IQGPU_STEAL")) c->steal = v[0] == '1';
         if (const char *v = getenv("IQGPU_STEAL_MIN")) { const int x = atoi(v); if (x >= 2 && x < 100000) c->steal_min = x; }

@@ -137,7 +137,7 @@ struct iqgpu_chain {
     AgcState *d_agc_state = nullptr; AgcState agc_init{};
     float agc_rms_alpha = 0.0f;     // > 0: profile dx / local (liquid agc_crcf), AgcState.gain = g, .peak_memory = y2_prime
     DevBuf abuf, agc_peak, agc_gain, agc_peak_b;
-    // agc_peak is all zero: what a fused front launch needs (k_agc_verify leaves it so; the unfused kernels do not)
+    // agc_peak is all zero: what a fused front launch needs (k_agc_classify hands it back zeroed, agc_peak_b too; the unfused kernels do not)
     bool agc_peak_clean = false;
     // fused AGC of the locked phase (k_front_s1<.., AGC> + k_agc_verify): which chains qualify, the host's mirror of
     // "has the stream locked" (a closed form: the first chunk that starts after AGC_DIGITAL_LOCK_TIME of output), the
@@ -273,8 +273,8 @@ struct Call {
         for (int i = 0; i < 4; ++i) dst.w_wt[i] = cplan.w_wt[i];
     }
     int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
-    // the per-chunk peaks a fused front launch accumulates into start from zero: k_agc_verify zeroes what it has read, so only
-    // the first fused call behind an unfused one (or behind a reallocation) pays for a fill
+    // the per-chunk peaks a fused front launch accumulates into start from zero: k_agc_classify zeroes what it has read (agc_peak
+    // and agc_peak_b), so only the first fused call behind an unfused one (or behind a reallocation) pays for a fill
     hipError_t clean_agc_peaks()
     {
         if (c->agc_peak_clean) return hipSuccess;

@@ -38,17 +38,46 @@ def test_harness_matches_chain_and_oracle(gpu, oracle, tmp_path):
     assert d.max() <= 1 and (d == 0).mean() >= 0.998
 
 
-def test_harness_shards_are_independent_streams_stitched_in_order(gpu, tmp_path):
-    """BASELINE configs[4] in miniature: N file ranges, fresh state each, concatenated"""
+def oracle_shards(oracle, raw, bounds, kw):
+    """what N runs of the reference + `cat` produce: every shard a FRESH oracle chain over its own file range"""
+    return [oracle.Chain(**kw).process(raw[2 * a:2 * b]) for a, b in bounds]
+
+
+def int_close(got, want, min_same=0.998):
+    assert got.size == want.size, (got.size, want.size)
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1, int(d.max())
+    assert (d == 0).mean() >= min_same, float((d == 0).mean())
+
+
+def test_harness_shards_are_independent_streams_stitched_in_order(gpu, oracle, tmp_path):
+    """BASELINE configs[4] in miniature: N file ranges, fresh state each, concatenated -- against the concatenation of N ORACLE
+    shard outputs (the parity oracle of configs[4]), and byte-equal to N separate HIP chains"""
     n = 4 * 500_000
     raw = synth.raw_stream(n, 2.4e6, 2, "cs16")
     fin, fout = tmp_path / "in.cs16", tmp_path / "out.cs16"
     raw.tofile(fin)
     info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", "4", "--devices", "1", "--chunk-frames", "131072")
     got = np.fromfile(fout, np.int16)
-    parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 500_000:2 * (s + 1) * 500_000]) for s in range(4)]
+    bounds = [(s * 500_000, (s + 1) * 500_000) for s in range(4)]
+    int_close(got, np.concatenate(oracle_shards(oracle, raw, bounds, NRSC5)))
+    parts = [gpu.Chain(**NRSC5).process(raw[2 * a:2 * b]) for a, b in bounds]
     assert np.array_equal(got, np.concatenate(parts))
     assert info["shards"] == 4
+
+
+def test_harness_ragged_shards_cross_many_chunk_boundaries(gpu, oracle, tmp_path):
+    """shards that are no multiple of the harness chunk, of a tile or of the decimation group (the last one takes the
+    remainder), each many chunks long: the stitched file is the concatenation of the oracle's shard outputs"""
+    shards, n = 3, 3 * 777_777 + 5
+    raw = synth.raw_stream(n, 2.4e6, 21, "cs16")
+    fin, fout = tmp_path / "in.cs16", tmp_path / "out.cs16"
+    raw.tofile(fin)
+    info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", str(shards), "--devices", "1", "--chunk-frames", "49152")
+    per = n // shards
+    bounds = [(s * per, n if s == shards - 1 else (s + 1) * per) for s in range(shards)]
+    int_close(np.fromfile(fout, np.int16), np.concatenate(oracle_shards(oracle, raw, bounds, NRSC5)))
+    assert info["shards"] == shards and info["frames_in"] == n
 
 
 def test_harness_filter_options(gpu, tmp_path):
@@ -111,7 +140,7 @@ def test_harness_shards_on_non_decimating_chains(gpu, tmp_path, name, kw, extra)
         assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1
 
 
-def test_harness_shards_over_all_visible_devices(gpu, tmp_path):
+def test_harness_shards_over_all_visible_devices(gpu, oracle, tmp_path):
     """--shards K --devices min(K, device_count): one chain per GPU, outputs stitched in shard order (no collective)"""
     ndev = gpu.load().iqgpu_device_count()
     shards = 4
@@ -121,7 +150,9 @@ def test_harness_shards_over_all_visible_devices(gpu, tmp_path):
     raw.tofile(fin)
     info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", str(shards), "--devices", str(min(shards, ndev)), "--chunk-frames", "131072")
     got = np.fromfile(fout, np.int16)
-    parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 400_000:2 * (s + 1) * 400_000]) for s in range(shards)]
+    bounds = [(s * 400_000, (s + 1) * 400_000) for s in range(shards)]
+    int_close(got, np.concatenate(oracle_shards(oracle, raw, bounds, NRSC5)))
+    parts = [gpu.Chain(**NRSC5).process(raw[2 * a:2 * b]) for a, b in bounds]
     assert np.array_equal(got, np.concatenate(parts))
     assert info["shards"] == shards
 
@@ -205,7 +236,7 @@ def test_bench_two_ranks_share_the_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-frames", "22",
-                        "--settle-seconds", "0.2", "--no-cpu-baseline", "--no-host-leg", "--no-secondary --no-extra"],
+                        "--settle-seconds", "0.2", "--no-cpu-baseline", "--no-host-leg", "--no-secondary", "--no-extra"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]

@@ -363,6 +363,39 @@ def test_design_out_frames_is_the_oracles_count(kw):
         assert got.value == out.size // obpf, (n, got.value, out.size // obpf)
 
 
+def test_shard_plan_at_the_real_sizes_of_configs4():
+    """BASELINE configs[4] as written: 8 independent 10 GB raw cs16 shards = 2.5 G frames each (beyond 2^31), the NRSC-5
+    chain.  The harness places shard s at the sum of iqgpu_design_out_frames of the shards before it (iqgpu_run.c): the
+    closed form of the resampler law in Python integers must give the same counts and offsets -- no 32-bit step anywhere
+    (src/output_raw_file.c:146-184 writes what it is handed; the counts are resampler.c's)."""
+    import iq_tool_amd
+    from iq_tool_amd.chain import make_desc
+    lib = iq_tool_amd.load()
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+    d = make_desc(**kw)
+    info = iq_tool_amd._lib.ChainInfo()
+    assert lib.iqgpu_design_probe(C.byref(d), C.byref(info), None, 0, None, 0, None, 0) == 0
+    S, step = int(info.num_halfband_stages), int(info.arb_step)
+    assert S == 1 and step == 27053208                              # SPEC B.6: NRSC-5
+    total = 8 * 2_500_000_000 + 12_345                              # a ragged tail on the last shard
+    per = total // 8
+    offsets, off = [], 0
+    for s in range(8):
+        frames = total - s * per if s == 7 else per
+        got = C.c_size_t(0)
+        assert lib.iqgpu_design_out_frames(C.byref(d), frames, C.byref(got)) == 0
+        groups = frames >> S                                        # a fresh shard: rem = 0, phi = 0
+        want = -(-(groups << 24) // step)                           # ceil(G 2^24 / step), exact in Python ints
+        assert got.value == want, (s, frames, got.value, want)
+        assert frames > 2**31 and want > 2**29
+        offsets.append(off); off += want * 4
+    assert offsets[1] == 4 * (-(-((per >> 1) << 24) // step)) and off > 2**34      # byte offsets beyond 16 GiB
+    # the whole job as ONE stream emits at most a frame per shard boundary more or fewer (each shard restarts the phase)
+    one = C.c_size_t(0)
+    assert lib.iqgpu_design_out_frames(C.byref(d), total, C.byref(one)) == 0
+    assert abs(one.value - off // 4) <= 8
+
+
 @pytest.mark.parametrize("kw", [
     dict(input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=1024),
     dict(input_rate_hz=61.44e6, target_rate_hz=1488375.0, filters=(("lowpass", 300e3, 0.0),), filter_taps=4097, filter_impl="fir"),
