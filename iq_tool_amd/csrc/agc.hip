@@ -215,9 +215,12 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
                 const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
                 const float outp = pk * st.gain;
                 const float lower = a.target * kAgcLower;
-                // k_front_mid keeps max |y|^2 in float (1.5 ulp of the exact value the unfused kernels and the reference's cabsf
-                // give): a chunk that close to either threshold is not judged here -- the exact kernels redo the call
-                const float tol = a.peak_approx ? 4.0e-7f : 0.0f;
+                // k_front_mid keeps max |y|^2 in float.  Error budget of `outp` against the exact kernels' (and the reference's cabsf):
+                // m2 = fmaf(x, x, y y) is off by at most 1.5 ulp of a float (two roundings) = 1.8e-7 relative, the square root halves
+                // that, the cast of the root and the product with the gain round once more each in BOTH paths (2 x 6e-8 apart at
+                // worst): < 2.2e-7 relative in all.  A chunk within 8 FLT_EPSILON = 9.5e-7 (relative, at either threshold: more than
+                // four times the budget) is not judged here -- the exact kernels redo the call
+                const float tol = a.peak_approx ? 8.0f * 1.1920929e-7f : 0.0f;
                 if (outp > 1.0f - tol) bad = 1;                    // ratchet (or too close to call)
                 else if (a.peak_approx && fabsf(outp - lower) <= tol * lower) bad = 1;
                 else if (outp > lower) { k = 1; last_h = c; }
