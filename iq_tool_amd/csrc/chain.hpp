@@ -245,6 +245,8 @@ struct Call {
     bool casc, fast_s0, fast_s1;             // which front path runs
     bool fat = false;                        // fast_s1 as k_front_fat (front_fat.hip): 8 waves per CU, 1024-frame tiles
     bool mid = false;                        // ... or as k_front_mid (front_mid.hip): 12 waves per CU, 768-frame tiles
+    bool s2 = false;                         // casc with both stages fused into k_front_s2 (front_s2.hip); cplan is then the LAST stage's plan
+    int64_t s2_in_tiles = 0;                 //   ... and this the number of 512-frame input tiles of the call
     int wtile, casc_K, rem_k;
     float iq_mag = 0.0f, iq_phase = 0.0f;    // the correction factors this call applies (snapshot under aux_mu)
     bool agc_fused = false;                  // this call: gain applied in the front kernel, verified behind it

@@ -162,10 +162,16 @@ __device__ __forceinline__ double wave_max_d(double m)
     return m;
 }
 
-template <int BPS, bool EDGE, bool FAST, bool S0, bool AGC = false, bool NONCO = false>
+// FEED (k_front_s2, front_s2.hip): the tile's samples do not come from memory but from an earlier stage of the SAME wave --
+// feed->produce(t, x) leaves sample 256 c + 4 lane + s of tile t in x[c][s] (what unpack_chunk delivers for cf32 input)
+struct NoFeed { __device__ void produce(int64_t, cf2 (&)[2][4]) {} };
+template <int BPS, bool EDGE, bool FAST, bool S0, bool AGC = false, bool NONCO = false, typename FEED = NoFeed>
 __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, const int lane,
-                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg)
+                                          const int64_t t_begin, const int64_t t_emit0, const int64_t t_emit1, const int seg,
+                                          FEED *const feed = nullptr)
 {
+    constexpr bool kFeed = !__is_same(FEED, NoFeed);
+    static_assert(!kFeed || (!EDGE && !FAST && !S0 && BPS == 8), "a feeder stands in for the cf32 vector loads of a streaming run");
     // dc blocker (never in the FAST instantiation): wave-uniform state, carries per run as in k_cascade
     float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
     bool dc_started = false;
@@ -214,7 +220,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
             }
         }
     };
-    if (!EDGE) {
+    if (!EDGE && !kFeed) {
         const char *src = (const char *)a.raw + (t_begin * TILE - a.rem0) * VB + 4 * VB * lane;
         load_chunk<VB, IQGPU_NT_S1 != 0>(src, nxt[0]);
         if (NC == 2) load_chunk<VB, IQGPU_NT_S1 != 0>(src + 256 * VB, nxt[1]);
@@ -298,7 +304,10 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
 
         // ------------------------------------------------------------ pointwise -> LDS
         cf2 x[2][4];
-        if (!EDGE) {
+        if (kFeed) {
+            if (defer || defer_f) flush_pending();
+            feed->produce(t, x);
+        } else if (!EDGE) {
             // consume the prefetched frames first: the wait for them lands here, before the next
             // tile's loads are issued, so those stay in flight across the whole tile
             if (FAST) {

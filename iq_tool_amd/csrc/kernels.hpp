@@ -62,7 +62,8 @@ struct cd2 { double x, y; };
 // ---------------------------------------------------------------------------------------------
 // diagnostic switches (IQGPU_NO_FAST, IQGPU_AGC_NOFUSE, IQGPU_NO_RAW0, IQGPU_NO_KT, IQGPU_FFT_NO_R16): read from the
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
-enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u };
+enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u,
+                  kDbgNoS2 = 512u };       // IQGPU_NO_S2=1: two-stage chains keep k_cascade + k_front_s1 instead of the fused k_front_s2
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
@@ -230,6 +231,11 @@ int front_mid_tile(int nl);              // its tile: 128 nl frames
 // the half-wave's bank pairs prices lower, the fold's two extra instructions per slot counted)
 int front_tap_fold(uint32_t step, int nl);
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
+// two-stage chains (S = 2) with both half-bands and the polyphase in one kernel (front_s2.hip): a1 = the chain as k_cascade sees
+// it (K = 1), a2 = the last stage as k_front_s1 sees it, planned in ITS tiles (512 intermediate samples = 1024 input frames)
+int front_s2_waves();
+bool front_s2_shape(const FrontArgs &a1);          // needs casc_K, m[0], in_fmt
+hipError_t launch_front_s2(const FrontArgs &a1, const FrontArgs &a2, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most
 // wave_slots runs in all (edge runs included) when fixed_tpw == 0, else streaming runs of fixed_tpw tiles
 void plan_front_s1(FrontArgs &a, int64_t wave_slots, int fixed_tpw, int warm_tiles, int edge_tiles_per_wave, int tile_frames = kWTile, int align = 1, int lead = 0);

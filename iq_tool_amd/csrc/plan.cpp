@@ -163,6 +163,27 @@ void Call::plan_geometry()
             warm = (int)((c->rp.history_in + wtile - 1) / wtile); if (warm < 1) warm = 1;
             plan_front_s1(cplan, wave_slots(front_s1_waves(cplan)), fixed_tpw(), warm, 1, wtile);
         }
+        // S == 2: both stages in ONE kernel (k_front_s2, front_s2.hip), planned in tiles of the LAST stage -- 512 intermediate samples
+        // = 1024 input frames -- on the intermediate stream's own geometry.  Its streaming waves read the input as whole 16-byte
+        // words from the start of a decimation group; calls that do not start on one, or are shorter than the histories they have
+        // to leave behind, keep the two kernels (same bytes either way).
+        s2 = false;
+        const int64_t n_mid = (int64_t)frames_in >> 1;
+        if (casc && casc_K == 1 && c->rem == 0 && cplan.raw_aligned && !agc_fused && !(c->dbg & kDbgNoS2) && front_s2_shape(cplan) &&
+            (int64_t)frames_in >= (int64_t)c->hist_cap && n_mid >= (int64_t)c->hist2_cap) {
+            FrontArgs p2{};
+            p2.frames_in = n_mid; p2.rem0 = 0; p2.hist_cap = c->hist2_cap; p2.in_fmt = IQGPU_FMT_CF32; p2.out_fmt = filt ? (int)IQGPU_FMT_CF32 : fin_fmt;
+            p2.raw_aligned = 1;
+            p2.w_total_tiles = (n_mid + kWTile - 1) / kWTile;
+            plan_front_s1(p2, wave_slots(front_s2_waves()), fixed_tpw(), 1, 1);
+            s2 = true;
+            const FrontArgs keep = cplan;
+            cplan = p2;                                    // the run geometry everything else reads (dc carries included)
+            cplan.casc_K = keep.casc_K; cplan.m[0] = keep.m[0]; cplan.dbg = keep.dbg;
+            s2_in_tiles = ((int64_t)frames_in + kWTile - 1) / kWTile;
+            wtile = 2 * kWTile;                            // input frames per tile of the plan
+            rem_k = 0;
+        }
     }
 }
 

@@ -155,8 +155,11 @@ int Call::stage_front()
         a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
         a1.casc_wave_lds = (int)cascade_wave_lds(a1);
         a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
-        copy_plan(a1);
-        { KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream)); }
+        if (s2) a1.w_total_tiles = s2_in_tiles;          // (the fused kernel is planned in the last stage's tiles: cplan is a2's)
+        else {
+            copy_plan(a1);
+            KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream));
+        }
         // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
         if (n_mid > 0) {
             FrontArgs a2{};
@@ -172,7 +175,8 @@ int Call::stage_front()
             a2.out_fmt = a.out_fmt; a2.out = a.out;
             a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
             a2.agc_fused = agc_fused ? 1 : 0;
-            plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 1);
+            if (s2) copy_plan(a2);
+            else plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 1);
             for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
             a2.sink = c->d_sink;
             if (agc_fused) {
@@ -180,7 +184,7 @@ int Call::stage_front()
                 a2.agc_chunk_frames = c->agc_chunk; a2.agc_shift = c->S; a2.agc_rem = c->rem;
                 HIP_TRY(clean_agc_peaks());
             }
-            { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_front_s1(a2, c->stream)); }
+            { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(s2 ? launch_front_s2(a1, a2, c->stream) : launch_front_s1(a2, c->stream)); }
             if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a2); if (rc) return rc; }
             c->hist2_cur ^= 1;
         }
@@ -209,7 +213,7 @@ int Call::stage_front()
     }
     if (c->decim) c->hist_cur ^= 1;
     snprintf(c->front_kernel, sizeof(c->front_kernel), "%s",
-             casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? (c->nco_mode ? "k_front_mid<6,nco>" : "k_front_mid<6,nonco>")
+             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? (c->nco_mode ? "k_front_mid<6,nco>" : "k_front_mid<6,nonco>")
              : fast_s1 ? "k_front_s1" : c->late ? "k_front+k_interp" : "k_front");
     return IQGPU_OK;
 }

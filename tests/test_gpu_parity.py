@@ -969,6 +969,67 @@ def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatc
     int_close(fast[:want.size], want, min_same=0.998)
 
 
+@pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,extra", [
+    ("cs16", 10e6, 2.4e6, "cs16", dict(dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005)),   # BASELINE configs[2] in front of its filter
+    ("cs16", 10e6, 2.4e6, "cf32", dict(shift_hz=250e3)),                              # a mixer in front, cf32 out
+    ("cs16", 10e6, 2.4e6, "cs16", dict(shift_hz=-1.1e6, shift_after_resample=True)),  # the mixer behind the resampler
+    ("cu8", 10e6, 1488375.0, "cu8", dict()),                                          # 8-bit frames, 2-byte output
+    ("cs16", 2.4e6, 420e3, "cs16", dict(gain=0.5, dc_block=True)),                   # another ratio of the S = 2 band, a gain
+    ("cf32", 8e6, 1.3e6, "cs16", dict(shift_hz=1e5)),                                 # 8-byte frames
+    ("cs16", 10e6, 2.4e6, "cs16", dict(dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005,
+                                        filters=(("passband", 158.5e3, 113e3),), filter_taps=1024)),           # configs[2] whole
+])
+def test_two_stage_chain_in_one_kernel_equals_the_two_kernel_path(gpu, oracle, monkeypatch, in_format, in_rate, out_rate, out_format, extra):
+    """k_front_s2 (front_s2.hip: both half-bands and the polyphase of an S = 2 chain in one wave-autonomous kernel, the intermediate
+    stream never leaving the wave) against k_cascade + k_front_s1 (IQGPU_NO_S2=1): stage 0 is k_cascade's casc_stage on its row
+    layout, the rest is k_front_s1's own tile routine fed from registers -- same products in the same order, so the BYTES are
+    equal, over aligned calls (fused), a ragged one in between (the stream falls back to the two kernels and returns) and a
+    reset; the dc-blocker carries differ by rounding only (another run geometry), so with a dc blocker the bar is the oracle's."""
+    n = (1 << 22) + 4 * 777
+    if in_format == "cf32":
+        raw = synth.complex_signal(n, in_rate, 41).view(np.float32)
+    else:
+        raw = synth.raw_stream(n, in_rate, 41, in_format)
+    per = raw.size // n
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=in_rate, target_rate_hz=out_rate, **extra)
+    cuts = [0, 1 << 21, (1 << 21) + 40_000, (1 << 21) + 40_000 + 131_073, (1 << 21) + 40_000 + 131_073 + 262_147, n]
+    cuts[-2] = cuts[-2] + (-cuts[-2]) % 4                # back on a group boundary for the last call
+
+    def run():
+        ch = gpu.Chain(**kw)
+        parts, kernels = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            parts.append(ch.process(raw[per * a:per * b])); kernels.append(ch.front_kernel())
+        ch.reset()
+        parts.append(ch.process(raw[:per * (1 << 20)])); kernels.append(ch.front_kernel())
+        return np.concatenate(parts), kernels
+
+    fused, kf = run()
+    assert kf[0] == "k_front_s2" and kf[1] == "k_front_s2" and kf[-1] == "k_front_s2", kf
+    assert "k_cascade+k_front_s1" in kf                  # the ragged call left the stream off a group boundary
+    monkeypatch.setenv("IQGPU_NO_S2", "1")
+    two, kt = run()
+    monkeypatch.delenv("IQGPU_NO_S2")
+    assert all(k == "k_cascade+k_front_s1" for k in kt), kt
+    assert fused.size == two.size
+    if extra.get("dc_block"):
+        if fused.dtype == np.float32:
+            assert np.abs(fused - two).max() <= 2e-6
+        else:
+            assert np.abs(fused.astype(np.int64) - two.astype(np.int64)).max() <= 1
+    else:
+        assert np.array_equal(fused, two), (int((fused != two).sum()), int(np.flatnonzero(fused != two)[0]))
+    okw = dict(kw)
+    if okw.get("filter_taps", 0) % 2 == 0 and okw.get("filter_taps", 0):
+        okw["filter_taps"] += 1                          # src/config.c:233-236 (the library does it inside create)
+    och = oracle.Chain(**okw)
+    want = np.concatenate([och.process(raw[per * a:per * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    if fused.dtype == np.float32:
+        assert np.abs(fused[:want.size] - want).max() <= TOL
+    else:
+        int_close(fused[:want.size], want, min_same=0.995 if extra.get("filters") else 0.998)
+
+
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
 def test_one_stage_chain_all_input_formats(gpu, oracle, fmt):
     """the fast path's vector loaders (2, 4, 8 bytes per frame) and its scalar fallback"""
