@@ -235,11 +235,11 @@ __device__ __forceinline__ void casc_tiles(const FrontArgs &a, const CascLds &w,
     const int K = KT ? KT : a.casc_K;
     auto stage_m = [&](int k) { return KT ? (k == KT - 1 ? 5 : 3) : a.m[k]; };
     // dc blocker (SPEC B.5): v[n] = x[n] + c v[n-1], y[n] = x[n] - (1 - c) v[n-1]; v carried as a wave-uniform pair
-    float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
+    float dc_vr = 0.0f, dc_vi = 0.0f;
+    DcLane lane_pow{1.0f, 1.0f, 1.0f};                     // c^(4 lane) and the scan's cross-row weights
     bool dc_started = false;
     if (a.dc_enable) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
+        lane_pow = dc_lane_init(a, lane);
     }
     const bool unit_gain = a.gain == 1.0f;
     char *XE0 = w.XE[0], *XO0 = w.XO[0];

@@ -46,7 +46,8 @@ struct S2Feed {
     int lane, seg;
     RawChunk nxt[2];
     v2f cs_n[2][4];
-    float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f, se = 0.0f, so = 0.0f;
+    float dc_vr = 0.0f, dc_vi = 0.0f, se = 0.0f, so = 0.0f;
+    DcLane lane_pow{1.0f, 1.0f, 1.0f};
     bool unit_gain, nco_on, dc_started = false;
 
     __device__ __forceinline__ S2Feed(const FrontArgs &a_, const cf2 *nco_, char *slice0, int lane_, int seg_)
@@ -54,10 +55,7 @@ struct S2Feed {
     {
         unit_gain = a.gain == 1.0f;
         nco_on = a.nco_mode != 0;
-        if (a.dc_enable) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
-        }
+        if (a.dc_enable) lane_pow = dc_lane_init(a, lane);
     }
     __device__ __forceinline__ void lookup(int64_t first_frame)
     {

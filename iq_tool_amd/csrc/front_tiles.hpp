@@ -173,11 +173,11 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     constexpr bool kFeed = !__is_same(FEED, NoFeed);
     static_assert(!kFeed || (!EDGE && !FAST && !S0 && BPS == 8), "a feeder stands in for the cf32 vector loads of a streaming run");
     // dc blocker (never in the FAST instantiation): wave-uniform state, carries per run as in k_cascade
-    float dc_vr = 0.0f, dc_vi = 0.0f, lane_pow = 1.0f;      // lane_pow = c^(4 lane)
+    float dc_vr = 0.0f, dc_vi = 0.0f;
+    DcLane lane_pow{1.0f, 1.0f, 1.0f};                     // c^(4 lane) and the scan's cross-row weights
     bool dc_started = false;
     if (!FAST && a.dc_enable) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) if (lane & (1 << k)) lane_pow *= a.dc_cpow[k];
+        lane_pow = dc_lane_init(a, lane);
     }
     constexpr int VB = BPS ? BPS : 4;
     constexpr int NC = S0 ? 1 : 2;                  // 256-frame chunks per tile: S0 = no half-band stage, a tile

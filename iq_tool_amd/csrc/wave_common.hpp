@@ -214,10 +214,34 @@ __device__ __forceinline__ cf2 cmul_tab(cf2 x, cf2 cs)
     return y;
 }
 
+// Per-lane constants of the dc-blocker scan: c^(4 lane), and the weights of the two cross-row steps.
+struct DcLane { float pw, wa, wb; };
+__device__ __forceinline__ DcLane dc_lane_init(const FrontArgs &a, int lane)
+{
+    DcLane d{1.0f, 1.0f, 1.0f};
+    const int ia = (lane & 15) + 1, ib = lane - 31;          // c^(4 ia): from lane 15 of the row before; c^(4 ib): from lane 31
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (lane & (1 << k)) d.pw *= a.dc_cpow[k];
+        if (ia & (1 << k)) d.wa *= a.dc_cpow[k];
+        if (ib > 0 && (ib & (1 << k))) d.wb *= a.dc_cpow[k];
+    }
+    return d;
+}
+template <int CTRL, int ROW_MASK, bool BOUND0>
+__device__ __forceinline__ float dpp_f(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, BOUND0));
+}
+
 // DC blocker over one 256-frame chunk (lane: frames 4 lane .. 4 lane + 3).  hist: bit s set = frame s is an
 // already-processed history frame (enters the recurrence as zero and is left untouched).
 // (vr, vi) = v[n-1] at the chunk's first frame on entry, at the next chunk's first frame on exit.
-__device__ __forceinline__ void dc_chunk(const FrontArgs &a, int lane, float lane_pow, cf2 x[4], unsigned hist, float &vr, float &vi)
+// The scan over the 64 lanes -- B_l = sum_{j <= l} c^(4 (l - j)) b_j -- runs on DPP moves (round 4; until then six ds_bpermute
+// pairs with their index arithmetic, 16 LDS-crossbar operations per chunk: two thirds of this function's instructions):
+// four row_shr steps inside the rows of 16 (lanes without a source read 0), then lane 15 of rows 0 / 2 into rows 1 / 3
+// (row_bcast15) and lane 31 into rows 2 / 3 (row_bcast31), each weighted by the distance to the receiving lane.
+__device__ __forceinline__ void dc_chunk(const FrontArgs &a, int lane, const DcLane &dl, cf2 x[4], unsigned hist, float &vr, float &vi)
 {
     const float cc = a.dc_c, aa = a.dc_a;
     cf2 xd[4];
@@ -226,16 +250,16 @@ __device__ __forceinline__ void dc_chunk(const FrontArgs &a, int lane, float lan
     float br = xd[0].x, bi = xd[0].y;
 #pragma unroll
     for (int s = 1; s < 4; ++s) { br = fmaf(br, cc, xd[s].x); bi = fmaf(bi, cc, xd[s].y); }
-    // inclusive scan over the 64 lanes: B_l += c^(4*2^k) B_(l-2^k)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float ur = __shfl_up(br, 1 << k), ui = __shfl_up(bi, 1 << k);
-        if (lane >= (1 << k)) { br = fmaf(a.dc_cpow[k], ur, br); bi = fmaf(a.dc_cpow[k], ui, bi); }
-    }
-    float er = __shfl_up(br, 1), ei = __shfl_up(bi, 1);           // exclusive
-    if (lane == 0) { er = 0.0f; ei = 0.0f; }
-    const float tr = __shfl(br, 63), ti = __shfl(bi, 63);         // the chunk's aggregate
-    float sr = fmaf(lane_pow, vr, er), si = fmaf(lane_pow, vi, ei);   // v[n-1] of the lane's first frame
+    br = fmaf(a.dc_cpow[0], dpp_f<0x111, 0xf, true>(0.0f, br), br); bi = fmaf(a.dc_cpow[0], dpp_f<0x111, 0xf, true>(0.0f, bi), bi);   // row_shr:1
+    br = fmaf(a.dc_cpow[1], dpp_f<0x112, 0xf, true>(0.0f, br), br); bi = fmaf(a.dc_cpow[1], dpp_f<0x112, 0xf, true>(0.0f, bi), bi);   // row_shr:2
+    br = fmaf(a.dc_cpow[2], dpp_f<0x114, 0xf, true>(0.0f, br), br); bi = fmaf(a.dc_cpow[2], dpp_f<0x114, 0xf, true>(0.0f, bi), bi);   // row_shr:4
+    br = fmaf(a.dc_cpow[3], dpp_f<0x118, 0xf, true>(0.0f, br), br); bi = fmaf(a.dc_cpow[3], dpp_f<0x118, 0xf, true>(0.0f, bi), bi);   // row_shr:8
+    br = fmaf(dl.wa, dpp_f<0x142, 0xa, false>(0.0f, br), br);       bi = fmaf(dl.wa, dpp_f<0x142, 0xa, false>(0.0f, bi), bi);         // row_bcast15 -> rows 1, 3
+    br = fmaf(dl.wb, dpp_f<0x143, 0xc, false>(0.0f, br), br);       bi = fmaf(dl.wb, dpp_f<0x143, 0xc, false>(0.0f, bi), bi);         // row_bcast31 -> rows 2, 3
+    const float er = dpp_f<0x138, 0xf, true>(0.0f, br), ei = dpp_f<0x138, 0xf, true>(0.0f, bi);                                         // wave_shr:1: exclusive
+    const float tr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, br), 63));                            // the chunk's aggregate
+    const float ti = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bi), 63));
+    float sr = fmaf(dl.pw, vr, er), si = fmaf(dl.pw, vi, ei);         // v[n-1] of the lane's first frame
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float yr = fmaf(-aa, sr, xd[s].x), yi = fmaf(-aa, si, xd[s].y);
