@@ -240,7 +240,7 @@ def step_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
     14 taps per output).  The user filter twice: `direct` as the direct form it is specified as (what liquid's firfilt
     executes and SURVEY 8d counts), `executed` as the overlap-save block convolution the product runs for filters of
     96 taps and more (two N-point transforms at 5 N log2 N plus the N-point product per N - L + 1 outputs, N by the rule
-    of iqgpu_api.cpp).  Returns (executed, direct)."""
+    of abi.cpp).  Returns (executed, direct)."""
     f = frames * (2.0 + (6.0 if desc_kw.get("shift_hz") else 0.0) + (8.0 if desc_kw.get("dc_block") else 0.0)
                   + (3.0 if desc_kw.get("iq_correct") else 0.0))
     for i in range(info.num_halfband_stages):

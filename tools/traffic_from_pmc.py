@@ -48,7 +48,7 @@ def one(out, cfg):
 def main():
     out = sys.argv[1]
     head = one(out, "2")
-    res = dict(kernel="k_front_mid<6, false, 4, 0, false>", kernel_sha=bench.kernel_sha(), all_sources_sha=bench.all_sources_sha(), log2_frames=28,
+    res = dict(kernel="k_front_mid<6, false, 4, 0, false, false>", kernel_sha=bench.kernel_sha(), all_sources_sha=bench.all_sources_sha(), log2_frames=28,
                rule="2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per step, separate --pmc passes (tools/profile_round.sh)")
     if head:
         res.update(head)
