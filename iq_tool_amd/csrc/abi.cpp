@@ -73,7 +73,7 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_hfreq) (void)hipFree(c->d_hfreq);
     if (c->d_ihb) (void)hipFree(c->d_ihb);
     if (c->d_agc_state) (void)hipFree(c->d_agc_state);
-    c->abuf.release(); c->agc_peak.release(); c->agc_gain.release(); c->agc_peak_b.release();
+    c->abuf.release(); c->agc_peak.release(); c->agc_gain.release(); c->agc_peak_b.release(); c->agc_hist.release();
     if (c->d_agc_flag) (void)hipFree(c->d_agc_flag);
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
@@ -346,6 +346,12 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             fa.iq_enable = c->desc.iq_correct_enable ? 1 : 0; fa.dc_enable = c->dc ? 1 : 0;
             fa.nco_mode = c->nco_mode; fa.pnco_mode = c->pnco_mode; fa.agc_chunk_frames = c->agc_chunk; fa.agc_shift = c->S;
             if (c->cascade) { fa.S = 1; fa.in_fmt = IQGPU_FMT_CF32; }      // k_cascade in front: the last stage sees cf32, one half-band
+            if (c->agc_rms_alpha > 0.0f) {
+                int64_t chunk = 0; int32_t nch = 0;
+                agc_rms_geometry(c->agc_rms_alpha, 0, 0, &chunk, &c->agc_rms_warm, &nch);
+                CREATE_RC(c->agc_hist.ensure(((size_t)c->agc_rms_warm + 1) * sizeof(cf2)));
+                CREATE_TRY(hipMemset(c->agc_hist.p, 0, c->agc_hist.cap));
+            }
             c->agc_fusable = c->agc_rms_alpha == 0.0f && c->decim && !c->late && !c->force_generic && !c->fp.enabled &&
                              (c->cascade || c->S == 0 || (c->S == 1 && c->rp.stages[0].m == 10)) && front_s1_agc_fusable(fa);
         }
@@ -558,7 +564,7 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     { const int rc = pipe_advance(c, c->pipe_seq); if (rc && !c->poisoned) return rc; }   // batches in flight come first (same stream)
     c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
-    c->agc_locked_host = false; c->agc_seen_host = 0; c->agc_peak_clean = false;
+    c->agc_locked_host = false; c->agc_seen_host = 0; c->agc_peak_clean = false; c->agc_rms_pos = 0;
     HIP_TRY(hipMemsetAsync(c->d_dc_state, 0, sizeof(cd2), c->stream));
     if (c->agc) { // agc_reset, src/agc.c:224-238
         c->agc_init.last_strong = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0;

@@ -318,13 +318,20 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
 // a nonlinear recurrence with no closed form across samples.  What makes it parallel is that it FORGETS:
 // linearised around its fixed point the state error decays like (1 - alpha / 2)^n, so a lane that starts
 // `warm` = 40 / alpha samples early from ANY state arrives within 2e-9 of the true one.
-//   k_agc_rms_spec: one LANE per chunk of the call's output.  Chunks that begin within `warm` samples of the
-//       call's start run from the carried state at sample 0 (exact); the others from a guess `warm` samples
-//       ahead of their first output.  Each lane records the state it arrived with and the state it left.
+//   The chunk grid belongs to the STREAM, not to the call (round 4): chunk k covers stream positions [k C, (k + 1) C), and
+//   what a lane does depends on positions and samples only, never on where the calls were cut -- the output is the same
+//   under ANY split of the stream into calls, byte for byte (test_agc_rms_is_split_invariant).
+//   k_agc_rms_spec: one LANE per chunk that overlaps the call.  A chunk that began in an earlier call continues from the
+//       carried state.  Every other chunk starts `warm` samples ahead of its first output -- in the history the chain
+//       keeps of the AGC's input (the last `warm` samples of earlier calls) where that lies before the call -- from a
+//       guess made of those samples alone (gain = 1 / rms of the first 32, unit energy); within `warm` samples of the
+//       last reset it starts AT the reset, from the reset state (exact).  Each lane records the state it arrived with
+//       and the state it left.
 //   k_agc_rms_fix:  checks, in parallel, that every chunk arrived where its predecessor left (2e-6 relative
-//       in gain and energy); if one did not -- a silent stretch freezes the gain (p <= 1e-6) and with it the
-//       guess -- one lane re-runs the stream from there until the states meet again.  Then stores the
-//       stream state.
+//       in gain and energy; the first chunk's predecessor is the carried state); if one did not -- a silent stretch
+//       freezes the gain (p <= 1e-6) and with it the guess -- one lane re-runs the stream from there until the states
+//       meet again.  Then stores the stream state.  (The sequential BITS are out of reach of any parallel scheme:
+//       tools/agc_merge_probe.c)
 // Unpinned like every liquid operator (DESIGN SPEC): parity with the oracle's restatement (glibc expf / logf) to 2e-5.
 // ---------------------------------------------------------------------------------------------
 struct RmsSt { float g, p; };
@@ -415,17 +422,30 @@ __device__ __forceinline__ void rms_run(const AgcRmsArgs &a, int64_t i0, int64_t
 
 __global__ __launch_bounds__(64) void k_agc_rms_spec(const AgcRmsArgs a)
 {
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.n_chunks) return;
-    const int64_t s = c * a.chunk, e = (s + a.chunk < a.n) ? s + a.chunk : a.n;
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= a.n_chunks) return;
+    const int64_t abs_s = (a.pos0 / a.chunk + j) * a.chunk;                              // the chunk's first stream position
+    const int64_t s = (abs_s > a.pos0 ? abs_s : a.pos0) - a.pos0;                        // ... and its part in this call: x[s .. e)
+    const int64_t e = (abs_s + a.chunk < a.pos0 + a.n ? abs_s + a.chunk : a.pos0 + a.n) - a.pos0;
     const float han = -0.5f * a.alpha;
     RmsSt st{a.state->gain, a.state->peak_memory};
-    int64_t i = 0;
-    if (s > a.warm) { i = s - a.warm; st.p = 1.0f; }            // a guess: the call's first gain, unit energy
-    rms_run<false>(a, i, s, st, han);
-    a.st[4 * c + 0] = st.g; a.st[4 * c + 1] = st.p;
+    if (abs_s >= a.pos0) {                                   // the chunk begins in this call: a trajectory of its own
+        const int64_t a0 = abs_s - a.warm;
+        int64_t i;
+        if (a0 <= 0) { i = -a.pos0; st.g = 1.0f; st.p = 1.0f; }      // from the reset, in the reset state (agc_reset: src/agc.c:227-229)
+        else {
+            i = a0 - a.pos0;                                 // >= -warm = -hist_valid here
+            float m = 0.0f;
+            for (int k = 0; k < 32; ++k) { const cf2 v = a.x[i + k]; m = fmaf(v.x, v.x, fmaf(v.y, v.y, m)); }
+            m *= 1.0f / 32.0f;
+            st.g = m > 1e-20f ? fminf(1.0f / sqrtf(m), 1e6f) : 1.0f;
+            st.p = 1.0f;
+        }
+        rms_run<false>(a, i, s, st, han);
+    }
+    a.st[4 * j + 0] = st.g; a.st[4 * j + 1] = st.p;
     rms_run<true>(a, s, e, st, han);
-    a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
+    a.st[4 * j + 2] = st.g; a.st[4 * j + 3] = st.p;
 }
 
 __device__ __forceinline__ bool rms_close(float a, float b) { return fabsf(a - b) <= 2e-6f * fmaxf(fabsf(a), fabsf(b)); }
@@ -435,15 +455,21 @@ __global__ __launch_bounds__(1024) void k_agc_rms_fix(const AgcRmsArgs a)
     __shared__ int first_bad;
     if (threadIdx.x == 0) first_bad = 0x7fffffff;
     __syncthreads();
-    for (int c = 1 + (int)threadIdx.x; c < a.n_chunks; c += 1024)
-        if (!rms_close(a.st[4 * c], a.st[4 * c - 2]) || !rms_close(a.st[4 * c + 1], a.st[4 * c - 1])) atomicMin(&first_bad, c);
+    const float g0 = a.state->gain, p0 = a.state->peak_memory;          // the predecessor of the call's first chunk
+    for (int c = (int)threadIdx.x; c < a.n_chunks; c += 1024) {
+        const float pg = c ? a.st[4 * c - 2] : g0, pp = c ? a.st[4 * c - 1] : p0;
+        if (!rms_close(a.st[4 * c], pg) || !rms_close(a.st[4 * c + 1], pp)) atomicMin(&first_bad, c);
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float han = -0.5f * a.alpha;
+    const int64_t k0 = a.pos0 / a.chunk;
     for (int64_t c = first_bad; c < a.n_chunks; ++c) {
-        RmsSt st{a.st[4 * c - 2], a.st[4 * c - 1]};                    // where the stream really is
+        RmsSt st{c ? a.st[4 * c - 2] : g0, c ? a.st[4 * c - 1] : p0};   // where the stream really is
         if (rms_close(a.st[4 * c], st.g) && rms_close(a.st[4 * c + 1], st.p)) continue;
-        const int64_t s = c * a.chunk, e = (s + a.chunk < a.n) ? s + a.chunk : a.n;
+        const int64_t abs_s = (k0 + c) * a.chunk;
+        const int64_t s = (abs_s > a.pos0 ? abs_s : a.pos0) - a.pos0;
+        const int64_t e = (abs_s + a.chunk < a.pos0 + a.n ? abs_s + a.chunk : a.pos0 + a.n) - a.pos0;
         rms_run<true>(a, s, e, st, han);
         a.st[4 * c + 2] = st.g; a.st[4 * c + 3] = st.p;
     }
@@ -454,14 +480,14 @@ __global__ __launch_bounds__(1024) void k_agc_rms_fix(const AgcRmsArgs a)
     }
 }
 
-void agc_rms_geometry(float alpha, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks)
+void agc_rms_geometry(float alpha, int64_t pos0, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks)
 {
     int64_t w = (int64_t)(40.0 / (double)alpha + 0.5);         // e^-20 of the guess's error is left
     w = (w + 1) & ~(int64_t)1;
     int64_t ch = w / 16; if (ch < 2048) ch = 2048;
     ch &= ~(int64_t)1;
     *warm = w; *chunk = ch;
-    *n_chunks = (int32_t)((n + ch - 1) / ch);
+    *n_chunks = n > 0 ? (int32_t)((pos0 + n + ch - 1) / ch - pos0 / ch) : 0;     // chunks of the stream's grid that overlap [pos0, pos0 + n)
 }
 
 hipError_t launch_agc_rms(const AgcRmsArgs &a, hipStream_t s)

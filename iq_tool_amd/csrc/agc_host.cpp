@@ -35,14 +35,23 @@ AgcArgs Call::agc_args() const
 int Call::stage_agc()
 {
     if (c->agc_rms_alpha > 0.0f) {
+        if (p.n_emit <= 0) return IQGPU_OK;
+        // abuf = [the last agc_rms_warm samples of earlier calls][this call's n_emit]: chunks of the stream's grid that begin early
+        // in this call warm up on the samples in front of it
+        const int64_t W = c->agc_rms_warm;
+        cf2 *const xin = (cf2 *)c->abuf.p + W;
         AgcRmsArgs ra{};
-        ra.x = (const cf2 *)c->abuf.p; ra.n = p.n_emit; ra.alpha = c->agc_rms_alpha; ra.state = c->d_agc_state;
-        agc_rms_geometry(ra.alpha, ra.n, &ra.chunk, &ra.warm, &ra.n_chunks);
+        ra.x = xin; ra.n = p.n_emit; ra.alpha = c->agc_rms_alpha; ra.state = c->d_agc_state;
+        ra.pos0 = (int64_t)c->agc_rms_pos; ra.hist_valid = ra.pos0 < W ? ra.pos0 : W;
+        agc_rms_geometry(ra.alpha, ra.pos0, ra.n, &ra.chunk, &ra.warm, &ra.n_chunks);
         int rc = c->agc_gain.ensure((size_t)(ra.n_chunks > 0 ? ra.n_chunks : 1) * 4 * sizeof(float)); if (rc) return rc;
         ra.st = (float *)c->agc_gain.p;
         ra.out_fmt = c->desc.out_format; ra.out = d_out;
         KernelTimer kt(c, IQGPU_K_AGC);
+        HIP_TRY(launch_copy_cf((cf2 *)c->abuf.p, (const cf2 *)c->agc_hist.p, W, c->stream));
         HIP_TRY(launch_agc_rms(ra, c->stream));
+        HIP_TRY(launch_copy_cf((cf2 *)c->agc_hist.p, xin + p.n_emit - W, W, c->stream));     // the last W of [history | new]
+        c->agc_rms_pos += (uint64_t)p.n_emit;
         return IQGPU_OK;
     }
     const AgcArgs ga = agc_args();

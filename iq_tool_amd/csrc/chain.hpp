@@ -137,6 +137,9 @@ struct iqgpu_chain {
     AgcState *d_agc_state = nullptr; AgcState agc_init{};
     float agc_rms_alpha = 0.0f;     // > 0: profile dx / local (liquid agc_crcf), AgcState.gain = g, .peak_memory = y2_prime
     DevBuf abuf, agc_peak, agc_gain, agc_peak_b;
+    // dx / local: the chunk grid of the parallel scheme belongs to the stream -- its position since the last reset, and the last
+    // `agc_rms_warm` samples of the AGC's input (what a chunk that begins early in the next call warms up on), agc.hip
+    DevBuf agc_hist; int64_t agc_rms_warm = 0; uint64_t agc_rms_pos = 0;
     // agc_peak is all zero: what a fused front launch needs (k_agc_classify hands it back zeroed, agc_peak_b too; the unfused kernels do not)
     bool agc_peak_clean = false;
     // fused AGC of the locked phase (k_front_s1<.., AGC> + k_agc_verify): which chains qualify, the host's mirror of

@@ -438,8 +438,10 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s);
 
 // RMS profiles dx / local (liquid agc_crcf): chunk-parallel with warm-up, then verified / repaired (agc.hip)
 struct AgcRmsArgs {
-    const cf2 *x;             // the call's output samples before the AGC (cf32)
+    const cf2 *x;             // the call's output samples before the AGC (cf32); x[-hist_valid .. -1] = the samples in front of them
     int64_t    n;
+    int64_t    pos0;          // stream position (samples since the last reset) of x[0]: the chunk grid is the STREAM's
+    int64_t    hist_valid;    // min(warm, pos0)
     float      alpha;         // loop bandwidth: AGC_DX_BANDWIDTH 1e-4, AGC_LOCAL_BANDWIDTH 1e-2
     AgcState  *state;         // gain = g, peak_memory = y2_prime
     int64_t    chunk, warm;   // outputs per lane; samples a speculative lane starts ahead
@@ -448,7 +450,7 @@ struct AgcRmsArgs {
     int32_t    out_fmt;
     void      *out;
 };
-void agc_rms_geometry(float alpha, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks);
+void agc_rms_geometry(float alpha, int64_t pos0, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks);
 hipError_t launch_agc_rms(const AgcRmsArgs &a, hipStream_t s);   // peak, scan, apply
 // after a fused launch of the front kernel: all chunks healthy at the unchanged gain -> state advanced, *verify_flag = 0;
 // otherwise state untouched and *verify_flag = 1 (the caller has queued the unfused kernels behind it, run_if = verify_flag)

@@ -82,7 +82,7 @@ int Call::prepare_buffers()
     }
     if (c->agc && c->agc_rms_alpha > 0.0f) {
         int64_t chunk, warm; int32_t n_chunks;
-        agc_rms_geometry(c->agc_rms_alpha, p.n_emit, &chunk, &warm, &n_chunks);
+        agc_rms_geometry(c->agc_rms_alpha, (int64_t)c->agc_rms_pos, p.n_emit, &chunk, &warm, &n_chunks);
         int rc = c->agc_gain.ensure((size_t)(n_chunks > 0 ? n_chunks : 1) * 4 * sizeof(float)); if (rc) return rc;
     } else if (c->agc) {
         const AgcGeom g = agc_geom();
@@ -333,8 +333,10 @@ static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
     k.fin_out = d_out; k.fin_fmt = c->desc.out_format;
     k.agc_fused = agc_fused;
     if (c->agc && !agc_fused) {
-        int rc = c->abuf.ensure(((size_t)k.p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
-        k.fin_out = c->abuf.p; k.fin_fmt = IQGPU_FMT_CF32;
+        // (dx / local: the AGC's input of earlier calls stands in front of this call's, see stage_agc)
+        const size_t lead = c->agc_rms_alpha > 0.0f ? (size_t)c->agc_rms_warm : 0;
+        int rc = c->abuf.ensure((lead + (size_t)k.p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
+        k.fin_out = (cf2 *)c->abuf.p + lead; k.fin_fmt = IQGPU_FMT_CF32;
     }
     k.plan_geometry();
     if (c->iq_pinned) { k.iq_mag = c->iq_pin_mag; k.iq_phase = c->iq_pin_phase; }                  // a pipelined batch: as of its submit()

@@ -625,6 +625,40 @@ def test_agc_rms_profiles_in_preset_chain(gpu, oracle, profile):
         assert st["samples_seen"] == och.agc.samples_seen
 
 
+@pytest.mark.parametrize("profile", ["local", "dx"])
+@pytest.mark.parametrize("out_format", ["cf32", "cs16"])
+def test_agc_rms_is_split_invariant(gpu, profile, out_format):
+    """dx / local under ANY split of the stream into calls give the same bytes and the same state (round 4): the chunk grid of the
+    parallel scheme is the stream's, a chunk that begins early in a call warms up on the AGC input the chain kept from earlier
+    calls, every guess is a function of samples alone (agc.hip).  One call against random cuts (odd lengths, one-frame calls,
+    calls shorter than a chunk and than the warm-up), a fade and a silent stretch in the signal (the repair pass runs), then
+    a reset and the same again."""
+    n = 2_400_000
+    rng = np.random.default_rng(77)
+    env = np.ones(n, np.float32)
+    env[600_000:900_000] = 0.05                          # a fade
+    env[1_500_000:1_700_000] = 0.0                       # digital silence: y2_prime falls below 1e-6, the gain freezes
+    x = synth.complex_signal(n, 2.4e6, 78) * env * np.float32(0.4)
+    raw = np.empty(2 * n, np.int16)
+    raw[0::2] = np.clip(np.round(x.real * 32767.0), -32768, 32767).astype(np.int16)
+    raw[1::2] = np.clip(np.round(x.imag * 32767.0), -32768, 32767).astype(np.int16)
+    kw = dict(NRSC5, out_format=out_format, agc=True, agc_profile=profile)
+    ch = gpu.Chain(**kw)
+    one = ch.process(raw)
+    st_one = ch.agc_state()
+    for trial in range(3):
+        cuts = sorted(set(int(v) for v in rng.integers(0, n, 9)) | {0, n})
+        if trial == 1:
+            cuts = sorted(set(cuts) | {1, 2, 5, 4097, n - 1})
+        if trial == 2:
+            cuts = list(range(0, n, 262144)) + [n]      # the binding's batches
+        ch.reset()
+        got = np.concatenate([ch.process(raw[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert got.size == one.size
+        assert np.array_equal(got, one), (trial, cuts, int((got != one).sum()), int(np.flatnonzero(got != one)[0]))
+        assert ch.agc_state() == st_one
+
+
 def test_agc_rms_silence_freezes_the_gain_and_the_repair_pass_runs(gpu, oracle):
     """a silent stretch drives y2_prime below 1e-6 and the gain stops moving: a lane that starts inside it from a
     guess can never find the true state, the verifier must catch that and re-run the stream from there"""
