@@ -12,8 +12,9 @@
  *     independent (one per GPU shard);
  *   - the stream is continuous across calls: any split of the input into calls produces the
  *     same output bytes (all in-scope operators are chunk-size invariant).  The
- *     one exception is the reference's own: the output AGC works chunk by chunk, so with
- *     agc_enable every call is cut into agc_chunk_frames-sized chunks from its first frame;
+ *     one exception is the reference's own: the "digital" output AGC works chunk by chunk, so with
+ *     that profile every call is cut into agc_chunk_frames-sized chunks from its first frame
+ *     (the "dx" / "local" profiles are per-sample loops: any split gives the same bytes);
  *   - nothing is flushed at end of stream (resampler / FIR tails and the FFT-filter remainder
  *     are dropped exactly as the reference drops them, src/filter.c:521-525);
  *   - frames_out may be 0 (resampler group buffering, FFT block quantisation);
