@@ -26,8 +26,8 @@ for cfg in 3 4 preset; do
   rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg$cfg" -o stats --output-format csv -- $TIMED --config $cfg > "$OUT/stats_cfg$cfg.log" 2>&1
   echo "stats cfg $cfg done"
 done
-# ---- counters of the headline kernel, three variants
-for v in mid fat s1; do
+# ---- counters of the headline kernel (PMC_VARIANTS: default all three)
+for v in ${PMC_VARIANTS:-mid fat s1}; do
   variant $v
   i=0
   for set in "${SETS[@]}"; do
@@ -59,7 +59,7 @@ done
   echo "# profiles/${TAG}_pmc_summary.txt -- rocprofv3 --pmc passes of \`$BENCH\` (BASELINE configs[1], 2^28 frames per launch),"
   echo "# one pass per counter set, never combined with tracing (tools/profile_round.sh); per-dispatch averages."
   echo "# Three kernels for the same chain: mid = k_front_mid (default), fat = k_front_fat (IQGPU_FAT=1), s1 = k_front_s1 (IQGPU_NO_FAT=1)."
-  for v in mid fat s1; do
+  for v in ${PMC_VARIANTS:-mid fat s1}; do
     echo "## variant $v"
     for p in "$OUT"/pmc_${v}_*/; do
       f=$(find "$p" -name '*counter_collection.csv' | head -1)
