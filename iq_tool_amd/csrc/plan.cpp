@@ -135,9 +135,13 @@ void Call::plan_geometry()
               ((c->dbg & kDbgForceFat) || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * kFatTile * wave_slots(front_fat_waves()));
         const int mid_nl = (!casc && !fast_s0) ? front_mid_nl(cplan) : 0;
         // (run descriptors hold tile indices in 32 bits)
+        // (k_front_mid from 6 tiles per wave on: measured round 4 at 2^21 .. 2^25 frames, kernel ms k_front_s1 / k_front_mid:
+        //  0.014 / 0.023, 0.017 / 0.023, 0.023 / 0.028, 0.039 / 0.036, 0.067 / 0.055 -- the crossover lies between 2^23 and 2^24 frames
+        //  = 3.6 and 7.1 tiles per wave; the pipelined host path's 2^24-frame batches now run the headline kernel)
+        constexpr int kMidMinTilesPerWave = 6;
         const bool mid_ok = mid_nl != 0 && (int64_t)frames_in < ((int64_t)1 << 40) &&
               ((c->dbg & kDbgForceFat)
-                  || (int64_t)frames_in >= (int64_t)kFatMinTilesPerWave * front_mid_tile(mid_nl) * wave_slots(front_mid_waves()));
+                  || (int64_t)frames_in >= (int64_t)kMidMinTilesPerWave * front_mid_tile(mid_nl) * wave_slots(front_mid_waves()));
         // (measured on one box, 2^28 frames: k_front_s1 0.437 ms, k_front_fat 0.404, k_front_mid 0.381: the 12-wave kernel is the
         //  default; IQGPU_FAT=1 selects the 8-wave one where its step class applies)
         fat = fat_ok && ((c->dbg & kDbgUseFat) || !mid_ok);

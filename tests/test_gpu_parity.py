@@ -955,15 +955,22 @@ def test_mid_kernel_run_stealing_keeps_the_bytes(gpu, monkeypatch, weights, stea
 
 
 def test_fat_kernel_takes_long_calls_by_itself(gpu):
-    """without any switch: a 2^25-frame call runs k_front_fat (the profile names the kernel), a 2^20-frame one k_front_s1, and
-    the stream continues across the change of kernel"""
+    """without any switch: a long call runs k_front_mid (iqgpu_chain_front_kernel names what was launched), a 2^20-frame one
+    k_front_s1, a 2^24-frame one -- the pipelined host path's batch, 7 tiles per wave -- k_front_mid again (the size rule of
+    plan.cpp: from 6 tiles per wave on), and the stream continues across the changes of kernel"""
     n = (1 << 25) + 12345
     raw = np.tile(synth.raw_stream(1 << 20, 2.4e6, 5, "cs16"), 33)[:2 * n]
     ch = gpu.Chain(**NRSC5)
     a = ch.process(raw[:2 * (1 << 20)])
-    b = ch.process(raw[2 * (1 << 20):])
-    one = gpu.Chain(**NRSC5).process(raw)
-    assert np.array_equal(np.concatenate([a, b]), one)
+    assert ch.front_kernel() == "k_front_s1"
+    b = ch.process(raw[2 * (1 << 20):2 * ((1 << 20) + (1 << 24))])
+    assert ch.front_kernel().startswith("k_front_mid")
+    c = ch.process(raw[2 * ((1 << 20) + (1 << 24)):])
+    assert ch.front_kernel().startswith("k_front_mid")    # 15.7 M frames are left: 6.7 tiles per wave
+    one_ch = gpu.Chain(**NRSC5)
+    one = one_ch.process(raw)
+    assert one_ch.front_kernel().startswith("k_front_mid")
+    assert np.array_equal(np.concatenate([a, b, c]), one)
 
 
 @pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,shift", [
