@@ -1549,6 +1549,70 @@ def _enveloped_stream(n, seed, segments):
     return np.clip(np.rint(raw * env[:, None]), -32768, 32767).astype(np.int16).reshape(-1)
 
 
+def _tone_stream(n, amp_segments, f_hz=-200e3, rate=2.4e6):
+    """cs16 complex tone (constant envelope) whose amplitude follows (start_second, amplitude) segments: behind the +200 kHz shift
+    it sits at 0 Hz, where the half-band and the polyphase filter pass it with a gain that is flat to rounding -- every output
+    sample of a segment has the same magnitude to ~1e-6, and so have the per-chunk peaks"""
+    t = np.arange(n, dtype=np.float64)
+    amp = np.zeros(n)
+    for t0, a in amp_segments:
+        amp[int(t0 * rate):] = a
+    # every change of amplitude (the start included) as a 20 000-frame raised-cosine ramp: no overshoot of the filters' step
+    # response, so the peak the AGC locks on IS the steady magnitude
+    ramp = 20000
+    k = np.hanning(ramp + 1); k /= k.sum()
+    from scipy.signal import fftconvolve
+    amp = fftconvolve(np.concatenate([np.zeros(ramp), amp]), k)[ramp // 2:ramp // 2 + n]
+    x = amp * np.exp(2j * np.pi * f_hz / rate * t)
+    raw = np.empty(2 * n, np.int16)
+    raw[0::2] = np.rint(x.real * 32767.0).astype(np.int16)
+    raw[1::2] = np.rint(x.imag * 32767.0).astype(np.int16)
+    return raw
+
+
+@pytest.mark.parametrize("case", ["at_the_ratchet", "at_the_lower_threshold"])
+def test_agc_fused_float_peaks_next_to_the_thresholds(gpu, monkeypatch, case):
+    """k_front_mid keeps the per-chunk peaks in FLOAT and k_agc_classify sends every chunk within 8 eps of a threshold
+    to the exact kernels -- here every chunk IS next to one.  A constant-envelope tone with agc_target = 1 locks at gain =
+    1 / peak, so peak x gain of every later chunk is 1 to within the ripple of the cs16 quantisation (+-2e-5: chunks land on both
+    sides of the ratchet threshold `> 1`, some inside the 8 eps band); stepping the amplitude to 0.75 (smooth ramps: no filter
+    overshoot) puts the chunks next to the lower threshold 0.75 x target the same way.  Whatever the classification makes of them, bytes and AGC state must equal
+    the unfused (exact, double-precision peaks) path's."""
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # every fused call on k_front_mid
+    n = int(2.4e6 * 8)
+    if case == "at_the_ratchet":
+        raw = _tone_stream(n, [(0.0, 0.45)])
+    else:
+        raw = _tone_stream(n, [(0.0, 0.45), (3.5, 0.45 * 0.75), (5.0, 0.45), (6.0, 0.45 * 0.75 * (1.0 + 2e-7))])
+    kw = dict(NRSC5, agc=True, agc_target=1.0)
+    splits = [int(2.4e6 * 3.2)] + [16384 * 60] * 4
+    splits.append(n - sum(splits))
+
+    def run(nofuse):
+        if nofuse:
+            monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+        else:
+            monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+        ch = gpu.Chain(**kw)
+        outs, pos, states = [], 0, []
+        for k in splits:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+            states.append(ch.agc_state())
+        return np.concatenate(outs), states
+
+    fused, st_f = run(False)
+    plain, st_p = run(True)
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE", raising=False)
+    assert st_f[-1]["locked"]
+    assert np.array_equal(fused, plain), (case, int((fused != plain).sum()))
+    assert st_f == st_p
+    # the construction does what it says: behind the lock the output magnitude sits at the target (or at 0.75 of it) to 1e-5
+    tail = fused[-2 * 100000:].astype(np.float64).reshape(-1, 2)
+    mag = np.hypot(tail[:, 0], tail[:, 1]) / 32767.0
+    want_mag = 1.0 if case == "at_the_ratchet" else 0.75
+    assert abs(np.median(mag) / want_mag - 1.0) < 2e-3, float(np.median(mag))
+
+
 @pytest.mark.parametrize("kernel", ["by_size", "mid"])
 @pytest.mark.parametrize("case", ["steady", "ratchet", "fade_and_creep", "many_calls", "odd_chunk"])
 def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case, kernel):
