@@ -17,8 +17,9 @@
 // (test_cascade_instantiations_equal_the_generic_kernel).  The intermediate stream never leaves the wave.
 //
 // Edge tiles (stream history, end of the call) are few and keep the two-kernel arithmetic literally: an edge wave runs
-// casc_tiles<EDGE> over the input tiles of its run into the (now almost untouched) intermediate buffer, fences, and runs
-// run_tiles<EDGE> over them; the histories both leave for the next call are the ones the two kernels left.
+// casc_tiles<EDGE> over the input tiles of its run into a PRIVATE stretch of intermediate samples (a few KB per edge wave: the
+// runs of neighbouring edge waves overlap in their warm-up tiles, whose first samples differ from wave to wave), fences, and
+// runs run_tiles<EDGE> over them; the histories both leave for the next call are the ones the two kernels left.
 #include "cascade_tiles.hpp"
 #include "front_tiles.hpp"
 
@@ -33,6 +34,9 @@ __host__ __device__ constexpr int s2_wave_lds(int m0) { return kWaveLds + s2_sta
 static_assert(kS2NcoLds + kS2ArbLds + kS2Waves * s2_wave_lds(5) <= 160 * 1024, "LDS");
 
 struct S2Args { FrontArgs a1, a2; };              // a1: the chain as k_cascade sees it (K = 1), a2: the last stage as k_front_s1 sees it
+// intermediate samples an edge wave keeps for itself: its run of edge_tpw last-stage tiles, the warm-up tile in front, the input
+// tile behind the call's last group (a1.casc_out = the base of these stretches, one per edge wave)
+__host__ __device__ constexpr int64_t s2_edge_slots(int64_t edge_tpw) { return 256 * (2 * edge_tpw + 4); }
 
 // The feeder of a streaming run: input sub-tile u = 2 t + c of 512 frames -> the lane's four stage-0 outputs x[c][0 .. 3].
 template <int BPS, int M0>
@@ -191,7 +195,12 @@ __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
         //  decimation group leaves frames there that complete no sample but belong to the history it hands on)
         int64_t u0 = first < 0 ? 0 : first, u1 = 2 * e1;
         if (u1 > a1.w_total_tiles || e1 == a2.w_total_tiles) u1 = a1.w_total_tiles;
-        casc_tiles<BPS, true, false, 0>(a1, cw, lane, first < 0 ? u0 - 1 : u0, u0, u1, seg);
+        // intermediate sample 256 u0 (the first one this run computes) sits at the start of the wave's private stretch
+        cf2 *const priv = p.a1.casc_out + gw * s2_edge_slots(a2.w_edge_tpw) - 256 * u0;
+        FrontArgs a1e = p.a1;
+        a1e.casc_out = priv;
+        a2.raw = priv;
+        casc_tiles<BPS, true, false, 0>(a1e, cw, lane, first < 0 ? u0 - 1 : u0, u0, u1, seg);
         // the wave's own stores, then its own loads of the same lines: out to memory and this CU's L1 refreshed
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -208,6 +217,7 @@ __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
 }
 
 int front_s2_waves() { return kS2Waves; }
+int64_t front_s2_mid_samples(const FrontArgs &a2) { return (a2.w_n_edge + 1) * s2_edge_slots(a2.w_edge_tpw); }
 
 // which chains: two stages with liquid's 60 dB lengths, a vector-loadable input format, no fused AGC (that path keeps the two
 // kernels), the call aligned on a decimation group (the streaming waves read whole 16-byte words)

@@ -234,6 +234,7 @@ hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
 // two-stage chains (S = 2) with both half-bands and the polyphase in one kernel (front_s2.hip): a1 = the chain as k_cascade sees
 // it (K = 1), a2 = the last stage as k_front_s1 sees it, planned in ITS tiles (512 intermediate samples = 1024 input frames)
 int front_s2_waves();
+int64_t front_s2_mid_samples(const FrontArgs &a2);  // cf32 samples of the intermediate buffer it needs (edge waves only): needs the plan
 bool front_s2_shape(const FrontArgs &a1);          // needs casc_K, m[0], in_fmt
 hipError_t launch_front_s2(const FrontArgs &a1, const FrontArgs &a2, hipStream_t s);
 // fills the w_* geometry from frames_in / rem0 / hist_cap / alignment (w_total_tiles must be set): at most

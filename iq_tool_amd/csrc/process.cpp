@@ -69,7 +69,8 @@ int Call::prepare_buffers()
         rc = c->dc_carry.ensure((size_t)dg.n_seg * sizeof(cd2)); if (rc) return rc;
     }
     if (casc) {
-        const int64_t n_mid = ((int64_t)rem_k + (int64_t)frames_in) >> casc_K;
+        // the intermediate stream between k_cascade and the last stage -- or, with both in k_front_s2, a few KB per edge wave
+        const int64_t n_mid = s2 ? front_s2_mid_samples(cplan) : ((int64_t)rem_k + (int64_t)frames_in) >> casc_K;
         int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
     }
     // run descriptors of k_front_mid: a fresh array starts exhausted (all zero), a used one is left exhausted by every launch
