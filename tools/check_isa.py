@@ -196,8 +196,10 @@ HOT = {
                        ("_ZN5iqgpu10k_front_s1ILi8ELb0ELb0ELb0ELi4EEEvNS_9FrontArgsE", 128),      # last stage behind k_cascade (configs 3, 4)
                        ("_ZN5iqgpu10k_front_s1ILi2ELb0ELb1ELb0ELi2EEEvNS_9FrontArgsE", 128),      # cu8-nrsc5 preset shapes
                        ("_ZN5iqgpu10k_front_s1ILi4ELb0ELb1ELb0ELi3EEEvNS_9FrontArgsE", 128)],
-    "cascade_wave.hip": [("_ZN5iqgpu9k_cascadeILi4ELb0ELi1EEEvNS_9FrontArgsE", 168),               # config 3 (12 waves)
+    "cascade_wave.hip": [("_ZN5iqgpu9k_cascadeILi4ELb0ELi1EEEvNS_9FrontArgsE", 168),               # S = 2 calls off a group boundary (12 waves)
                          ("_ZN5iqgpu9k_cascadeILi2ELb1ELi4EEEvNS_9FrontArgsE", 128)],              # config 4 (16 waves)
+    "front_s2.hip": [("_ZN5iqgpu10k_front_s2ILi4ELi5EEEvNS_6S2ArgsE", 168),                        # config 3 (12 waves)
+                     ("_ZN5iqgpu10k_front_s2ILi2ELi5EEEvNS_6S2ArgsE", 168)],
 }
 
 
@@ -221,7 +223,8 @@ def check_hot(lines_by_src):
 def main():
     lines = compile_isa()
     errors, n = check(lines)
-    errors += check_hot({"front_wave.hip": lines, "cascade_wave.hip": compile_isa(SRC_CASC)})
+    errors += check_hot({"front_wave.hip": lines, "cascade_wave.hip": compile_isa(SRC_CASC),
+                         "front_s2.hip": compile_isa(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_s2.hip"))})
     errors += check_no_read2_b32(lines, "front_wave.hip")
     errors += check_no_read2_b32(compile_isa(SRC_CASC), "cascade_wave.hip")
     errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_mid.hip"), "k_front_mid", 168)
