@@ -292,6 +292,8 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         {
             int ncu = 0;
             if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+            // (diagnostic: IQGPU_CUS=n plans every launch for n CUs -- how does a CU's throughput depend on how many of them work?)
+            if (const char *v = getenv("IQGPU_CUS")) { const int x = atoi(v); if (x >= 8 && x <= c->n_cu) c->n_cu = x; }
         }
         CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;

@@ -412,9 +412,15 @@ __device__ __forceinline__ bool steal_run(const FrontArgs &a, const int64_t gw, 
 {
     unsigned long long *const D = a.w_steal;
     const int n = (int)(a.w_n_edge + a.w_n_stream);
-    const int stride = n / a.w_steal_lanes;                             // (n >= 64 >= lanes: the host leaves short launches static)
+    // the victims of a round: one wave in each of `lanes` DIFFERENT workgroups, 37 workgroups apart -- workgroup b runs on XCD
+    // b mod 8 and 37 = 5 (mod 8), so eight consecutive lanes look at all eight XCDs (round 4, first attempt: descriptors a fixed
+    // stride of 4 .. 64 workgroups apart = always the thief's own XCD: runs only changed hands inside an XCD) -- and the wave
+    // slot inside the workgroup varies with the lane too
+    const int n_wg = n / kMidWaves;                                     // (n >= 64 * 12: the host leaves short launches static)
+    const int wg = (int)(gw / kMidWaves), slot = (int)(gw % kMidWaves);
     for (int round = 0; round < a.w_steal_rounds; ++round) {
-        const int v = (int)((gw + 1 + (int64_t)lane * stride + (int64_t)round * 17) % n);
+        const int vb = (wg + 1 + lane * 37 + round * (64 * 37 + 11)) % n_wg;
+        const int v = vb * kMidWaves + (slot + lane * 5 + round) % kMidWaves;
         unsigned long long *const Dv = D + (size_t)v * (size_t)a.w_steal_stride;
         // (a read-modify-write, not a load: atomics execute at the memory side, while an sc1 load may be served by this XCD's L2
         //  with what the line held a launch ago -- the L2s of different XCDs are not coherent -- and an exhausted descriptor hides

@@ -200,7 +200,7 @@ int Call::stage_front()
         }
         // k_front_mid, IQGPU_STEAL=1, one run per resident wave: every wave claims its tiles through its run descriptor and waves
         // that finish early split the runs of those that are behind (front_mid.hip; off by default, profiles/r04_steal.md)
-        if (mid && c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64) {
+        if (mid && c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64 * (int64_t)front_mid_waves()) {
             a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
             a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = c->steal_rounds;
         }

@@ -15,7 +15,7 @@ import iq_tool_amd
 from iq_tool_amd import synth
 from iq_tool_amd.chain import DeviceBuffer
 
-frames = 1 << 28
+frames = 1 << int(os.environ.get("IQGPU_CLOCK_LOG2", "28"))       # (with IQGPU_CUS=n: scale the work with the CUs, e.g. 128 CUs, 2^27 frames)
 raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 1, "cs16"), frames >> 22)
 ch = iq_tool_amd.Chain(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
 d_in = DeviceBuffer(raw.nbytes)
