@@ -1071,6 +1071,60 @@ def test_two_stage_chain_in_one_kernel_equals_the_two_kernel_path(gpu, oracle, m
         int_close(fused[:want.size], want, min_same=0.995 if extra.get("filters") else 0.998)
 
 
+@pytest.mark.parametrize("seed", range(int(_os_agc.environ.get("IQGPU_FUZZ_SEEDS", "24"))))
+def test_two_stage_random_schedules(gpu, monkeypatch, seed):
+    """k_front_s2 against k_cascade + k_front_s1 on random two-stage chains: ratio anywhere in [1/8, 1/4), any vector-loadable input
+    format, output format, gain, iq correction, a shift in front of or behind the resampler, random call schedules that stay on
+    decimation groups for a while and leave them (the stream alternates between the fused kernel and the two kernels), short
+    calls (edge waves only), block_samples.  No dc blocker (its carries belong to the run geometry): the BYTES must be equal."""
+    rng = np.random.default_rng(12000 + seed)
+    in_rate = float(rng.choice([2.4e6, 8e6, 10e6]))
+    ratio = float(rng.uniform(0.1255, 0.2495))
+    in_format = str(rng.choice(["cs16", "cs16", "cu8", "cs8", "cu16", "cf32"]))
+    out_format = str(rng.choice(["cs16", "cs16", "cu8", "cf32"]))
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=in_rate, target_rate_hz=in_rate * ratio)
+    if rng.integers(0, 2):
+        kw["shift_hz"] = float(rng.uniform(-0.3, 0.3)) * in_rate * (ratio if rng.integers(0, 2) else 1.0)
+        if abs(kw["shift_hz"]) < 1.0:
+            kw["shift_hz"] = 1234.0
+        kw["shift_after_resample"] = bool(rng.integers(0, 2)) and abs(kw["shift_hz"]) < 0.3 * in_rate * ratio
+    if rng.integers(0, 3) == 0:
+        kw["gain"] = float(rng.choice([0.5, 2.0, 0.37]))
+    if rng.integers(0, 3) == 0:
+        kw.update(iq_correct=True, iq_mag=0.02, iq_phase=-0.01)
+    if rng.integers(0, 4) == 0:
+        kw["block_samples"] = int(rng.choice([4096, 65536]))
+    n = int(rng.integers(300_000, 1_600_000))
+    if in_format == "cf32":
+        raw = synth.complex_signal(n, in_rate, 900 + seed).view(np.float32)
+    else:
+        raw = synth.raw_stream(n, in_rate, 900 + seed, in_format)
+    per = raw.size // n
+    cuts = {0, n}
+    for v in rng.integers(0, n, int(rng.integers(1, 7))):
+        v = int(v)
+        cuts.add(v - v % 4 if rng.integers(0, 3) else v)            # mostly on a decimation group, sometimes not
+    if rng.integers(0, 3) == 0:
+        a = int(rng.integers(0, n - 5000)); a -= a % 4
+        cuts |= {a, a + 4 * int(rng.integers(1, 600))}              # a call shorter than the histories: edge waves / two kernels
+    cuts = sorted(cuts)
+
+    def run():
+        ch = gpu.Chain(**kw)
+        outs, kernels = [], set()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            outs.append(ch.process(raw[per * a:per * b])); kernels.add(ch.front_kernel())
+        return np.concatenate(outs), kernels
+
+    fused, kf = run()
+    monkeypatch.setenv("IQGPU_NO_S2", "1")
+    two, kt = run()
+    monkeypatch.delenv("IQGPU_NO_S2")
+    assert "k_front_s2" not in kt
+    assert fused.size == two.size, (kw, cuts)
+    assert np.array_equal(fused, two), (kw, cuts, kf, int((fused != two).sum()), int(np.flatnonzero(fused != two)[0]))
+
+
 @pytest.mark.parametrize("fmt", ["cu8", "cs8", "cu16", "sc16q11", "cf32", "cs24", "cs32"])
 def test_one_stage_chain_all_input_formats(gpu, oracle, fmt):
     """the fast path's vector loaders (2, 4, 8 bytes per frame) and its scalar fallback"""
