@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     }
     constexpr bool EDGE = false;                      // (for CLOCK_END: the diagnostic -DIQGPU_CLOCKSTAMP build, tools/clock.py)
     CLOCK_BEGIN;
-    int64_t t0 = 0, t1 = 0;
+    int64_t t0 = 0, t1 = 0, r_cur = -1;
     bool have = false;
     if (gw < a.w_n_edge) {
         // edge work in tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) of G::TILE frames, runs of w_edge_tpw of them (768-frame
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         t0 = w_run_start_weighted(a, r); t1 = w_run_start_weighted(a, r + 1);
-        have = true;
+        have = true; r_cur = r;
         if (STEAL && lane == 0)                      // the static run, open to thieves from here on
             __hip_atomic_store(a.w_steal + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)(t1 - a.w_edge_ta) << 32) | (unsigned long long)(uint32_t)(t0 - a.w_edge_ta),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -545,6 +545,18 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
             int ln = (int)__lane_id();
             asm volatile("" : "+v"(ln));
             if (have) run_mid<NL, NONCO, L3, L4, AGC, true>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
+            if (a.w_run_stride > 0) {
+                // fixed-length runs dealt round-robin to the resident waves: the wave's next static run
+                if (r_cur < 0) break;                       // (an edge wave: done)
+                r_cur += a.w_run_stride;
+                if (r_cur >= a.w_n_stream) break;
+                t0 = w_run_start(a, r_cur); t1 = w_run_start(a, r_cur + 1);
+                if (ln == 0)
+                    __hip_atomic_store(a.w_steal + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)(t1 - a.w_edge_ta) << 32) | (unsigned long long)(uint32_t)(t0 - a.w_edge_ta),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have = true;
+                continue;
+            }
             if (!steal_run(a, gw, ln, t0, t1)) break;
             have = true; n_stolen += 1;
         }
@@ -642,7 +654,7 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     int l3 = 0, l4 = 0;
     if (nl == 0 || !mid_class(a.step, nl, &l3, &l4)) return hipErrorInvalidValue;
     const size_t lds = mid_lds_bytes(nl, nonco);
-    const int64_t n_items = a.w_n_edge + a.w_n_stream;
+    const int64_t n_items = a.w_n_edge + (a.w_run_stride > 0 && a.w_run_stride < a.w_n_stream ? a.w_run_stride : a.w_n_stream);
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
 #define IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, STEAL)                                                            \
@@ -652,7 +664,7 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
         hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC, STEAL>), dim3(grid), dim3(kMidThreads), lds, s, a); \
     } while (0)
     /* run stealing: six outputs per lane only, and only when the host provides descriptors and asks for it */
-    const bool steal = a.w_steal != nullptr && a.w_steal_rounds > 0;
+    const bool steal = a.w_steal != nullptr && (a.w_steal_rounds > 0 || a.w_run_stride > 0);
 #define IQGPU_LAUNCH_MID(NL, NONCO, L3, L4, AGC)                                                                    \
     do {                                                                                                              \
         if (NL == 6 && steal) IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, (NL == 6));                                 \

@@ -74,9 +74,9 @@ int Call::prepare_buffers()
         int rc = c->mid.ensure(((size_t)n_mid + 8) * sizeof(cf2)); if (rc) return rc;
     }
     // run descriptors of k_front_mid: a fresh array starts exhausted (all zero), a used one is left exhausted by every launch
-    if (mid && c->steal) {
+    if (mid && (c->steal || fixed_tpw() != 0)) {
         const void *was = c->steal_buf.p;
-        const size_t slots = (size_t)(cplan.w_n_edge + cplan.w_n_stream) + 64;
+        const size_t slots = (size_t)(fixed_tpw() != 0 ? wave_slots(front_mid_waves()) + cplan.w_n_edge : cplan.w_n_edge + cplan.w_n_stream) + 64;
         int rc = c->steal_buf.ensure(slots * (size_t)c->steal_stride * sizeof(unsigned long long)); if (rc) return rc;
         if (c->steal_buf.p != was && hipMemsetAsync(c->steal_buf.p, 0, c->steal_buf.cap, c->stream) != hipSuccess)
             return fail(IQGPU_EHIP, "hipMemsetAsync failed");
@@ -203,6 +203,12 @@ int Call::stage_front()
         if (mid && c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64 * (int64_t)front_mid_waves()) {
             a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
             a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = c->steal_rounds;
+        } else if (mid && fixed_tpw() != 0 && a.w_n_stream > wave_slots(front_mid_waves()) - a.w_n_edge) {
+            // block_samples != 0 (BASELINE configs[1] as worded: "256 k-sample blocks"): more fixed-length runs than resident waves --
+            // one round of workgroups, every streaming wave takes runs s, s + stride, ... through the multi-run instantiation
+            a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
+            a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = 0;
+            a.w_run_stride = wave_slots(front_mid_waves()) - a.w_n_edge;
         }
         a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (front_mid_nl(a) == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)

@@ -954,6 +954,35 @@ def test_mid_kernel_run_stealing_keeps_the_bytes(gpu, monkeypatch, weights, stea
             assert np.array_equal(got, s1)
 
 
+@pytest.mark.parametrize("block_samples", [4096, 6144, 262144])
+def test_more_fixed_runs_than_resident_waves(gpu, monkeypatch, block_samples):
+    """block_samples != 0 on a long call: more fixed-length runs than the chip holds waves -- k_front_mid is launched as ONE round
+    of workgroups and every streaming wave takes runs s, s + stride, ... (FrontArgs::w_run_stride, front_mid.hip); with IQGPU_CUS=16
+    a wave walks through dozens of runs.  Same tiles, same warm-up rule: the bytes of the default geometry, AGC state included."""
+    n = (1 << 25) + 4321
+    raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 78, "cs16"), 9)[:2 * n]
+
+    def run(agc, **extra):
+        ch = gpu.Chain(**dict(NRSC5, agc=agc, **extra))
+        outs, pos = [], 0
+        for k in [(1 << 24), n - (1 << 24)]:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        assert ch.front_kernel().startswith("k_front_mid")
+        return np.concatenate(outs), (ch.agc_state() if agc else None)
+
+    for agc in (False, True):
+        ref, st_ref = run(agc)
+        for cus in (None, "16"):
+            if cus:
+                monkeypatch.setenv("IQGPU_CUS", cus)
+            got, st_got = run(agc, block_samples=block_samples)
+            if cus:
+                monkeypatch.delenv("IQGPU_CUS")
+            assert got.size == ref.size
+            assert np.array_equal(got, ref), (agc, cus, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+            assert st_got == st_ref
+
+
 def test_fat_kernel_takes_long_calls_by_itself(gpu):
     """without any switch: a long call runs k_front_mid (iqgpu_chain_front_kernel names what was launched), a 2^20-frame one
     k_front_s1, a 2^24-frame one -- the pipelined host path's batch, 7 tiles per wave -- k_front_mid again (the size rule of
