@@ -214,16 +214,27 @@ __device__ __forceinline__ Tw4 load_tw4(const cf2 *tw, int tid)
     return t;
 }
 
-template <int N, int Ns>
-__device__ __forceinline__ void r16_passes(cf2 *buf, const cf2 *tw, int tid, const Tw4 cur)
+// FIRST: the pass's input is in registers -- io[r] = point tid + r T, which is what the window load (and the last pass of the
+// transform in front) leaves in a thread -- instead of LDS; WAIT: other threads may still be reading the buffer (the inverse
+// transform: the forward one's last pass), so the writes wait for a barrier.  The LAST pass (Ns = T: k = j, the autosorted
+// destination of thread j is point j + r T again) leaves its results in io[] in natural order and writes nothing.  Window load,
+// spectrum product, and output therefore never touch LDS: 4 LDS round trips and 7 barriers per block instead of 8 and 14.
+template <int N, int Ns, bool FIRST, bool WAIT>
+__device__ __forceinline__ void r16_passes(cf2 *buf, const cf2 *tw, int tid, const Tw4 cur, cf2 (&io)[16])
 {
     if constexpr (Ns < N) {
         constexpr int T = N / 16;
+        constexpr bool LAST = Ns * 16 == N;
         const int j = tid, k = j & (Ns - 1);
         cf2 v[16];
-        const cf2 *src = buf + sw(j);
+        if constexpr (FIRST) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = src[r * T + ((r * T) >> 5)];
+            for (int r = 0; r < 16; ++r) v[r] = io[r];
+        } else {
+            const cf2 *src = buf + sw(j);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = src[r * T + ((r * T) >> 5)];
+        }
         if (Ns > 1) {
             const cf2 w3 = cmulf(cur.w1, cur.w2), w5 = cmulf(cur.w4, cur.w1), w6 = cmulf(cur.w4, cur.w2), w7 = cmulf(cur.w4, w3);
             v[1] = cmulf(v[1], cur.w1); v[2] = cmulf(v[2], cur.w2); v[3] = cmulf(v[3], w3); v[4] = cmulf(v[4], cur.w4);
@@ -234,53 +245,60 @@ __device__ __forceinline__ void r16_passes(cf2 *buf, const cf2 *tw, int tid, con
             v[15] = cmulf(v[15], cmulf(cur.w8, w7));
         }
         dft16(v);
-        const Tw4 nxt = load_tw4<N, Ns * 16>(tw, tid);               // issued in front of the barriers
-        cf2 *dst = buf + sw((j - k) * 16 + k);
-        __syncthreads();
+        if constexpr (LAST) {
+            static_assert(Ns == T, "the last radix-16 pass has Ns = N / 16");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r * Ns + ((r * Ns) >> 5)] = v[(r >> 2) + 4 * (r & 3)];
-        __syncthreads();
-        r16_passes<N, Ns * 16>(buf, tw, tid, nxt);
+            for (int r = 0; r < 16; ++r) io[r] = v[(r >> 2) + 4 * (r & 3)];
+        } else {
+            const Tw4 nxt = load_tw4<N, Ns * 16>(tw, tid);           // issued in front of the barriers
+            cf2 *dst = buf + sw((j - k) * 16 + k);
+            if constexpr (!FIRST || WAIT) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * Ns + ((r * Ns) >> 5)] = v[(r >> 2) + 4 * (r & 3)];
+            __syncthreads();
+            r16_passes<N, Ns * 16, false, false>(buf, tw, tid, nxt, io);
+        }
     }
 }
 
-template <int LOG2N>
-__device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int tid)
+// io[r]: in = point tid + r T of the sequence, out = point tid + r T of its transform
+template <int LOG2N, bool WAIT>
+__device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int tid, cf2 (&io)[16])
 {
     constexpr int N = 1 << LOG2N, T = N / 16;
     constexpr int Ns2 = (LOG2N & 1) ? 2 : 1;                          // after the radix-2 pass
     constexpr int Ns4 = (LOG2N & 2) ? Ns2 * 4 : Ns2;                  // after the radix-4 pass
+    static_assert(Ns4 * 16 <= N, "at least one radix-16 pass");
     const Tw4 first = load_tw4<N, Ns4>(tw, tid);                      // of the first radix-16 pass: in flight under the passes in front
-    if constexpr ((LOG2N & 1) != 0) {                                 // radix-2, Ns = 1: no twiddles
-        constexpr int nb = N >> 1;                                    // 8 butterflies per thread
-        cf2 v0[8], v1[8];
-        const cf2 *src = buf + sw(tid);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v0[i] = src[i * T + ((i * T) >> 5)]; v1[i] = src[nb + (nb >> 5) + i * T + ((i * T) >> 5)]; }
-        __syncthreads();
+    if constexpr ((LOG2N & 1) != 0) {                                 // radix-2, Ns = 1: no twiddles; points tid + i T and N/2 + tid + i T
+        if constexpr (WAIT) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int j = tid + i * T;
-            buf[sw(2 * j)] = cf2{v0[i].x + v1[i].x, v0[i].y + v1[i].y};
-            buf[sw(2 * j + 1)] = cf2{v0[i].x - v1[i].x, v0[i].y - v1[i].y};
+            buf[sw(2 * j)] = cf2{io[i].x + io[8 + i].x, io[i].y + io[8 + i].y};
+            buf[sw(2 * j + 1)] = cf2{io[i].x - io[8 + i].x, io[i].y - io[8 + i].y};
         }
         __syncthreads();
     }
     if constexpr ((LOG2N & 2) != 0) {                                 // radix-4: 4 butterflies per thread
         constexpr int Ns = Ns2, nb = N >> 2, tstride = N / (Ns * 4);
+        constexpr bool from_regs = (LOG2N & 1) == 0;                  // the first pass: point tid + i T + r N/4 = io[i + 4 r]
         cf2 v[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = tid + i * T, k = j & (Ns - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i][r] = buf[sw(j) + r * nb + ((r * nb) >> 5)];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (from_regs) v[i][r] = io[i + 4 * r];
+                else v[i][r] = buf[sw(j) + r * nb + ((r * nb) >> 5)];
+            }
             if (Ns > 1) {
 #pragma unroll
                 for (int r = 1; r < 4; ++r) v[i][r] = cmulf(v[i][r], tw[k * r * tstride]);
             }
             dft4(v[i][0], v[i][1], v[i][2], v[i][3]);
         }
-        __syncthreads();
+        if constexpr (!from_regs || WAIT) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = tid + i * T, k = j & (Ns - 1), j0 = (j - k) * 4 + k;
@@ -289,11 +307,13 @@ __device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int tid)
         }
         __syncthreads();
     }
-    r16_passes<N, Ns4>(buf, tw, tid, first);
+    if constexpr (Ns4 == 1) r16_passes<N, 1, true, WAIT>(buf, tw, tid, first, io);
+    else r16_passes<N, Ns4, false, false>(buf, tw, tid, first, io);
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__((1 << LOG2N) / 16) void k_fftconv16(const FftConvArgs a)
+// (four waves per SIMD: 4 workgroups of N = 4096, 2 of N = 8192 -- what their LDS allows -- need 128 VGPRs or fewer)
+__global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_eu(4))) void k_fftconv16(const FftConvArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int N = 1 << LOG2N, T = N / 16;                        // blockDim.x = T
@@ -302,11 +322,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void k_fftconv16(const FftConvAr
     constexpr int NP = N + (N >> 5) + 2;
     cf2 *X = (cf2 *)smem;
     cf2 *s_nco = X + NP;
-    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];
+    if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];   // (read behind the barriers of the transforms)
 
     const int64_t o0 = (int64_t)blockIdx.x * V;
+    cf2 io[16];                                                      // point tid + i T of the window / spectrum / result
     {
-        cf2 *dst = X + sw(tid);
         const cf2 *srcg = a.fbuf + o0 + tid;
         const bool nt = 4 * L1 <= N;
         const int64_t room = a.fbuf_len - o0 - tid;                  // window samples this thread may read: p = tid + i T < room
@@ -322,27 +342,26 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void k_fftconv16(const FftConvAr
                 if (nt) { const f2v q = __builtin_nontemporal_load((const f2v *)(srcg + i * T)); vin = cf2{q.x, q.y}; }
                 else vin = srcg[i * T];
             }
-            dst[i * T + ((i * T) >> 5)] = vin;
+            io[i] = vin;
         }
     }
-    __syncthreads();
-    fft16_lds<LOG2N>(X, a.twiddle, tid);
+    fft16_lds<LOG2N, false>(X, a.twiddle, tid, io);
     {
-        cf2 *px = X + sw(tid);
         const cf2 *ph = a.hfreq + tid;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const cf2 z = cmulf(px[i * T + ((i * T) >> 5)], ph[i * T]);
-            px[i * T + ((i * T) >> 5)] = cf2{z.x, -z.y};
+            const cf2 z = cmulf(io[i], ph[i * T]);
+            io[i] = cf2{z.x, -z.y};
         }
     }
-    __syncthreads();
-    fft16_lds<LOG2N>(X, a.twiddle, tid);
-    cf2 *Y = X;
+    fft16_lds<LOG2N, true>(X, a.twiddle, tid, io);
     const int64_t left = a.n_emit - o0;
     const int nv = left < (int64_t)V ? (int)left : V;
-    for (int i = tid; i < nv; i += T) {
-        cf2 y = Y[sw(L1 + i)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = tid + r * T - L1;                              // output i of the block is point L1 + i of the result
+        if (i < 0 || i >= nv) continue;
+        cf2 y = io[r];
         y.y = -y.y;
         const int64_t k = o0 + i;
         if (a.pnco_mode != 0)

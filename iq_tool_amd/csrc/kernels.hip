@@ -437,16 +437,18 @@ hipError_t launch_dc_prefix(const DcPrefixArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+constexpr int kDcScanThreads = 1024;      // one workgroup, 3 segments a thread for a launch of 3 072 runs: 11.7 us (256 threads: 17.8 us; loading the
+                                          // aggregates ahead of the folds changes nothing -- the folds' 64-bit index arithmetic and the barriers of the scan do)
 // carry[s] = state before segment s; state <- state after the last sample.  The per-segment maps
-// v -> f_s v + g_s (f_s = c^len_s, g_s = the segment's aggregate) compose associatively: each of the 256
+// v -> f_s v + g_s (f_s = c^len_s, g_s = the segment's aggregate) compose associatively: each of the
 // threads folds a contiguous slice of segments, the slices are scanned through LDS, then every thread
 // replays its slice from its prefix.  All in double.
-__global__ __launch_bounds__(kThreads) void k_dc_scan(const DcScanArgs a)
+__global__ __launch_bounds__(kDcScanThreads) void k_dc_scan(const DcScanArgs a)
 {
-    __shared__ double sf[kThreads], sr[kThreads], si[kThreads];
+    __shared__ double sf[kDcScanThreads], sr[kDcScanThreads], si[kDcScanThreads];
     const int tid = threadIdx.x;
     const int n = a.geom.n_seg;
-    const int per = (n + kThreads - 1) / kThreads;
+    const int per = (n + kDcScanThreads - 1) / kDcScanThreads;
     const int s0 = tid * per, s1 = (s0 + per < n) ? s0 + per : n;
     auto seg_len = [&](int sgm) {
         const int64_t beg = dc_seg_start(a.geom, sgm);
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void k_dc_scan(const DcScanArgs a)
     sf[tid] = F; sr[tid] = Gr; si[tid] = Gi;
     __syncthreads();
     // inclusive scan of the maps (later map applied after the earlier one)
-    for (int o = 1; o < kThreads; o <<= 1) {
+    for (int o = 1; o < kDcScanThreads; o <<= 1) {
         double pf = 1.0, pr = 0.0, pi = 0.0;
         const bool has = tid >= o;
         if (has) { pf = sf[tid - o]; pr = sr[tid - o]; pi = si[tid - o]; }
@@ -490,12 +492,12 @@ __global__ __launch_bounds__(kThreads) void k_dc_scan(const DcScanArgs a)
         }
     }
     __syncthreads();
-    if (tid == kThreads - 1) { a.state->x = sf[tid] * v0r + sr[tid]; a.state->y = sf[tid] * v0i + si[tid]; }
+    if (tid == kDcScanThreads - 1) { a.state->x = sf[tid] * v0r + sr[tid]; a.state->y = sf[tid] * v0i + si[tid]; }
 }
 
 hipError_t launch_dc_scan(const DcScanArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(kDcScanThreads), 0, s, a);
     return hipGetLastError();
 }
 
