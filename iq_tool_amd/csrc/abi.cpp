@@ -364,8 +364,8 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
         if (c->fp.enabled && !c->force_generic && Lt >= 2 && 2 * (Lt - 1) <= (size_t)kMaxFftN &&
             (c->fp.block > 0 || Lt >= (size_t)kFftMinTaps)) {
             // N = 4 (L-1) rounded up to a power of two in [256, 4096], larger (up to 16384, in place in LDS) only
-            // when the taps need it; measured with k_fftconv16 on config 3 (1025 taps): N 2048 0.31 ms, 4096 0.22, 8192 0.24,
-            // 16384 0.29; on config 4 (4097 taps): N 8192 0.146 ms, 16384 0.144
+            // when the taps need it; measured with k_fftconv16 (round 4: first and last pass in registers) on config 3 (1025 taps):
+            // N 2048 0.25 ms, 4096 0.15, 8192 0.16, 16384 0.21; on config 4 (4097 taps): N 8192 0.105 ms, 16384 0.114
             int lg = 8;
             while ((size_t)(1 << lg) < 4 * (Lt - 1) && (1 << lg) < 4096) ++lg;
             while ((size_t)(1 << lg) < 2 * (Lt - 1)) ++lg;

@@ -37,6 +37,15 @@ for v in ${PMC_VARIANTS:-mid fat s1}; do
   echo "pmc $v done"
 done
 variant mid
+# ---- the same counter sets for the kernels of configs 3 and 4
+for cfg in 3 4; do
+  i=0
+  for set in "${SETS[@]}"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set -d "$OUT/pmc_cfg${cfg}_$i" -o pmc --output-format csv -- $BENCH --config $cfg > "$OUT/pmc_cfg${cfg}_$i.log" 2>&1
+  done
+  echo "pmc cfg $cfg done"
+done
 # ---- HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, every config
 for cfg in 2 3 4 preset; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -64,6 +73,13 @@ done
     for p in "$OUT"/pmc_${v}_*/; do
       f=$(find "$p" -name '*counter_collection.csv' | head -1)
       [ -n "$f" ] && python3 tools/pmc_summary.py "$f" k_front
+    done
+  done
+  for cfg in 3 4; do
+    echo "## config $cfg (every iqgpu kernel of the step)"
+    for p in "$OUT"/pmc_cfg${cfg}_*/; do
+      f=$(find "$p" -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python3 tools/pmc_summary.py "$f" iqgpu
     done
   done
   echo "## HBM traffic per config (KiB as rocprofv3 reports them; FETCH_SIZE is doubled per the gfx950 note)"
