@@ -120,6 +120,8 @@ __global__ __launch_bounds__(kFftMaxThreads) void k_fftconv(const FftConvArgs a)
     cf2 *buf0 = (cf2 *)smem, *buf1 = buf0 + NP;
     cf2 *s_nco = buf1 + NP;                                  // only when the post NCO is on
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += nthr) s_nco[i] = a.nco_tab[i];
+    if (a.move_n > 0 && blockIdx.x == gridDim.x - 1)
+        for (int64_t i = tid; i < a.move_n; i += nthr) a.move_dst[i] = a.move_src[i];
 
     // window sample p <-> filter-input stream index s = blk*V - L1 + p <-> fbuf[L1 + s]
     const int64_t o0 = (int64_t)blockIdx.x * V;
@@ -323,6 +325,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
     cf2 *X = (cf2 *)smem;
     cf2 *s_nco = X + NP;
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];   // (read behind the barriers of the transforms)
+    if (a.move_n > 0 && blockIdx.x == gridDim.x - 1)                 // the next call's history, into the other buffer of the pair
+        for (int64_t i = tid; i < a.move_n; i += T) a.move_dst[i] = a.move_src[i];
 
     const int64_t o0 = (int64_t)blockIdx.x * V;
     cf2 io[16];                                                      // point tid + i T of the window / spectrum / result

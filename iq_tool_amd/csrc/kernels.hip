@@ -515,6 +515,8 @@ __global__ __launch_bounds__(kThreads) void k_fir(const FirArgs a)
     const int64_t o0 = (int64_t)blockIdx.x * kFirOutTile;
     const int L = a.ntaps;
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += kThreads) s_nco[i] = a.nco_tab[i];
+    if (a.move_n > 0 && blockIdx.x == gridDim.x - 1)
+        for (int64_t i = tid; i < a.move_n; i += kThreads) a.move_dst[i] = a.move_src[i];
 
     float ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
     for (int k0 = 0; k0 < L; k0 += kFirTapChunk) {

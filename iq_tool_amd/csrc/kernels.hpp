@@ -63,7 +63,8 @@ struct cd2 { double x, y; };
 // diagnostic switches (IQGPU_NO_FAST, IQGPU_AGC_NOFUSE, IQGPU_NO_RAW0, IQGPU_NO_KT, IQGPU_FFT_NO_R16): read from the
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
 enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u,
-                  kDbgNoS2 = 512u };       // IQGPU_NO_S2=1: two-stage chains keep k_cascade + k_front_s1 instead of the fused k_front_s2
+                  kDbgNoS2 = 512u,         // IQGPU_NO_S2=1: two-stage chains keep k_cascade + k_front_s1 instead of the fused k_front_s2
+                  kDbgNoFusedMove = 1024u }; // IQGPU_NO_FUSED_MOVE=1: the filter's history moves by a copy kernel, not inside the filter kernel
 
 struct FrontArgs {
     uint32_t    dbg;          // kDbg* switches of the chain
@@ -314,6 +315,11 @@ struct FirArgs {
     const cf2 *nco_tab;
     int32_t    out_fmt;
     void      *out;
+    // the next call's buffer front (history + still-pending samples) lives in the OTHER buffer of the pair: nobody reads that
+    // one during this launch, so the last workgroup copies it on the side (one launch fewer per step than a copy kernel)
+    cf2       *move_dst;
+    const cf2 *move_src;
+    int64_t    move_n;
 };
 hipError_t launch_fir(const FirArgs &a, hipStream_t s);
 
@@ -338,6 +344,9 @@ struct FftConvArgs {
     const cf2 *nco_tab;
     int32_t    out_fmt;
     void      *out;
+    cf2       *move_dst;      // as FirArgs: the next call's buffer front, copied by the last workgroup
+    const cf2 *move_src;
+    int64_t    move_n;
 };
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s);
 

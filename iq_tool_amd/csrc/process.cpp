@@ -234,6 +234,11 @@ int Call::stage_filter()
     fa.pnco_mode = c->late ? 0 : c->pnco_mode; fa.pnco_theta0 = c->pnco_theta; fa.pnco_dtheta = c->nco_dtheta; fa.nco_tab = c->d_nco_tab;
     if (c->late) { fa.out_fmt = IQGPU_FMT_CF32; fa.out = icur + c->ihist; }
     else         { fa.out_fmt = fin_fmt; fa.out = fin_out; }
+    // next call's buffer front: history (L-1) + still-pending samples, into the other buffer of the pair -- by the filter kernel's
+    // last workgroup when one is launched (nobody reads that buffer meanwhile), else by a copy kernel
+    const size_t keep = L1 + (size_t)p.fpending_next;
+    const bool fused_move = n_filt > 0 && !(c->dbg & kDbgNoFusedMove);
+    if (fused_move) { fa.move_dst = (cf2 *)c->fbuf[c->fcur ^ 1].p; fa.move_src = fcur + n_filt; fa.move_n = (int64_t)keep; }
     if (c->d_hfreq) {
         FftConvArgs ca{};
         ca.dbg = c->dbg;
@@ -242,16 +247,17 @@ int Call::stage_filter()
         ca.log2n = c->fft_log2n; ca.threads = c->fft_threads; ca.n_emit = n_filt;
         ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
         ca.out_fmt = fa.out_fmt; ca.out = fa.out;
+        ca.move_dst = fa.move_dst; ca.move_src = fa.move_src; ca.move_n = fa.move_n;
         KernelTimer kt(c, IQGPU_K_FILTER);
         HIP_TRY(launch_fftconv(ca, c->stream));
     } else {
         KernelTimer kt(c, IQGPU_K_FILTER);
         HIP_TRY(launch_fir(fa, c->stream));
     }
-    // next call's buffer front: history (L-1) + still-pending samples
-    const size_t keep = L1 + (size_t)p.fpending_next;
-    { KernelTimer kt(c, IQGPU_K_MOVE);
-      HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream)); }
+    if (!fused_move) {
+        KernelTimer kt(c, IQGPU_K_MOVE);
+        HIP_TRY(launch_copy_cf((cf2 *)c->fbuf[c->fcur ^ 1].p, fcur + n_filt, (int64_t)keep, c->stream));
+    }
     c->fcur ^= 1;
     c->fpending = p.fpending_next;
     return IQGPU_OK;

@@ -1887,3 +1887,67 @@ def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, sh
         want = np.concatenate([och.process(rb[a * bpf:b * bpf]) for a, b in zip(cuts[:-1], cuts[1:])])
         assert want.size == fused.size
         int_close(fused, want, min_same=0.995)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=257, filter_impl="fft"),
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, filters=(("passband", 158.5e3, 113e3),), filter_taps=1025),
+    dict(in_format="cs16", out_format="cf32", input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("lowpass", 100e3, 0.0),), filter_taps=63),
+    dict(in_format="cs16", out_format="cf32", input_rate_hz=8e3, target_rate_hz=20e3, filters=(("lowpass", 1e3, 0.0),), filter_taps=129),
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("lowpass", 100e3, 0.0),), filter_taps=512, filter_impl="fft",
+         fft_size=2048),
+], ids=["fft257", "fft1025", "fir63", "pre-filter-interp", "fft-blocks"])
+def test_filter_history_moved_inside_the_filter_kernel(gpu, monkeypatch, kw):
+    """The filter's input buffers are a pair: the last workgroup of the filter kernel copies the next call's front (L - 1 samples of
+    history + what an FFT-kind filter still holds back) into the other one (FirArgs::move_*; until round 4 a k_copy_cf launch).
+    Ragged calls, empty ones and calls that emit nothing (the copy kernel steps in: no filter launch): the stream of the copy-kernel
+    path (IQGPU_NO_FUSED_MOVE=1), byte for byte."""
+    n = 700_001
+    raw = synth.raw_stream(n, kw["input_rate_hz"], 91, "cs16")
+    splits = [1, 0, 300_000, 7, 65536, 12345, n - 377_889]
+    assert sum(splits) == n
+    got = run_gpu(gpu, raw, splits=splits, **kw)
+    monkeypatch.setenv("IQGPU_NO_FUSED_MOVE", "1")
+    ref = run_gpu(gpu, raw, splits=splits, **kw)
+    assert got.size == ref.size and got.size > 0
+    assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# lifecycle: what _destroy_dsp_components (src/pipeline.c:148-157) does for the reference's objects
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_create_process_destroy_returns_the_device_memory(gpu):
+    """iqgpu_chain_destroy frees everything a chain took on the device -- tables, histories, the stage buffers that grew with the
+    calls, the pinned staging of submit / collect, streams and events: 60 chains of four shapes created, run (blocking and
+    pipelined) and destroyed leave the free device memory where it was (the allocator may keep a few MB of its own)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                     # the runtime libiqgpu.so itself is linked against (already loaded)
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        fr, tot = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+        return fr.value
+
+    shapes = [dict(NRSC5), dict(NRSC5, agc=True), dict(CONFIG3), dict(CONFIG4),
+              dict(NRSC5, agc=True, agc_profile="local"), dict(NRSC5, target_rate_hz=2.4e6 * 1.5)]
+    raws = {"cs16": synth.raw_stream(1 << 20, 2.4e6, 5, "cs16"), "cu8": synth.raw_stream(1 << 20, 61.44e6, 6, "cu8")}
+
+    def cycle(k):
+        kw = shapes[k % len(shapes)]
+        ch = gpu.Chain(**kw)
+        raw = raws[kw["in_format"]]
+        ch.process(raw)
+        ch.process(raw[:2 * 70001])
+        if k % 3 == 0:
+            ch.process_pipelined(raw[:2 * 300000], 65536)
+        ch.close()
+
+    for k in range(len(shapes)):
+        cycle(k)                                       # whatever the runtime allocates once (code objects, its own pools)
+    free0 = free_bytes()
+    for k in range(60):
+        cycle(k)
+    free1 = free_bytes()
+    assert free0 - free1 < 64 << 20, "device memory not returned: %.1f MB" % ((free0 - free1) / 2**20)
