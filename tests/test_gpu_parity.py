@@ -1951,3 +1951,37 @@ def test_create_process_destroy_returns_the_device_memory(gpu):
         cycle(k)
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20, "device memory not returned: %.1f MB" % ((free0 - free1) / 2**20)
+
+
+@pytest.mark.gpu
+def test_handles_on_their_own_threads_share_the_device(gpu):
+    """include/iqgpu.h: one thread per handle, any number of handles.  Four chains of different shapes, each driven by its own
+    host thread through ragged calls (ctypes drops the GIL inside a call: the launches of the four really interleave on the
+    device, each handle on its own stream), produce the bytes they produce alone."""
+    import threading
+    shapes = [
+        (dict(NRSC5), "cs16", 2.4e6, 11),
+        (dict(NRSC5, agc=True), "cs16", 2.4e6, 12),
+        (dict(in_format="cs16", out_format="cs16", input_rate_hz=10e6, target_rate_hz=2.4e6, dc_block=True, iq_correct=True, iq_mag=0.01,
+              iq_phase=-0.02, filters=(("passband", 158.5e3, 113e3),), filter_taps=257), "cs16", 10e6, 13),
+        (dict(in_format="cu8", out_format="cu8", input_rate_hz=61.44e6, target_rate_hz=1488375.0), "cu8", 61.44e6, 14),
+    ]
+    n = 3_000_000
+    raws = [synth.raw_stream(n, rate, seed, fmt) for _, fmt, rate, seed in shapes]
+    splits = [[1_000_000, 3, 65536, n - 1_065_539], [n // 2, n - n // 2], [700_001, 1_299_999, 1_000_000], [n]]
+    alone = [run_gpu(gpu, raws[i], splits=splits[i], **shapes[i][0]) for i in range(len(shapes))]
+    got, errs = [None] * len(shapes), []
+
+    def worker(i):
+        try:
+            for _ in range(3):                           # a few rounds each: the threads overlap for certain
+                got[i] = run_gpu(gpu, raws[i], splits=splits[i], **shapes[i][0])
+        except Exception as e:                           # noqa: BLE001 -- reported below, in the main thread
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(shapes))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    for i in range(len(shapes)):
+        assert np.array_equal(got[i], alone[i]), i
