@@ -53,13 +53,15 @@ constexpr int kMidEdgeLds = kMidEdgeMax * kWaveLds;
 constexpr int kMidNcoLds = 2 * 1024 * 8;
 constexpr int kMidArbLds = 256 * 14 * 4;                    // the edge waves' table (layout of k_front_s1)
 constexpr int kMidTabLds = kMidNcoLds + kMidArbLds + kFTapLds;
-static_assert(kMidWaves > 12 || kMidTabLds + kMidWaves * kMidWaveLds + kMidEdgeLds <= 160 * 1024, "LDS");
+static_assert(kMidWaves > 12 || kMidTabLds + kMidWaves * kMidWaveLds + kMidEdgeLds + 16 <= 160 * 1024, "LDS");
 
 int front_mid_waves() { return kMidWaves; }
 int front_mid_max_edge_waves() { return kMidEdgeMax; }
 static size_t mid_lds_bytes(int nl, bool nonco)
 {
-    return (size_t)kMidTabLds - (nonco ? kMidNcoLds : 0) + (size_t)kMidWaves * (nl == 8 ? MidGeom<8>::XBYTES : MidGeom<6>::XBYTES) + kMidEdgeLds;
+    // (+ 16: the workgroup's run counter of the fixed-run mode, behind everything else -- a static __shared__ word would move the
+    //  dynamic block off the 8 KB boundary nco_phasor2 relies on)
+    return (size_t)kMidTabLds - (nonco ? kMidNcoLds : 0) + (size_t)kMidWaves * (nl == 8 ? MidGeom<8>::XBYTES : MidGeom<6>::XBYTES) + kMidEdgeLds + 16;
 }   // (no NCO tables without a mixer)
 
 __device__ __forceinline__ float wave_max_f(float m)
@@ -497,6 +499,8 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     fill_tap_planes(s_tap, a.arb_table, tid, kMidThreads, a.tap_fold != 0);
     for (int i = lane; i < G::XBYTES / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < kMidEdgeLds / 16; i += kMidThreads) ((float4 *)arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned *const s_run_next = (unsigned *)(arena + kMidEdgeLds);   // fixed-length runs (w_run_stride): the workgroup's next run
+    if (STEAL && tid == 0) *s_run_next = 0u;
     __syncthreads();
 
     const int64_t gw = (int64_t)blockIdx.x * kMidWaves + wave;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     }
     constexpr bool EDGE = false;                      // (for CLOCK_END: the diagnostic -DIQGPU_CLOCKSTAMP build, tools/clock.py)
     CLOCK_BEGIN;
-    int64_t t0 = 0, t1 = 0, r_cur = -1;
+    int64_t t0 = 0, t1 = 0;
     bool have = false;
     if (gw < a.w_n_edge) {
         // edge work in tiles [0, w_edge_ta) and [w_edge_tb, w_total_tiles) of G::TILE frames, runs of w_edge_tpw of them (768-frame
@@ -523,10 +527,10 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
-        if (r >= a.w_n_stream) return;
+        if (r >= a.w_n_stream || (a.w_run_stride > 0 && r >= a.w_run_stride)) return;
         t0 = w_run_start_weighted(a, r); t1 = w_run_start_weighted(a, r + 1);
-        have = true; r_cur = r;
-        if (STEAL && lane == 0)                      // the static run, open to thieves from here on
+        have = !(STEAL && a.w_run_stride > 0);       // (fixed-length runs: every run comes from the workgroup's queue, below)
+        if (STEAL && have && lane == 0)              // the static run, open to thieves from here on
             __hip_atomic_store(a.w_steal + (size_t)gw * (size_t)a.w_steal_stride, ((unsigned long long)(uint32_t)(t1 - a.w_edge_ta) << 32) | (unsigned long long)(uint32_t)(t0 - a.w_edge_ta),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -546,9 +550,10 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
             asm volatile("" : "+v"(ln));
             if (have) run_mid<NL, NONCO, L3, L4, AGC, true>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
             if (a.w_run_stride > 0) {
-                // fixed-length runs dealt round-robin to the resident waves: the wave's next static run
-                if (r_cur < 0) break;                       // (an edge wave: done)
-                r_cur += a.w_run_stride;
+                // fixed-length runs: the workgroup's next one (an LDS add: no memory traffic, nothing to reset between launches)
+                unsigned k = 0u;
+                if (ln == 0) k = __hip_atomic_fetch_add(s_run_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int64_t r_cur = (int64_t)blockIdx.x + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)k) * (int64_t)gridDim.x;
                 if (r_cur >= a.w_n_stream) break;
                 t0 = w_run_start(a, r_cur); t1 = w_run_start(a, r_cur + 1);
                 if (ln == 0)

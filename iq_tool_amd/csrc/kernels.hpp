@@ -133,9 +133,11 @@ struct FrontArgs {
     // All descriptors are exhausted (next >= end) when a launch ends, which is the state the next launch needs.
     unsigned long long *w_steal;
     int32_t     w_steal_min, w_steal_rounds;   // a run is split only while it has at least w_steal_min unclaimed tiles; sampling rounds before a wave gives up
-    int64_t     w_run_stride;                  // > 0 (fixed-length runs, block_samples != 0): the launch holds ONE round of workgroups and
-                                               // streaming wave s takes runs s, s + w_run_stride, ... (tables and tap planes filled once per
-                                               // workgroup instead of once per 12 runs); 0 = one run per wave
+    int64_t     w_run_stride;                  // > 0 (fixed-length runs, block_samples != 0, more of them than resident waves): the launch holds
+                                               // ONE round of workgroups (tables and tap planes filled once per workgroup instead of once per 12
+                                               // runs) of w_run_stride + w_n_edge waves; workgroup b owns runs b, b + gridDim.x, ... and its waves
+                                               // -- the edge waves too, once their edge runs are done -- take them in order through a counter in
+                                               // LDS (the oldest wave of a SIMD is the fastest: it ends up with more runs).  0 = one run per wave
     int32_t     w_steal_stride, w_steal_lanes; // descriptor w sits at w_steal[w * w_steal_stride] (spread over the memory channels: the claims of
                                                // 3072 waves and the thieves' samples otherwise all land on the few channels that hold 24 KB);
                                                // lanes that sample per round (<= 64)
