@@ -149,14 +149,20 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) load_chunk<4>(src + 16 * c, nxo[c]);
     };
+    // phase of a frame = theta0 + frame * dtheta (mod 2^32): the lane's share of the product once per run, the tile's share on the
+    // scalar unit -- a v_mul_lo_u32 per chunk and tile is a quarter-rate instruction each (4 of the tile's ~340 VALU instructions,
+    // the time of 16)
+    const uint32_t th_lane = a.nco_theta0 + (uint32_t)(4 * lane) * a.nco_dtheta;
+    const uint32_t tho_lane = a.nco_theta0 + (uint32_t)(2 * NL * lane - 19) * a.nco_dtheta;
     auto nco_lookup = [&](int64_t T) {
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(T * G::TILE) * a.nco_dtheta));
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
-            const uint32_t th = a.nco_theta0 + ((uint32_t)(T * G::TILE) + (uint32_t)(256 * c + 4 * lane)) * a.nco_dtheta;
+            const uint32_t th = th_lane + (tb + (uint32_t)(256 * c) * a.nco_dtheta);
             cs_n[c][0] = nco_phasor2(w.nco, th, 0);
             cs_n[c][1] = nco_phasor2(w.nco, th + 2u * a.nco_dtheta, 0);
         }
-        uint32_t tho = a.nco_theta0 + ((uint32_t)(T * G::TILE) + (uint32_t)(2 * NL * lane - 19)) * a.nco_dtheta;
+        uint32_t tho = tho_lane + tb;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             cs_o[i] = nco_phasor2(w.nco, tho, 1);               // the odd stream only meets the centre tap 0.5: half-scaled copy
