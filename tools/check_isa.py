@@ -137,10 +137,9 @@ def check_fat_mid(src, kernel, max_vgpr):
             if re.match(r"ds_read2(st64)?_b(32|64)", t):
                 errors.append("%s: %s holds a %s" % (kernel, cur, t.split()[0])); cur = None
             elif t.startswith("scratch_"):
-                # (the opt-in run-stealing instantiations -- last template argument true -- are an experiment that is off by
-                #  default: the fused-AGC + mixer shape of it holds 24 bytes of scratch outside its tile loop's FMA runs)
-                if not cur.endswith("ELb1EEEvNS_9FrontArgsE") or kernel != "k_front_mid":
-                    errors.append("%s: %s spills to scratch" % (kernel, cur))
+                # (the multi-run instantiations of k_front_mid -- last template argument true: run stealing, fixed-length runs --
+                #  were exempt until the NCO phase left the tile loop's vector multiplies: they hold no scratch either now)
+                errors.append("%s: %s spills to scratch" % (kernel, cur))
                 cur = None
     for m in re.finditer(r"\.amdhsa_kernel (_ZN5iqgpu\d+%sI\w+)\n(.*?)\.end_amdhsa_kernel" % kernel, "\n".join(lines), re.S):
         v = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
