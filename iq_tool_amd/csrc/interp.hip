@@ -68,6 +68,8 @@ __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
         s_arb[arm * kArbWin + k] = a.arb_table[arm * 16 + k];
     }
     for (int i = tid; i < a.n_hb_taps; i += kThreads) s_hb[i] = a.hb_taps[i];
+    if (a.move_n > 0 && blockIdx.x == gridDim.x - 1)
+        for (int64_t i = tid; i < a.move_n; i += kThreads) a.move_dst[i] = a.move_src[i];
 
     const int n0 = kInterpTile >> S;                         // resampler outputs per tile
     const int64_t step = (int64_t)a.step;

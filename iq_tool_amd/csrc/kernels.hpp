@@ -381,6 +381,9 @@ struct InterpArgs {
     const cf2 *nco_tab;
     int32_t    out_fmt;
     void      *out;
+    cf2       *move_dst;      // as FirArgs: the next call's history, into the other buffer of the pair, by the last workgroup
+    const cf2 *move_src;
+    int64_t    move_n;
 };
 // fills ext / lvl_off / in_cap from S, m[], step; returns the input history (samples) k_interp needs
 int make_interp_geometry(InterpArgs &a);

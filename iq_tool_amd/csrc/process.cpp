@@ -273,9 +273,16 @@ int Call::stage_late_resampler()
     ia.hb_taps = c->d_ihb; ia.arb_table = c->d_arb;
     ia.pnco_mode = c->pnco_mode; ia.pnco_theta0 = c->pnco_theta; ia.pnco_dtheta = c->nco_dtheta; ia.nco_tab = c->d_nco_tab;
     ia.out_fmt = fin_fmt; ia.out = fin_out;
+    // the next call's history (the last ihist resampler inputs) into the other buffer of the pair: by k_interp's last workgroup
+    // when it is launched, else by a copy kernel
+    const bool fused_move = p.n_emit > 0 && !(c->dbg & kDbgNoFusedMove);
+    ia.move_dst = nullptr; ia.move_src = nullptr; ia.move_n = 0;
+    if (fused_move) { ia.move_dst = (cf2 *)c->ibuf[c->icur ^ 1].p; ia.move_src = icur + p.n_x; ia.move_n = (int64_t)c->ihist; }
     { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(launch_interp(ia, c->n_cu, c->stream)); }
-    { KernelTimer kt(c, IQGPU_K_MOVE);
-      HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream)); }
+    if (!fused_move) {
+        KernelTimer kt(c, IQGPU_K_MOVE);
+        HIP_TRY(launch_copy_cf((cf2 *)c->ibuf[c->icur ^ 1].p, icur + p.n_x, (int64_t)c->ihist, c->stream));
+    }
     c->icur ^= 1;
     return IQGPU_OK;
 }

@@ -1896,10 +1896,12 @@ def test_agc_fused_in_the_run_time_switched_kernels(gpu, oracle, monkeypatch, sh
     dict(in_format="cs16", out_format="cf32", input_rate_hz=8e3, target_rate_hz=20e3, filters=(("lowpass", 1e3, 0.0),), filter_taps=129),
     dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, filters=(("lowpass", 100e3, 0.0),), filter_taps=512, filter_impl="fft",
          fft_size=2048),
-], ids=["fft257", "fft1025", "fir63", "pre-filter-interp", "fft-blocks"])
+    dict(in_format="cs16", out_format="cs16", input_rate_hz=8e3, target_rate_hz=44.1e3, shift_hz=1e3, shift_after_resample=True),
+], ids=["fft257", "fft1025", "fir63", "pre-filter-interp", "fft-blocks", "interp"])
 def test_filter_history_moved_inside_the_filter_kernel(gpu, monkeypatch, kw):
     """The filter's input buffers are a pair: the last workgroup of the filter kernel copies the next call's front (L - 1 samples of
-    history + what an FFT-kind filter still holds back) into the other one (FirArgs::move_*; until round 4 a k_copy_cf launch).
+    history + what an FFT-kind filter still holds back) into the other one (FirArgs::move_*; until round 4 a k_copy_cf launch);
+    k_interp does the same for the interpolating resampler's input history.
     Ragged calls, empty ones and calls that emit nothing (the copy kernel steps in: no filter launch): the stream of the copy-kernel
     path (IQGPU_NO_FUSED_MOVE=1), byte for byte."""
     n = 700_001
