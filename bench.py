@@ -586,9 +586,9 @@ def main():
             line["config"]["workload"] = "DIAGNOSTIC (IQGPU_BENCH_TARGET_HZ=%s), not a BASELINE config: " % DIAG_TARGET_HZ + str(line["config"]["workload"])
         if args.preset:
             line["config"]["workload"] = ("cs16-fm-nrsc5 preset (iq_tool_presets.conf:216-222): BASELINE configs[1] + digital output AGC -- fused into the "
-                                          "front kernel past the 2 s lock, verified by k_agc_verify; per-kernel ms: "
+                                          "front kernel past the 2 s lock, verified by k_agc_classify (classification + verdict, one launch); per-kernel ms: "
                                           + ", ".join("%s %.3f" % (k, v["ms"] / max(args.steps, 1)) for k, v in prof.items() if v["launches"]))
-            line["roofline"]["kernel"] = front_kernel + " with the fused AGC + k_agc_classify / k_agc_verify"
+            line["roofline"]["kernel"] = front_kernel + " with the fused AGC + k_agc_classify (+ verdict)"
             line["roofline"]["traffic"] = None
         if world == 1 and not args.no_cpu_baseline and args.config == 2 and not args.preset:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)

@@ -337,7 +337,7 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
                 ? monotonic_sec() : 0.0, 0};
             CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
             {   // [0] verdict of the verifier, [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk (agc.hip)
-                const int32_t init[4] = {0, 0, 0, -1};
+                const int32_t init[8] = {0, 0, 0, -1, 0, 0, 0, 0};     // ... [4] the tickets of k_agc_classify's workgroups
                 CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(init)));
                 CREATE_TRY(hipMemcpy(c->d_agc_flag, init, sizeof(init), hipMemcpyHostToDevice));
             }

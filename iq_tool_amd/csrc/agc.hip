@@ -199,9 +199,10 @@ __global__ __launch_bounds__(kThreads) void k_agc_apply(const AgcArgs a)
 // the state advances here: samples_seen, and the strong-peak time of the last healthy chunk.  Anything else sets
 // *verify_flag: the unfused kernels queued behind redo the call from the untouched state.
 // verify_flag[0] = the verdict (the fallback launches' run_if); [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk
-// (reset by k_agc_verify for the next call; zero / -1 at create).  k_agc_classify hands the peak array back zeroed (round 3:
+// (reset by the verdict for the next call; zero / -1 at create; [4] = the tickets of the classification's workgroups).  k_agc_classify hands the peak array back zeroed (round 3:
 // a fill in front of every fused launch did that; folding the classification into the one verdict workgroup was tried and
 // is slower -- 16384 chunks of closed-form bookkeeping on one CU take 30 us).
+__device__ void agc_verdict(const AgcArgs &a);
 __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -236,12 +237,24 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
 #pragma unroll
     for (int k2 = 32; k2 >= 1; k2 >>= 1) { const int o = __shfl_xor(last_h, k2); last_h = o > last_h ? o : last_h; }
     if ((threadIdx.x & 63) == 0 && last_h >= 0) atomicMax(a.verify_flag + 3, last_h);
+    // the verdict, by whichever workgroup is the last to get here (one launch instead of two: n_chunks / 256 tickets on one word --
+    // 64 for a 2^28-frame call -- cost less than the launch they save; a ticket per block of a LARGE grid does not)
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(a.verify_flag + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    agc_verdict(a);
 }
 
-__global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
+// (the body of the verdict: one workgroup of any size)
+__device__ void agc_verdict(const AgcArgs &a)
 {
     __shared__ int s_bad;
-    __shared__ double s_scan[1024];
+    __shared__ double s_scan[256];
     __shared__ double s_carry;
     const int tid = threadIdx.x, nthr = (int)blockDim.x;
     const AgcState st = *a.state;
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
     __syncthreads();
     if (tid == 0) {
         a.verify_flag[0] = s_bad;
-        a.verify_flag[1] = 0; a.verify_flag[2] = 0; a.verify_flag[3] = -1;      // ready for the next call
+        a.verify_flag[1] = 0; a.verify_flag[2] = 0; a.verify_flag[3] = -1; a.verify_flag[4] = 0;      // ready for the next call
         if (!s_bad) {
             AgcState nx = st;
             if (last_healthy >= 0) nx.last_strong = t_of(last_healthy);
@@ -288,8 +301,8 @@ __global__ __launch_bounds__(1024) void k_agc_verify(const AgcArgs a)
 
 hipError_t launch_agc_verify(const AgcArgs &a, hipStream_t s)
 {
-    if (a.geom.n_chunks > 0) hipLaunchKernelGGL(k_agc_classify, dim3((unsigned)((a.geom.n_chunks + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_agc_verify, dim3(1), dim3(1024), 0, s, a);
+    const unsigned nb = a.geom.n_chunks > 0 ? (unsigned)((a.geom.n_chunks + 255) / 256) : 1u;
+    hipLaunchKernelGGL(k_agc_classify, dim3(nb), dim3(256), 0, s, a);        // classification, then the verdict in its last workgroup
     return hipGetLastError();
 }
 

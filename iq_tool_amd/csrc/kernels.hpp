@@ -447,7 +447,7 @@ struct AgcArgs {
     int32_t    out_fmt;
     void      *out;
     const int32_t *run_if;    // not NULL: the three kernels do nothing unless *run_if != 0
-    int32_t   *verify_flag;   // k_agc_verify: set to 1 when the fused pass cannot stand (see agc.hip)
+    int32_t   *verify_flag;   // k_agc_classify's verdict: [0] set to 1 when the fused pass cannot stand (see agc.hip; 8 ints)
     unsigned long long *peak2_fallback;   // k_agc_classify zeroes this one too: the peak array of the conditional fallback launches
     int32_t    peak_approx;   // the fused kernel left float-accumulated peaks (k_front_mid): a chunk within a few ulp of a threshold
                               // is sent to the exact, unfused kernels instead of being classified
