@@ -491,6 +491,23 @@ def main():
 
     import torch
 
+    # This rank onto the socket of ITS GPU -- CPU mask and preferred memory node -- before anything initialises the GPU (the
+    # runtime's helper threads inherit the mask; `import torch` comes first on purpose -- it makes no GPU call, and its bundled HIP
+    # runtime has to be the one the process loads: libiqgpu.so loaded ahead of it brings /opt/rocm's and torch then sees no device) and before any pinned buffer exists (iqgpu_bind_thread_to_device reads sysfs
+    # only: no HIP call).  The reference is one host process (src/pipeline.c:96-116); the placement of N feeding processes on a
+    # two-socket node is this build's to own.  IQGPU_BENCH_NO_BIND=1 leaves the rank where the launcher put it.
+    numa = {"numa_node": -1, "numa_pci_bus_id": "", "numa_bound": False}
+    if os.environ.get("IQGPU_BENCH_STUB") != "1" and os.environ.get("IQGPU_BENCH_NO_BIND") != "1":
+        try:
+            import iq_tool_amd as _pkg
+            node, bdf, err = _pkg.bind_thread_to_device(local_rank)
+            numa = {"numa_node": node, "numa_pci_bus_id": bdf, "numa_bound": err is None and node >= 0}
+            if err:
+                numa["numa_note"] = err
+            numa["cpus_allowed"] = len(os.sched_getaffinity(0))
+        except Exception as exc:                       # placement is best effort: never a reason not to measure
+            numa["numa_note"] = "%s: %s" % (type(exc).__name__, exc)
+
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -516,6 +533,7 @@ def main():
     lib = iq_tool_amd.load()                          # raises when libiqgpu.so is missing
     if lib.iqgpu_device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    local_rank_asked = local_rank
     if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1":
         local_rank %= lib.iqgpu_device_count()        # plumbing check on a box with fewer GPUs than ranks (never a scaling number)
     if local_rank >= lib.iqgpu_device_count():
@@ -526,12 +544,24 @@ def main():
     # which physical device every rank drives (ordinal + PCI bus id, gathered over gloo): an N-rank line shows N distinct GPUs
     import ctypes
     bus = ctypes.create_string_buffer(64)
-    lib.iqgpu_device_pci_bus_id(local_rank, bus, 64)
+    bus_rc = lib.iqgpu_device_pci_bus_id(local_rank, bus, 64)
     mine = {"rank": rank, "ordinal": local_rank, "pci_bus_id": bus.value.decode(), "host": socket.gethostname()}
+    if bus_rc != 0:
+        mine["pci_bus_id_error"] = lib.iqgpu_last_error().decode("utf-8", "replace")
+    mine.update(numa)
+    if mine["numa_pci_bus_id"]:                        # what sysfs said before the runtime was up against what the runtime says now
+        mine["numa_matches_runtime"] = mine["numa_pci_bus_id"].lower() == mine["pci_bus_id"].lower()
+    share = os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1"
+    if local_rank_asked != local_rank:
+        mine["note"] = "rank asked for ordinal %d, shares ordinal %d (IQGPU_BENCH_SHARE_GPU)" % (local_rank_asked, local_rank)
     devices = [mine]
     if dist is not None:
         devices = [None] * world
         dist.all_gather_object(devices, mine)
+    if world > 1 and not share:
+        ids = [(d["host"], d["pci_bus_id"]) for d in devices]
+        if any(d.get("pci_bus_id_error") for d in devices) or len(set(ids)) != world:
+            raise SystemExit("bench.py: %d ranks do not sit on %d distinct GPUs: %s" % (world, world, devices))
 
     case = run_case(args, dist, dev, local_rank, world, rank, args.config, args.preset, args.steps, args.warmup, args.settle_seconds, args.log2_frames)
     front_kernel = case["chain"].front_kernel()
@@ -570,6 +600,9 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(min(frames, 1 << SEGMENT_LOG2))), case["log2_frames"]),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES, "devices": devices,
+                       # every IQGPU_* variable this process saw: the library reads its diagnostic switches from the environment at
+                       # iqgpu_chain_create, so a stray export changes what the line measures -- it is at least on record
+                       "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("IQGPU_")},
                        "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"
                                    + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -590,10 +623,7 @@ def main():
                                           + ", ".join("%s %.3f" % (k, v["ms"] / max(args.steps, 1)) for k, v in prof.items() if v["launches"]))
             line["roofline"]["kernel"] = front_kernel + " with the fused AGC + k_agc_classify (+ verdict)"
             line["roofline"]["traffic"] = None
-        if world == 1 and not args.no_cpu_baseline and args.config == 2 and not args.preset:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
-        else:
-            line["cpu_baseline"] = None
+        line["cpu_baseline"] = None                    # filled in below, once every GPU leg of every rank is done
     # ---- the other single-GPU BASELINE configs and the shipped preset: short legs of their own, after everything that feeds `value`
     # (N = 1 only: they are per-GPU figures, and a leg that failed on one rank of several would leave the others in a barrier)
     sec = extra = None
@@ -613,7 +643,16 @@ def main():
                 extra["reference_binary"] = {"status": "probe failed: %s: %s" % (type(exc).__name__, exc)}
         if not args.no_secondary:
             sec = secondary_cases(args, dist, dev, local_rank, world, rank)
+    # ---- the CPU pipeline "in the same run" (north_star), at every N: rank 0 times it on its own host cores once the GPU legs of
+    # all ranks are behind the barrier (the other ranks are done and idle; a 1-rank run needs no barrier)
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
+        if not args.no_cpu_baseline and args.config == 2 and not args.preset:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_frames_log2)
+            except Exception as exc:
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         line["secondary"] = sec
         line["extra"] = extra
         print(json.dumps(line), flush=True)

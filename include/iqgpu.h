@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IQGPU_ABI_VERSION 4
+#define IQGPU_ABI_VERSION 5
 
 /* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
 enum {
@@ -148,6 +148,16 @@ int         iqgpu_device_count(void);            /* number of HIP devices, 0 if 
 /* PCI bus id ("0000:05:00.0") of device `ordinal` (hipDeviceGetPCIBusId): what a multi-GPU launcher logs to show that its
  * ranks sit on distinct devices (bench.py `config.devices`; the reference has no counterpart: it runs on the host) */
 int         iqgpu_device_pci_bus_id(int ordinal, char *buf, size_t cap);
+/* NUMA placement of whoever feeds a GPU (ABI v5).  No counterpart in the reference: it is one host process whose stage threads
+ * stay on the CPU (src/pipeline.c:96-116); here every bench rank / harness shard thread streams through pinned buffers into ONE
+ * device and should sit on that device's socket.  Both read sysfs only (KFD topology -> PCI address -> numa_node /
+ * local_cpulist) and make NO HIP call, so they can -- and should -- run before the first GPU call of the process or thread and
+ * before its pinned buffers are allocated.  *node = -1 when the host does not say (single node, VM); IQGPU_EUNSUPPORTED when a
+ * *_VISIBLE_DEVICES variable holds something other than indices (the device order is then not derived and nothing is bound).
+ * iqgpu_bind_thread_to_device: sched_setaffinity of the CALLING THREAD to the node's CPUs (intersected with its current mask)
+ * and a preferred-node memory policy for it; threads created afterwards inherit both. */
+int         iqgpu_device_numa_node(int ordinal, int *node, char *pci_bus_id, size_t cap);
+int         iqgpu_bind_thread_to_device(int ordinal, int *node);
 
 /* ---- chain lifecycle: replaces _create_dsp_components/_destroy_dsp_components (src/pipeline.c:138-157) ---- */
 void   iqgpu_chain_desc_init(iqgpu_chain_desc *d);                 /* reference defaults: gain 1, cs16->cs16, no ops */
@@ -274,8 +284,9 @@ void  *iqgpu_chain_get_stream(const iqgpu_chain *c);
 int    iqgpu_chain_synchronize(iqgpu_chain *c);
 int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets every launch with HIP events  */
 int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
-/* name of the front kernel the LAST process call launched ("k_front_mid<6,nco>", "k_front_s1", "k_front_fat",
- * "k_cascade+k_front_s1", "k_front", "k_front+k_interp"; "" before the first call): diagnostics, bench.py's roofline.kernel */
+/* name of the front kernel the LAST process call launched ("k_front_mid<6,nco>", "k_front_mid<6,nonco>", "k_front_mid<8,nco>" (the
+ * outputs per lane of the instantiation and whether it mixes), "k_front_s1", "k_front_fat", "k_front_s2", "k_cascade+k_front_s1",
+ * "k_front", "k_front+k_interp"; "" before the first call): diagnostics, bench.py's roofline.kernel */
 const char *iqgpu_chain_front_kernel(const iqgpu_chain *c);
 
 /* diagnostic hook: copies the chain's 64 KiB scratch (per-phase cycle counters in builds

@@ -2,7 +2,7 @@
 post_processor sample path (see DESIGN.md).  The compute lives in lib/libiqgpu.so (HIP, gfx950);
 importing the package never falls back to a CPU implementation."""
 from ._lib import FMT, IqgpuError, LIB_PATH, load          # noqa: F401
-from .chain import Chain, DeviceBuffer, PinnedBuffer, make_desc   # noqa: F401
+from .chain import Chain, DeviceBuffer, PinnedBuffer, bind_thread_to_device, design_out_frames, make_desc   # noqa: F401
 from .iq_optimizer import IqOptimizer                            # noqa: F401
 
 __all__ = ["Chain", "DeviceBuffer", "PinnedBuffer", "IqOptimizer", "make_desc", "FMT", "IqgpuError", "load", "LIB_PATH"]

@@ -91,6 +91,8 @@ SYMBOLS = [
     ("iqgpu_last_error", C.c_char_p, []),
     ("iqgpu_device_count", C.c_int, []),
     ("iqgpu_device_pci_bus_id", C.c_int, [C.c_int, C.c_char_p, _sz]),
+    ("iqgpu_device_numa_node", C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_char_p, _sz]),
+    ("iqgpu_bind_thread_to_device", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     ("iqgpu_chain_desc_init", None, [C.POINTER(ChainDesc)]),
     ("iqgpu_chain_create", C.c_int, [C.POINTER(ChainDesc), C.POINTER(_vp)]),
     ("iqgpu_chain_destroy", None, [_vp]),

@@ -64,6 +64,28 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
     return d
 
 
+def design_out_frames(frames_in, **kw):
+    """frames a FRESH chain of this description emits for a stream of frames_in frames (iqgpu_design_out_frames: the closed
+    form a stitching writer places shard outputs with; no device needed)"""
+    d = make_desc(**kw)
+    n = C.c_size_t(0)
+    check(_lib.load().iqgpu_design_out_frames(C.byref(d), int(frames_in), C.byref(n)))
+    return int(n.value)
+
+
+def bind_thread_to_device(ordinal):
+    """iqgpu_bind_thread_to_device: the calling thread onto the NUMA node of HIP device `ordinal` (sysfs only, no HIP call --
+    meant to run before the first GPU call and before pinned buffers are allocated).  Returns (node, pci_bus_id, error): node -1
+    when the host does not say or nothing could be bound, error None or the library's message."""
+    lib = _lib.load()
+    node, bus = C.c_int(-1), C.create_string_buffer(64)
+    rc = lib.iqgpu_device_numa_node(int(ordinal), C.byref(node), bus, 64)
+    if rc != 0:
+        return -1, "", lib.iqgpu_last_error().decode("utf-8", "replace")
+    rc = lib.iqgpu_bind_thread_to_device(int(ordinal), C.byref(node))
+    return node.value, bus.value.decode(), (None if rc == 0 else lib.iqgpu_last_error().decode("utf-8", "replace"))
+
+
 class Chain:
     """pre_processor -> resampler -> post_processor for one stream, on one GPU."""
 

@@ -102,6 +102,10 @@ static void free_device_state(iqgpu_chain *c)
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
+// the eight words behind d_agc_flag as a chain starts (and restarts, iqgpu_chain_reset) with them; static storage: the reset's
+// asynchronous copy reads it after the call has returned
+static const int32_t kAgcFlagInit[8] = {0, 0, 0, -1, 0, 0, 0, 0};
+
 template <typename T>
 static int upload(T **dst, const T *src, size_t n)
 {
@@ -337,9 +341,9 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
                 ? monotonic_sec() : 0.0, 0};
             CREATE_TRY(hipMemcpy(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice));
             {   // [0] verdict of the verifier, [1] ratchet seen, [2] weak chunk seen, [3] last healthy chunk (agc.hip)
-                const int32_t init[8] = {0, 0, 0, -1, 0, 0, 0, 0};     // ... [4] the tickets of k_agc_classify's workgroups
-                CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(init)));
-                CREATE_TRY(hipMemcpy(c->d_agc_flag, init, sizeof(init), hipMemcpyHostToDevice));
+                // ... [4] the tickets of k_agc_classify's workgroups (kAgcFlagInit)
+                CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(kAgcFlagInit)));
+                CREATE_TRY(hipMemcpy(c->d_agc_flag, kAgcFlagInit, sizeof(kAgcFlagInit), hipMemcpyHostToDevice));
             }
             // the fused path exists for the specialised front kernel: the shipped cs16 NRSC-5 preset shape
             FrontArgs fa{};
@@ -571,6 +575,9 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     if (c->agc) { // agc_reset, src/agc.c:224-238
         c->agc_init.last_strong = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? monotonic_sec() : 0.0;
         HIP_TRY(hipMemcpyAsync(c->d_agc_state, &c->agc_init, sizeof(AgcState), hipMemcpyHostToDevice, c->stream));
+        // the verifier's words too: a classify launch lost to a device error would leave its ticket counter ([4]) non-zero, no
+        // workgroup of the next launch would then be "the last", and the stale verdict in [0] would stand for ever
+        HIP_TRY(hipMemcpyAsync(c->d_agc_flag, kAgcFlagInit, sizeof(kAgcFlagInit), hipMemcpyHostToDevice, c->stream));
     }
     if (c->late) HIP_TRY(hipMemsetAsync(c->ibuf[c->icur].p, 0, (size_t)c->ihist * sizeof(cf2), c->stream));
     if (c->decim)

@@ -296,6 +296,11 @@ __device__ void agc_verdict(const AgcArgs &a)
             nx.seen = st.seen + (uint64_t)a.n_out;
             *a.state = nx;
         }
+        // ... and to the host, where it waits for the verdict (the state above first: a host that has seen the word may read the state)
+        if (a.verdict_host) {
+            __threadfence_system();
+            __hip_atomic_store(a.verdict_host, s_bad, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -147,6 +147,16 @@ struct iqgpu_chain {
     // flag the verifier leaves for the fallback launches
     bool agc_fusable = false, agc_locked_host = false; uint64_t agc_seen_host = 0;
     int32_t *d_agc_flag = nullptr;
+    // The verdict on the HOST (round 5).  On the paths where the host waits for a call's output anyway -- iqgpu_chain_process, and
+    // submit / collect, whose host moves every batch from stage to stage -- the fallback kernels are not queued behind a fused
+    // launch as four launches that normally return at once (~19 us of a 400 us step): k_agc_classify's verdict also lands in a
+    // word of pinned host memory, the prepared fallback launches wait here, and whoever next needs the stream to be final
+    // (the next call into the chain, the batch's D2H copy, reset / synchronize / get_agc_state) reads the word and launches them
+    // only when it is set.  iqgpu_chain_process_device keeps the queued scheme: its caller owns the stream and its synchronisation.
+    // h_agc_verdict[0]: -1 = a verdict is awaited, 0 / 1 = k_agc_classify's answer
+    volatile int32_t *h_agc_verdict = nullptr; int32_t *d_agc_verdict = nullptr;   // the same word, host and device address
+    bool defer_fallback = false;                // set around process_device_impl by the host-ordered entry points
+    struct PendingVerdict { bool valid = false; bool mid = false; FrontArgs fb; AgcArgs ga; } pend;
     DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
     InterpArgs ia{};              // geometry of the r >= 1 path
     int ihist = 0;
@@ -305,5 +315,8 @@ struct Call {
 int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t frames_in, void *d_out, size_t out_capacity_bytes,
                         size_t *frames_out);                                              // process.cpp
 size_t agc_unfused_head(const iqgpu_chain *c, size_t frames_in, bool *locks);             // agc_host.cpp
+// behind a fused launch whose fallback waits for the verdict on the host: waits for the word, launches the fallback when it is set
+// (*ran = true then).  No-op without a pending verdict.
+int agc_resolve_pending(iqgpu_chain *c, bool *ran = nullptr);                             // agc_host.cpp
 int pipe_advance(iqgpu_chain *c, uint64_t upto);   // pipeline.cpp: queues the kernels of every submitted batch up to ticket `upto`
 int pipe_drain(iqgpu_chain *c, uint64_t upto);     // ... and their D2H copies

@@ -665,6 +665,9 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     int l3 = 0, l4 = 0;
     if (nl == 0 || !mid_class(a.step, nl, &l3, &l4)) return hipErrorInvalidValue;
     const size_t lds = mid_lds_bytes(nl, nonco);
+    // (fixed-length runs dealt out inside a workgroup need the multi-run instantiation, which exists for six outputs per lane only:
+    //  any other shape gets one static run per wave, however the caller filled w_run_stride)
+    if (nl != 6 || a.w_steal == nullptr) a.w_run_stride = 0;
     const int64_t n_items = a.w_n_edge + (a.w_run_stride > 0 && a.w_run_stride < a.w_n_stream ? a.w_run_stride : a.w_n_stream);
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;

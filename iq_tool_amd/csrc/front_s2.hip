@@ -233,6 +233,11 @@ bool front_s2_shape(const FrontArgs &a1)
 hipError_t launch_front_s2(const FrontArgs &a1, const FrontArgs &a2, hipStream_t s)
 {
     if (!front_s2_shape(a1) || a1.rem0 != 0 || a2.rem0 != 0 || a2.agc_fused) return hipErrorInvalidValue;
+    // S2Feed::produce fetches the 512 input frames behind a streaming run's last sub-tile ahead, and the tail of the call must stay
+    // with the edge waves that leave stage 0's history: both hold for the plans plan_geometry makes (a2's streaming region ends
+    // hist2_cap intermediate samples and a whole tile in front of the call's end) -- checked here, not assumed
+    if (a2.w_n_stream > 0 && ((a2.w_edge_tb + 1) * 1024 > a1.frames_in || 1024 * (a2.w_total_tiles - a2.w_edge_tb) < (int64_t)a1.hist_cap))
+        return hipErrorInvalidValue;
     const int64_t n_items = a2.w_n_edge + a2.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kS2Waves - 1) / kS2Waves);
     if (grid == 0) return hipSuccess;

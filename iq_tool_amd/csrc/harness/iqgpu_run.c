@@ -15,7 +15,14 @@
  * --shards N splits the input file into N equal frame ranges, one worker thread (and one GPU,
  * round-robin over --devices) per range, each with fresh state, and stitches the outputs in shard
  * order with pwrite at offsets known up front (the output count of a shard is a closed form):
- * exactly what N iq_tool runs + cat would produce (BASELINE configs[4]).  No collective.
+ * exactly what N iq_tool runs + cat would produce (BASELINE configs[4]).  No collective.  Every shard thread binds itself to
+ * the NUMA node of its GPU before its first GPU call and before it allocates its pinned buffers (iqgpu_bind_thread_to_device),
+ * and fails when the frames its chain produced differ from the count its output offset was planned with.
+ *
+ * --synthetic FRAMES [--synthetic-hash SEED]: no input file.  Without a seed one constant pinned buffer is sent again and again
+ * (the PCIe-inclusive rate of the path, nothing else); with one, shard s is the stream frame n -> splitmix64((SEED + s) * K + n)
+ * of its own (iq_tool_amd/synth.py hash_stream restates it): configs[4] at its real size -- 8 x 2.5 G frames -- without 80 GB of
+ * files, every range of every shard reproducible by the checker.
  */
 #define _GNU_SOURCE
 #define _FILE_OFFSET_BITS 64
@@ -41,6 +48,8 @@ typedef struct {
     size_t chunk_frames;
     int shards, devices, device0;
     long long synthetic_frames;       /* > 0: no input file, reuse one pinned buffer (PCIe-inclusive rate) */
+    int have_hash; unsigned long long hash_seed;   /* ... or generate shard s as the counter-hash stream of seed hash_seed + s */
+    int no_bind;                      /* --no-numa-bind */
     int quiet;
 } Options;
 
@@ -50,12 +59,43 @@ typedef struct {
     long long first_frame, frames;    /* input range */
     long long out_offset_bytes;       /* where this shard's output starts in the output file */
     long long frames_out;             /* result */
+    long long planned_out;            /* iqgpu_design_out_frames(frames): what out_offset_bytes of the NEXT shard was computed from */
+    int device, numa_node;            /* where it ran; -1 = the host does not say / not bound */
     double seconds, stream_seconds;   /* whole shard incl. set-up / copy-process-copy loop only */
     int rc;
     char err[256];
 } Shard;
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+/* frame n of the stream with this seed: splitmix64 of a counter (any range of it can be regenerated, iq_tool_amd/synth.py) */
+static inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+/* cs16: I, Q = the two low 16-bit words as signed values, arithmetic >> 2 (quarter scale: nothing on the path clips); every other
+ * integer format: the low bytes of the hash as they are (full-scale noise) */
+static void hash_fill(void *dst, int fmt, size_t bps, uint64_t seed, long long first, size_t n)
+{
+    const uint64_t base = seed * 0xD1342543DE82EF95ull;
+    if (fmt == IQGPU_FMT_CS16) {
+        int16_t *d = (int16_t *)dst;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t x = mix64(base + (uint64_t)(first + (long long)i));
+            d[2 * i] = (int16_t)((int16_t)(x & 0xffffu) >> 2);
+            d[2 * i + 1] = (int16_t)((int16_t)((x >> 16) & 0xffffu) >> 2);
+        }
+    } else {
+        unsigned char *d = (unsigned char *)dst;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t x = mix64(base + (uint64_t)(first + (long long)i));
+            memcpy(d + i * bps, &x, bps);              /* (little-endian hosts only, like the raw formats themselves) */
+        }
+    }
+}
 
 static int fmt_from_name(const char *s)
 {
@@ -84,6 +124,11 @@ static void *run_shard(void *arg)
     int in_fd = -1, out_fd = -1;
     const double t0 = now_s();
 
+    /* this thread -- and with it the pages it touches first and the buffers it pins -- onto the socket of its GPU, before anything
+     * touches that GPU.  Best effort: a host that hides its topology leaves the thread where it is (numa_node stays -1) */
+    sh->device = d.device_ordinal; sh->numa_node = -1;
+    if (!o->no_bind) { int node = -1; if (iqgpu_bind_thread_to_device(d.device_ordinal, &node) == IQGPU_OK) sh->numa_node = node; }
+
     CK(iqgpu_chain_create(&d, &chain));
     const size_t chunk = o->chunk_frames;
     const size_t out_cap = iqgpu_chain_max_out_frames(chain, chunk) * obps;
@@ -101,7 +146,7 @@ static void *run_shard(void *arg)
     if (o->synthetic_frames <= 0) {
         in_fd = open(o->in_path, O_RDONLY);
         if (in_fd < 0) { snprintf(sh->err, sizeof(sh->err), "open %s: %s", o->in_path, strerror(errno)); sh->rc = -1; goto done; }
-    } else {
+    } else if (!o->have_hash) {
         for (int b = 0; b < NBUF; b++) memset(h_in[b], 0x11 * (b + 1), chunk * ibps);
     }
     if (o->out_path) {
@@ -128,6 +173,9 @@ static void *run_shard(void *arg)
                     if (r <= 0) { snprintf(sh->err, sizeof(sh->err), "pread: %s", r < 0 ? strerror(errno) : "short file"); sh->rc = -1; goto done; }
                     got += (size_t)r;
                 }
+            } else if (o->have_hash) {
+                /* (buffer b is free: chunk i - 2, its last user, retired in the iteration before this one) */
+                hash_fill(h_in[b], d.in_format, ibps, o->hash_seed + (uint64_t)sh->shard, done_in, n);
             }
             CK(iqgpu_memcpy_h2d_async(d_in[b], h_in[b], n * ibps, s_in));
             CK(iqgpu_event_record(e_in[b], s_in));
@@ -154,6 +202,10 @@ static void *run_shard(void *arg)
     }
     sh->frames_out = written;
     sh->stream_seconds = now_s() - t_loop;
+    if (written != sh->planned_out) {
+        snprintf(sh->err, sizeof(sh->err), "shard %d produced %lld frames, its place in the output was planned for %lld", sh->shard, written, sh->planned_out);
+        sh->rc = -1;
+    }
 done:
     if (chain) iqgpu_chain_synchronize(chain);
     for (int b = 0; b < NBUF; b++) {
@@ -182,7 +234,8 @@ static void usage(void)
             "          [--output-sample-format FMT] [--freq-shift HZ] [--shift-after-resample] [--gain G] [--dc-block]\n"
             "          [--iq-factors MAG:PHASE] [--no-resample] [--lowpass HZ] [--highpass HZ] [--pass-range A:B] [--stopband A:B]\n"
             "          [--transition-width HZ] [--attenuation DB] [--filter-taps N] [--filter-type fir|fft] [--filter-fft-size N]\n"
-            "          [--chunk-frames N (default 4194304)] [--shards N] [--devices N] [--device D] [--synthetic FRAMES] [--quiet]\n");
+            "          [--chunk-frames N (default 4194304)] [--shards N] [--devices N] [--device D] [--synthetic FRAMES [--synthetic-hash SEED]]\n"
+            "          [--no-numa-bind] [--quiet]\n");
 }
 
 int main(int argc, char **argv)
@@ -232,10 +285,13 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--devices")) o.devices = atoi(NEXT);
         else if (!strcmp(a, "--device")) o.device0 = atoi(NEXT);
         else if (!strcmp(a, "--synthetic")) o.synthetic_frames = atoll(NEXT);
+        else if (!strcmp(a, "--synthetic-hash")) { o.have_hash = 1; o.hash_seed = strtoull(NEXT, NULL, 0); }
+        else if (!strcmp(a, "--no-numa-bind")) o.no_bind = 1;
         else if (!strcmp(a, "--quiet")) o.quiet = 1;
         else { usage(); return 2; }
     }
     if (o.desc.in_format < 0 || o.desc.out_format < 0) { fprintf(stderr, "unknown sample format\n"); return 2; }
+    if (o.have_hash && (o.synthetic_frames <= 0 || o.desc.in_format == IQGPU_FMT_CF32)) { fprintf(stderr, "--synthetic-hash needs --synthetic FRAMES and an integer input format\n"); return 2; }
     if (!(in_rate > 0) || (!o.desc.no_resample && !(out_rate > 0)) || (!o.in_path && o.synthetic_frames <= 0)) { usage(); return 2; }
     o.desc.input_rate_hz = in_rate; o.desc.target_rate_hz = o.desc.no_resample ? in_rate : out_rate;
     if (o.shards < 1) o.shards = 1;
@@ -265,6 +321,7 @@ int main(int argc, char **argv)
          * or interpolating resampler, FFT-block quantisation in front of or behind it) */
         size_t nout = 0;
         if (iqgpu_design_out_frames(&o.desc, (size_t)sh[s].frames, &nout) != IQGPU_OK) { fprintf(stderr, "%s\n", iqgpu_last_error()); return 1; }
+        sh[s].planned_out = (long long)nout;
         off += (long long)nout * (long long)obps;
     }
     if (o.out_path) { int fd = open(o.out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) close(fd); }
@@ -282,9 +339,17 @@ int main(int argc, char **argv)
         if (sh[s].stream_seconds > stream_s) stream_s = sh[s].stream_seconds;
     }
     const double dt = now_s() - t0;
-    if (!o.quiet)
-        printf("{\"frames_in\": %lld, \"frames_out\": %lld, \"shards\": %d, \"seconds\": %.6f, \"msps_end_to_end\": %.3f, \"stream_seconds\": %.6f, \"msps_streaming\": %.3f, \"in_bytes_per_frame\": %zu, \"out_bytes_per_frame\": %zu}\n",
-               total_frames, frames_out, o.shards, dt, total_frames / dt / 1e6, stream_s, stream_s > 0 ? total_frames / stream_s / 1e6 : 0.0, ibps, obps);
+    if (!o.quiet) {
+        printf("{\"frames_in\": %lld, \"frames_out\": %lld, \"shards\": %d, \"devices\": %d, \"seconds\": %.6f, \"msps_end_to_end\": %.3f, \"stream_seconds\": %.6f, \"msps_streaming\": %.3f, "
+               "\"h2d_GBs\": %.3f, \"d2h_GBs\": %.3f, \"in_bytes_per_frame\": %zu, \"out_bytes_per_frame\": %zu, \"input\": \"%s\", \"per_shard\": [",
+               total_frames, frames_out, o.shards, o.devices, dt, total_frames / dt / 1e6, stream_s, stream_s > 0 ? total_frames / stream_s / 1e6 : 0.0,
+               stream_s > 0 ? (double)total_frames * (double)ibps / stream_s / 1e9 : 0.0, stream_s > 0 ? (double)frames_out * (double)obps / stream_s / 1e9 : 0.0, ibps, obps,
+               o.synthetic_frames <= 0 ? "file" : o.have_hash ? "synthetic-hash" : "synthetic-constant");
+        for (int s = 0; s < o.shards; s++)
+            printf("%s{\"shard\": %d, \"device\": %d, \"numa_node\": %d, \"first_frame\": %lld, \"frames_in\": %lld, \"frames_out\": %lld, \"planned_out\": %lld, \"out_offset_bytes\": %lld, \"seconds\": %.6f}",
+                   s ? ", " : "", s, sh[s].device, sh[s].numa_node, sh[s].first_frame, sh[s].frames, sh[s].frames_out, sh[s].planned_out, sh[s].out_offset_bytes, sh[s].stream_seconds);
+        printf("]}\n");
+    }
     free(th); free(sh);
     return rc;
 }

@@ -451,6 +451,9 @@ struct AgcArgs {
     unsigned long long *peak2_fallback;   // k_agc_classify zeroes this one too: the peak array of the conditional fallback launches
     int32_t    peak_approx;   // the fused kernel left float-accumulated peaks (k_front_mid): a chunk within a few ulp of a threshold
                               // is sent to the exact, unfused kernels instead of being classified
+    int32_t   *verdict_host;  // not NULL: a word of pinned host memory that receives the verdict too (system-scope store): on the paths
+                              // where the host waits for the call anyway it reads the verdict there and launches the fallback kernels
+                              // only when it is set, instead of queueing four launches that return at once (agc_host.cpp)
 };
 hipError_t launch_agc(const AgcArgs &a, hipStream_t s);
 

@@ -139,6 +139,7 @@ int Call::stage_front()
     else if (c->late) { a.out_fmt = IQGPU_FMT_CF32; a.out = icur + c->ihist; }
     else              { a.out_fmt = fin_fmt; a.out = fin_out; }
     a.sink = c->d_sink;
+    char mid_name[48] = "k_front_mid";
 
     if (casc) {
         // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
@@ -203,14 +204,18 @@ int Call::stage_front()
         if (mid && c->steal && fixed_tpw() == 0 && a.w_n_stream >= 64 * (int64_t)front_mid_waves()) {
             a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
             a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = c->steal_rounds;
-        } else if (mid && fixed_tpw() != 0 && a.w_n_stream > wave_slots(front_mid_waves()) - a.w_n_edge) {
+        } else if (mid && front_mid_nl(a) == 6 && fixed_tpw() != 0 && a.w_n_stream > wave_slots(front_mid_waves()) - a.w_n_edge) {
+            // (the multi-run instantiation exists for six outputs per lane only: the 8-per-lane experiment, IQGPU_MID8=1, keeps one
+            //  static run per wave over as many rounds of workgroups as the runs need -- ADVICE r4)
             // block_samples != 0 (BASELINE configs[1] as worded: "256 k-sample blocks"): more fixed-length runs than resident waves --
             // one round of workgroups, every streaming wave takes runs s, s + stride, ... through the multi-run instantiation
             a.w_steal = (unsigned long long *)c->steal_buf.p; a.w_steal_min = c->steal_min;
             a.w_steal_stride = c->steal_stride; a.w_steal_lanes = c->steal_lanes; a.w_steal_rounds = 0;
             a.w_run_stride = wave_slots(front_mid_waves()) - a.w_n_edge;
         }
-        a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (front_mid_nl(a) == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
+        const int mid_nl = mid ? front_mid_nl(a) : 0;
+        a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (mid_nl == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
+        if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s>", mid_nl, c->nco_mode ? "nco" : "nonco");
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : launch_front_s1(a, c->stream)); }
         if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
@@ -220,7 +225,7 @@ int Call::stage_front()
     }
     if (c->decim) c->hist_cur ^= 1;
     snprintf(c->front_kernel, sizeof(c->front_kernel), "%s",
-             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? (c->nco_mode ? "k_front_mid<6,nco>" : "k_front_mid<6,nonco>")
+             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? mid_name
              : fast_s1 ? "k_front_s1" : c->late ? "k_front+k_interp" : "k_front");
     return IQGPU_OK;
 }

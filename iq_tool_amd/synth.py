@@ -78,3 +78,26 @@ def agc_envelope_signal(n, rate_hz, seed):
     env[t > 4.0] = 0.2
     env[t > 11.0] = 1.5
     return x * env
+
+
+def hash_stream(n, seed, fmt="cs16", first=0):
+    """Frames [first, first + n) of the counter-hash stream the harness generates with `--synthetic FRAMES --synthetic-hash SEED`
+    (iq_tool_amd/csrc/harness/iqgpu_run.c hash_fill; shard s of a run uses seed SEED + s and counts from its own frame 0):
+    frame k -> splitmix64(seed * 0xD1342543DE82EF95 + k); cs16 takes the two low 16-bit words as signed values >> 2 (quarter
+    scale), every other integer format the low bytes of the hash as they are.  Any range of a 2.5 G-frame shard is reproducible
+    without the shard."""
+    with np.errstate(over="ignore"):
+        z = np.arange(first, first + n, dtype=np.uint64) + np.uint64((int(seed) * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    if fmt == "cs16":
+        out = np.empty(2 * n, np.int16)
+        out[0::2] = (z & np.uint64(0xFFFF)).astype(np.uint16).view(np.int16) >> 2
+        out[1::2] = ((z >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.uint16).view(np.int16) >> 2
+        return out
+    bps = {"cu8": 2, "cs8": 2, "cu16": 4, "sc16q11": 4, "cs24": 6, "cs32": 8, "cu32": 8}[fmt]
+    b = z.view(np.uint8).reshape(n, 8)[:, :bps].reshape(-1).copy()
+    return b.view({"cu8": np.uint8, "cs8": np.int8, "cu16": np.uint16, "sc16q11": np.int16, "cs24": np.uint8,
+                   "cs32": np.int32, "cu32": np.uint32}[fmt])

@@ -249,8 +249,10 @@ def test_bench_two_ranks_share_the_gpu():
     assert d["roofline"]["launches"] == 3 and d["roofline"]["kernel_ms"] > 0
 
 
-def test_harness_two_devices(gpu, tmp_path):
-    """iqgpu_run --shards 4 --devices 2: shards dealt round-robin over two cards, stitched in file order (skips on a one-GPU box)"""
+def test_harness_two_devices(gpu, oracle, tmp_path):
+    """iqgpu_run --shards 4 --devices 2: shards dealt round-robin over two cards, stitched in file order -- against the
+    concatenation of four ORACLE shard outputs, like every other shard test (the first multi-GPU box must not compare HIP with
+    HIP); byte-equal to four chains on device 0 on top.  Skips on a one-GPU box."""
     if gpu.load().iqgpu_device_count() < 2:
         pytest.skip("needs two HIP devices (BASELINE configs[4] runs one shard per GPU); this box has one")
     n = 4 * 400_000
@@ -259,6 +261,51 @@ def test_harness_two_devices(gpu, tmp_path):
     raw.tofile(fin)
     info = run("-i", str(fin), "-o", str(fout), *ARGS, "--shards", "4", "--devices", "2", "--chunk-frames", "131072")
     got = np.fromfile(fout, np.int16)
-    parts = [gpu.Chain(**NRSC5).process(raw[2 * s * 400_000:2 * (s + 1) * 400_000]) for s in range(4)]
+    bounds = [(s * 400_000, (s + 1) * 400_000) for s in range(4)]
+    int_close(got, np.concatenate(oracle_shards(oracle, raw, bounds, NRSC5)))
+    parts = [gpu.Chain(**NRSC5).process(raw[2 * a:2 * b]) for a, b in bounds]
     assert np.array_equal(got, np.concatenate(parts))
     assert info["shards"] == 4
+    assert [ps["device"] for ps in info["per_shard"]] == [0, 1, 0, 1]
+
+
+def test_harness_real_size_shards_from_the_hash_stream(gpu, oracle):
+    """BASELINE configs[4]'s shard SIZE (more than 2^31 frames, more than 2^33 input bytes per shard) through the harness: two
+    shards of 2^31 + 12345 frames of the counter-hash stream (--synthetic-hash: no 17 GB of files; synth.hash_stream regenerates
+    any range), output stitched in /dev/shm.  Counts and offsets against iqgpu_design_out_frames, the head of BOTH shards
+    against a fresh oracle chain each, the tail of shard 0 against a chain that ran the whole shard in calls of another size
+    (sha256): 32-bit frame counts anywhere in the harness or the plan would show here.  tools/gpu/r5_config5.py is the same
+    at 8 x 2.5 G frames (profiles/r05_config5_1gpu.json)."""
+    import hashlib
+    from iq_tool_amd.chain import design_out_frames
+    per, shards, seed = (1 << 31) + 12345, 2, 40
+    fout = "/dev/shm/iqgpu_test_real_size_%d.cs16" % os.getpid()
+    try:
+        info = run("--synthetic", str(per * shards), "--synthetic-hash", str(seed), "-o", fout, *ARGS, "--shards", str(shards), "--devices", "1")
+        want_n = design_out_frames(frames_in=per, **NRSC5)
+        assert info["frames_in"] == per * shards and info["input"] == "synthetic-hash"
+        for s, ps in enumerate(info["per_shard"]):
+            assert ps["frames_in"] == per and ps["frames_out"] == want_n == ps["planned_out"] and ps["out_offset_bytes"] == 4 * want_n * s, ps
+        assert os.path.getsize(fout) == 4 * want_n * shards
+        out = np.memmap(fout, dtype=np.int16, mode="r")
+        head = 1 << 21
+        for s in range(shards):
+            want = oracle.Chain(**NRSC5).process(synth.hash_stream(head, seed + s, "cs16", 0))
+            int_close(np.asarray(out[2 * want_n * s:2 * want_n * s + want.size]), want)
+        # (the whole of shard 0 again as ONE stream in calls of another size, sha256 against its range of the file, costs half a
+        #  minute of numpy hashing: IQGPU_TEST_FULL_STREAM=1 runs it here; tools/gpu/r5_config5.py always does, at 2.5 G frames)
+        if os.environ.get("IQGPU_TEST_FULL_STREAM") == "1":
+            ch, h, pos, n_out = gpu.Chain(**NRSC5), hashlib.sha256(), 0, 0
+            while pos < per:
+                n = min(1 << 27, per - pos)
+                y = ch.process(synth.hash_stream(n, seed, "cs16", pos))
+                h.update(y.tobytes()); n_out += y.size // 2; pos += n
+            assert n_out == want_n
+            assert hashlib.sha256(np.asarray(out[:2 * want_n]).tobytes()).hexdigest() == h.hexdigest()
+        # the very last output frames of both shards exist and are not the zeros of an unwritten hole
+        for s in range(shards):
+            assert np.any(np.asarray(out[2 * want_n * (s + 1) - 4096:2 * want_n * (s + 1)]) != 0)
+        del out
+    finally:
+        if os.path.exists(fout):
+            os.remove(fout)

@@ -983,6 +983,24 @@ def test_more_fixed_runs_than_resident_waves(gpu, monkeypatch, block_samples):
             assert st_got == st_ref
 
 
+def test_eight_per_lane_experiment_under_fixed_runs(gpu, monkeypatch):
+    """IQGPU_MID8=1 with block_samples = 262144: only the six-per-lane instantiation can deal fixed-length runs out
+    inside a workgroup; the 8-per-lane one must keep one static run per wave over as many rounds of workgroups as the runs need --
+    every streaming run processed, no part of the output left unwritten.  Bytes of the default geometry."""
+    n = (1 << 25) + 4321
+    raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 79, "cs16"), 9)[:2 * n]
+    ref_ch = gpu.Chain(**NRSC5)
+    ref = ref_ch.process(raw)
+    assert ref_ch.front_kernel() == "k_front_mid<6,nco>"
+    monkeypatch.setenv("IQGPU_MID8", "1")
+    for bs in (0, 262144):
+        ch = gpu.Chain(**dict(NRSC5, block_samples=bs))
+        got = ch.process(raw)
+        assert ch.front_kernel() == "k_front_mid<8,nco>", ch.front_kernel()
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (bs, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+
+
 def test_fat_kernel_takes_long_calls_by_itself(gpu):
     """without any switch: a long call runs k_front_mid (iqgpu_chain_front_kernel names what was launched), a 2^20-frame one
     k_front_s1, a 2^24-frame one -- the pipelined host path's batch, 7 tiles per wave -- k_front_mid again (the size rule of

@@ -435,3 +435,67 @@ def test_filter_design_fatal_paths_against_numpy_restatement(lib):
         with pytest.raises(ValueError):
             np_design.design(kw["filters"], kw["input_rate_hz"], kw.get("target_rate_hz", kw["input_rate_hz"]), no_resample=kw.get("no_resample", False),
                              filter_taps=kw.get("filter_taps", 0), impl=kw.get("filter_impl", "auto"), fft_size=kw.get("fft_size", 0))
+
+
+# --------------------------------------------------------------------------------------------
+# NUMA placement of the process / thread that feeds a GPU (iqgpu_device_numa_node, iqgpu_bind_thread_to_device: topology.cpp)
+# against a stand-in sysfs tree shaped like the 8-GPU, two-socket boxes of this pool (IQGPU_SYSFS_ROOT)
+# --------------------------------------------------------------------------------------------
+def _fake_sysfs(root, gpus):
+    """gpus: [(bus, numa_node, cpulist)]; KFD nodes 0, 1 are the two CPU sockets, the GPUs follow in this order"""
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            fh.write(text)
+    nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for n in range(2):
+        put(os.path.join(nodes, str(n), "properties"), "cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (bus, node, cpus) in enumerate(gpus):
+        put(os.path.join(nodes, str(2 + i), "properties"), "cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        dev = os.path.join(root, "bus", "pci", "devices", "0000:%02x:00.0" % bus)
+        put(os.path.join(dev, "numa_node"), "%d\n" % node)
+        put(os.path.join(dev, "local_cpulist"), cpus + "\n")
+
+
+def test_numa_binding_follows_the_device_through_a_stand_in_sysfs(tmp_path):
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two CPUs in the affinity mask")
+    half = len(allowed) // 2
+    lo, hi = allowed[:half], allowed[half:]
+    fmt = lambda cs: ",".join(str(c) for c in cs)       # noqa: E731
+    # four GPUs: two next to the first half of this machine's CPUs ("node 0"), two next to the second ("node 1"); the last entry's
+    # cpulist is a range that also names CPUs this process may not use (the binding intersects with the current mask)
+    gpus = [(0x0d, 0, fmt(lo)), (0x26, 0, fmt(lo)), (0x8e, 1, fmt(hi)), (0xa7, 1, "%d-%d" % (hi[0], hi[-1] + 400))]
+    _fake_sysfs(str(tmp_path), gpus)
+    prog = textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import iq_tool_amd
+        out = {}
+        for o in (0, 3, 1, 7):
+            node, bdf, err = iq_tool_amd.bind_thread_to_device(o)
+            out[str(o)] = dict(node=node, bdf=bdf, err=err, cpus=sorted(os.sched_getaffinity(0)))
+        print(json.dumps(out))
+    """ % ROOT)
+    def run(**env_extra):
+        env = dict(os.environ, IQGPU_SYSFS_ROOT=str(tmp_path), **env_extra)
+        for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            if k not in env_extra:
+                env.pop(k, None)
+        p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    r = run()
+    assert r["0"] == dict(node=0, bdf="0000:0d:00.0", err=None, cpus=lo)
+    # ordinal 3 next: node 1's CPUs are no longer in the mask the first call left -> refused, mask untouched, the error says why
+    assert r["3"]["node"] == 1 and r["3"]["bdf"] == "0000:a7:00.0" and "affinity mask" in r["3"]["err"] and r["3"]["cpus"] == lo
+    assert r["1"] == dict(node=0, bdf="0000:26:00.0", err=None, cpus=lo)
+    assert r["7"]["node"] == -1 and "out of range" in r["7"]["err"]
+    # device selection the way the runtime applies it: ROCR first, HIP on top of it; ordinal 0 is then the GPU on bus a7
+    r = run(ROCR_VISIBLE_DEVICES="1,2,3", HIP_VISIBLE_DEVICES="2,0")
+    assert r["0"] == dict(node=1, bdf="0000:a7:00.0", err=None, cpus=hi)
+    assert r["1"]["bdf"] == "0000:26:00.0" and r["3"]["node"] == -1
+    # UUID lists are not interpreted: nothing is bound and the caller is told
+    r = run(ROCR_VISIBLE_DEVICES="GPU-deadbeef")
+    assert r["0"]["node"] == -1 and "not a list of indices" in r["0"]["err"] and r["0"]["cpus"] == allowed
