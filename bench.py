@@ -49,6 +49,28 @@ OTHER = {
             log2_frames=29, rate=61.44e6, fmt="cu8", bps=2,
             workload="BASELINE configs[3]: cu8 61.44 MS/s -> 1.488375 MS/s, 5 half-bands, 4097-tap real FIR-kind low-pass behind the resampler (the same linear convolution as the time-domain form, executed as 8192-point overlap-save in LDS; the direct-form k_fir takes 6.9 ms for it), cu8 out"),
 }
+# the seven presets the reference ships enabled (/root/reference/iq_tool_presets.conf:190-248), each as the chain it configures for a
+# 2.4 MS/s capture in the preset's own sample format (an RTL-SDR's cu8 for the cu8 presets, cs16 otherwise): target rate, output
+# format, digital output AGC, no dc block / iq correction, and for the -usb / -lsb ones a complex band-pass 102 .. 215 kHz off
+# centre (pass_range a:b = centre (a + b) / 2, bandwidth b - a, src/config.c:203-214; transition width and taps by the
+# reference's defaults) which the reference places BEHIND the resampler (src/filter.c:53-90)
+def _preset(fmt, target, pass_range=None):
+    kw = dict(in_format=fmt, out_format=fmt, input_rate_hz=2.4e6, target_rate_hz=target, agc=True, agc_profile="digital")
+    if pass_range:
+        a, b = pass_range
+        kw["filters"] = (("passband", (a + b) / 2.0, b - a),)
+    return kw
+
+
+PRESETS = {
+    "cu8-nrsc5": _preset("cu8", 1488375.0),
+    "cu8-nrsc5-usb": _preset("cu8", 1488375.0, (102e3, 215e3)),
+    "cu8-nrsc5-lsb": _preset("cu8", 1488375.0, (-215e3, -102e3)),
+    "cs16-fm-nrsc5": _preset("cs16", 744187.5),
+    "cs16-fm-nrsc5-usb": _preset("cs16", 744187.5, (102e3, 215e3)),
+    "cs16-fm-nrsc5-lsb": _preset("cs16", 744187.5, (-215e3, -102e3)),
+    "cs16-am-nrsc5": _preset("cs16", 46511.71875),
+}
 BLOCK_SAMPLES = 0               # auto: one contiguous run of tiles per resident wavefront
 SEGMENT_LOG2 = 22              # synthetic segment generated on the host, tiled on the device
 
@@ -69,11 +91,15 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host_end_to_end leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` legs (BASELINE configs[2], configs[3], the preset with its AGC)")
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--preset-settle", type=float, default=0.4, help="seconds of untimed steps in front of each leg of secondary.presets")
+    ap.add_argument("--only-presets", action="store_true", help="diagnostic: skip the headline legs' extras and run secondary.presets only")
     ap.add_argument("--secondary-settle", type=float, default=0.7, help="seconds of untimed steps in front of each secondary leg")
     ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
     ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
     ap.add_argument("--stub-batch-frames", type=int, default=262144,
                     help="frames per submit() in the host_end_to_end_stub leg: what the INTEGRATION.md binding hands over (16 reference chunks of 16384)")
+    ap.add_argument("--stub64-batch-frames", type=int, default=1048576,
+                    help="frames per submit() in the host_end_to_end_stub64 leg: the stub's batch when the reader queue is deep (64 reference chunks)")
     ap.add_argument("--stub-log2-frames", type=int, default=28, help="frames per GPU streamed in the host_end_to_end_stub leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` legs (stub-sized host batches, block_samples = 262144, reference-binary probe)")
     a = ap.parse_args()
@@ -260,14 +286,20 @@ def step_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
     return f + executed, f + direct
 
 
-def run_case(args, dist, dev, local_rank, world, rank, config, preset, steps, warmup, settle_s, log2_frames):
-    """One timed leg: build the chain of `config` (2, 3, 4; preset = config 2 with the output AGC), put its batch into
-    HBM, settle, warm up, time `steps` steps between barriers.  Returns the raw figures; the caller formats them."""
+def run_case(args, dist, dev, local_rank, world, rank, config, preset, steps, warmup, settle_s, log2_frames, shipped=None):
+    """One timed leg: build the chain of `config` (2, 3, 4; preset = config 2 with the output AGC; shipped = the name of one of
+    PRESETS), put its batch into HBM, settle, warm up, time `steps` steps between barriers.  Returns the raw figures; the caller
+    formats them."""
     import torch
     import iq_tool_amd
     from iq_tool_amd import synth
     chain_kw, rate, fmt, in_bps, workload = (dict(CHAIN, agc=True) if preset else CHAIN), 2.4e6, "cs16", 4, None
-    if config != 2:
+    if shipped:
+        chain_kw = PRESETS[shipped]
+        fmt = chain_kw["in_format"]
+        in_bps = 2 if fmt == "cu8" else 4
+        workload = "preset %s on a 2.4 MS/s %s capture" % (shipped, fmt)
+    elif config != 2:
         o = OTHER[config]
         chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
         if log2_frames == 28:
@@ -310,7 +342,7 @@ def run_case(args, dist, dev, local_rank, world, rank, config, preset, steps, wa
 
     front = prof["front"]
     k_ms = front["ms"] / max(front["launches"], 1)
-    if config != 2 or preset:
+    if config != 2 or preset or shipped:
         # these run several kernels per step (cascade, last stage, dc carries, filter, AGC verdict):
         # price the whole step's device time, not one of them
         k_ms = sum(v["ms"] for v in prof.values()) / max(steps, 1)
@@ -393,6 +425,29 @@ def secondary_case(args, dist, dev, local_rank, world, rank, name, cfg, preset):
     e["traffic_over_algorithmic"] = round(tb / c["alg_bytes"], 3) if tb else None
     c["chain"].close()
     return e
+
+
+def shipped_presets(args, dist, dev, local_rank, world, rank):
+    """every preset of iq_tool_presets.conf:190-248 as a short device-resident leg: ms per 2^28-frame step, the HBM fraction of the
+    whole step (algorithmic bytes in + out over the device time of all its kernels), which kernels ran and what each took"""
+    import torch
+    out = {}
+    for name in PRESETS:
+        try:
+            c = run_case(args, dist, dev, local_rank, world, rank, 2, False, args.secondary_steps, 2, args.preset_settle, 28, shipped=name)
+            out[name] = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "frames_per_step": c["frames"],
+                         "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1),
+                         "hbm_GBs": round(c["achieved"], 1), "frac": round(c["achieved"] / HBM_PEAK_GBS, 4), "kernel_ms": round(c["k_ms"], 4),
+                         "front_kernel": c["chain"].front_kernel(),
+                         "kernels": {k: round(v["ms"] / max(c["steps"], 1), 4) for k, v in c["prof"].items() if v["launches"]},
+                         "timed_stages_per_step": round(sum(v["launches"] for v in c["prof"].values()) / max(c["steps"], 1), 2),
+                         "chain": "%s 2.4 MS/s -> %s %.5f kS/s, digital AGC%s" % (PRESETS[name]["in_format"], PRESETS[name]["out_format"],
+                                  PRESETS[name]["target_rate_hz"] / 1e3, ", complex band-pass behind the resampler" if "filters" in PRESETS[name] else "")}
+            c["chain"].close()
+        except Exception as exc:
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def reference_binary_probe(frames_log2=24):
@@ -588,7 +643,17 @@ def main():
                      "us_per_batch": round(s_dt / (s_frames / args.stub_batch_frames) * 1e6, 2),
                      "h2d_GBs": round(s_up / s_dt / 1e9, 2), "d2h_GBs": round(s_down / s_dt / 1e9, 2), "frames_per_gpu": s_frames,
                      "kernel": chain.front_kernel(),
-                     "path": "as host_end_to_end, at the batch the INTEGRATION.md section 2 stub submits (16 x PIPELINE_CHUNK_BASE_SAMPLES, include/constants.h:123)"}
+                     "path": "as host_end_to_end, at the batch the INTEGRATION.md section 2 stub submits when its reader queue holds 16 chunks (16 x PIPELINE_CHUNK_BASE_SAMPLES, include/constants.h:123)"}
+    # ... and at the batch the stub takes when the reader runs ahead (a file input: the pool holds 512 chunks, include/constants.h:110)
+    host_stub64 = None
+    if host_stub is not None:
+        chain.reset()
+        s_dt, s_frames, s_up, s_down = host_leg(dist, chain, seg, 1 << (args.stub_log2_frames + 1), args.stub64_batch_frames)
+        host_stub64 = {"value": round(world * s_frames / s_dt / 1e6, 2), "unit": "MS/s", "batch_frames": args.stub64_batch_frames,
+                       "us_per_batch": round(s_dt / (s_frames / args.stub64_batch_frames) * 1e6, 2),
+                       "h2d_GBs": round(s_up / s_dt / 1e9, 2), "d2h_GBs": round(s_down / s_dt / 1e9, 2), "frames_per_gpu": s_frames,
+                       "kernel": chain.front_kernel(),
+                       "path": "as host_end_to_end_stub, at the 64-chunk batch the stub takes when reader_output_queue is deep (file inputs)"}
 
     if rank == 0:
         line = {
@@ -631,7 +696,7 @@ def main():
         case = chain = None
         torch.cuda.empty_cache()
         if not args.no_extra:
-            extra = {"host_end_to_end_stub": host_stub}
+            extra = {"host_end_to_end_stub": host_stub, "host_end_to_end_stub64": host_stub64}
             try:
                 extra["block_samples_262144"] = device_residency_leg(args, dist, dev, local_rank, world, rank, 262144, args.secondary_steps)
             except Exception as exc:
@@ -642,7 +707,11 @@ def main():
             except Exception as exc:
                 extra["reference_binary"] = {"status": "probe failed: %s: %s" % (type(exc).__name__, exc)}
         if not args.no_secondary:
-            sec = secondary_cases(args, dist, dev, local_rank, world, rank)
+            sec = {} if args.only_presets else secondary_cases(args, dist, dev, local_rank, world, rank)
+            try:
+                sec["presets"] = shipped_presets(args, dist, dev, local_rank, world, rank)
+            except Exception as exc:
+                sec["presets"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # ---- the CPU pipeline "in the same run" (north_star), at every N: rank 0 times it on its own host cores once the GPU legs of
     # all ranks are behind the barrier (the other ranks are done and idle; a 1-rank run needs no barrier)
     if dist is not None:

@@ -75,6 +75,7 @@ static void free_device_state(iqgpu_chain *c)
     if (c->d_agc_state) (void)hipFree(c->d_agc_state);
     c->abuf.release(); c->agc_peak.release(); c->agc_gain.release(); c->agc_peak_b.release(); c->agc_hist.release();
     if (c->d_agc_flag) (void)hipFree(c->d_agc_flag);
+    if (c->h_agc_verdict) (void)hipHostFree((void *)c->h_agc_verdict);
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     for (int i = 0; i < 2; ++i) if (c->d_hist2[i]) (void)hipFree(c->d_hist2[i]);
@@ -344,6 +345,12 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
                 // ... [4] the tickets of k_agc_classify's workgroups (kAgcFlagInit)
                 CREATE_TRY(hipMalloc((void **)&c->d_agc_flag, sizeof(kAgcFlagInit)));
                 CREATE_TRY(hipMemcpy(c->d_agc_flag, kAgcFlagInit, sizeof(kAgcFlagInit), hipMemcpyHostToDevice));
+                // the verdict's second home: one word of pinned, device-visible host memory (chain.hpp, h_agc_verdict)
+                void *hv = nullptr, *dv = nullptr;
+                CREATE_TRY(hipHostMalloc(&hv, 64, hipHostMallocMapped | hipHostMallocCoherent));
+                c->h_agc_verdict = (volatile int32_t *)hv; c->h_agc_verdict[0] = 0;
+                CREATE_TRY(hipHostGetDevicePointer(&dv, hv, 0));
+                c->d_agc_verdict = (int32_t *)dv;
             }
             // the fused path exists for the specialised front kernel: the shipped cs16 NRSC-5 preset shape
             FrontArgs fa{};
@@ -428,6 +435,7 @@ extern "C" void iqgpu_chain_destroy(iqgpu_chain *c)
     (void)hipSetDevice(c->device);
     (void)pipe_advance(c, c->pipe_seq);            // batches submitted and never collected still run to completion
     (void)pipe_drain(c, c->pipe_seq);
+    (void)agc_resolve_pending(c);
     (void)hipStreamSynchronize(c->stream);
     for (hipStream_t st : c->pipe_d2h) if (st) (void)hipStreamSynchronize(st);
     free_device_state(c);
@@ -568,6 +576,8 @@ extern "C" int iqgpu_chain_reset(iqgpu_chain *c)
     HIP_TRY(hipSetDevice(c->device));
     // pre_processor_reset (dc state, NCO phase, filter), resampler_reset, post_processor_reset
     { const int rc = pipe_advance(c, c->pipe_seq); if (rc && !c->poisoned) return rc; }   // batches in flight come first (same stream)
+    { const int rc = agc_resolve_pending(c); if (rc && !c->poisoned) return rc; }        // ... and what their last fused launch owes
+    c->pend.valid = false;
     c->poisoned = false;
     c->rem = 0; c->phi = 0; c->nco_theta = 0; c->pnco_theta = 0;
     c->agc_locked_host = false; c->agc_seen_host = 0; c->agc_peak_clean = false; c->agc_rms_pos = 0;
@@ -601,6 +611,7 @@ extern "C" int iqgpu_chain_get_agc_state(iqgpu_chain *c, iqgpu_agc_state *st)
     static_assert(sizeof(iqgpu_agc_state) == sizeof(AgcState), "AGC state layout");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc; }     // batches submitted and not yet collected
+    { const int rc = agc_resolve_pending(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(st, c->d_agc_state, sizeof(AgcState), hipMemcpyDeviceToHost));
     return IQGPU_OK;
@@ -622,6 +633,7 @@ extern "C" int iqgpu_chain_set_stream(iqgpu_chain *c, void *hip_stream)
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc; }
+    { const int rc = agc_resolve_pending(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return IQGPU_OK;
@@ -631,7 +643,7 @@ extern "C" int iqgpu_chain_synchronize(iqgpu_chain *c)
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     HIP_TRY(hipSetDevice(c->device));
-    { int rc = pipe_advance(c, c->pipe_seq); if (!rc) rc = pipe_drain(c, c->pipe_seq); if (rc) return rc; }
+    { int rc = pipe_advance(c, c->pipe_seq); if (!rc) rc = pipe_drain(c, c->pipe_seq); if (!rc) rc = agc_resolve_pending(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (hipStream_t st : c->pipe_d2h) if (st) HIP_TRY(hipStreamSynchronize(st));
     return IQGPU_OK;

@@ -61,18 +61,30 @@ int Call::stage_agc()
     return IQGPU_OK;
 }
 
-// behind a fused front launch: the verifier, then the unfused kernels as launches that do nothing unless the
-// verifier raised its flag (same input, same history buffers, the untouched AGC state)
+// behind a fused front launch: the verifier, then the unfused kernels -- same input, same history buffers, the untouched AGC
+// state -- either queued right behind it as launches that do nothing unless the verifier raised its flag (iqgpu_chain_process_device:
+// the caller owns the stream, nothing may be left for later), or kept here until the host has read the verdict from its pinned word
+// (defer_fallback: iqgpu_chain_process and submit / collect, where the host waits for the call anyway; agc_resolve_pending)
+static hipError_t launch_agc_fallback(iqgpu_chain *c, const FrontArgs &fb, const AgcArgs &ga)
+{
+    hipError_t e = launch_front_s1(fb, c->stream);
+    if (e != hipSuccess) return e;
+    return launch_agc(ga, c->stream);
+}
+
 int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
 {
+    const bool defer = c->defer_fallback && c->h_agc_verdict != nullptr;
     AgcArgs va = agc_args();
     va.verify_flag = c->d_agc_flag;
     va.peak_approx = mid ? 1 : 0;
     va.peak2_fallback = (unsigned long long *)c->agc_peak_b.p;
+    va.verdict_host = defer ? c->d_agc_verdict : nullptr;
     KernelTimer kt(c, IQGPU_K_AGC);
+    if (defer) c->h_agc_verdict[0] = -1;               // (written before the launch is queued: the kernel's store comes later)
     HIP_TRY(launch_agc_verify(va, c->stream));
     FrontArgs fb = spec;
-    fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr; fb.w_steal = nullptr;
+    fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr; fb.w_steal = nullptr; fb.w_run_stride = 0;
     fb.out_fmt = IQGPU_FMT_CF32; fb.out = c->abuf.p;
     fb.run_if = c->d_agc_flag;
     if (fat || mid) {
@@ -82,12 +94,51 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
         if (warm < 1) warm = 1;
         plan_front_s1(fb, wave_slots(front_s1_waves(fb)), fixed_tpw(), warm, 1, kWTile);
     }
-    HIP_TRY(launch_front_s1(fb, c->stream));
     AgcArgs ga = va;
-    ga.peak2_fallback = nullptr;
+    ga.peak2_fallback = nullptr; ga.verdict_host = nullptr;
     ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
     ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
-    HIP_TRY(launch_agc(ga, c->stream));
+    if (defer) {
+        c->pend.valid = true; c->pend.fb = fb; c->pend.ga = ga;
+        return IQGPU_OK;
+    }
+    HIP_TRY(launch_agc_fallback(c, fb, ga));
+    return IQGPU_OK;
+}
+
+// The host's half of the deferred scheme: wait for k_agc_classify's verdict in the pinned word (the kernel is normally long done:
+// the word is polled, no runtime call), and launch the fallback only when it is set.  Called by everything that needs the stream
+// final or is about to queue work that touches the buffers the fallback reads: the next process call, the batch's D2H copy, reset,
+// synchronize, get_agc_state, set_stream, destroy.
+int agc_resolve_pending(iqgpu_chain *c, bool *ran)
+{
+    if (ran) *ran = false;
+    if (!c->pend.valid) return IQGPU_OK;
+    int32_t v = c->h_agc_verdict[0];
+    if (v < 0) {
+        const double t0 = monotonic_sec();
+        while ((v = c->h_agc_verdict[0]) < 0) {
+            if (monotonic_sec() - t0 > 0.25) {
+                // a quarter of a second without an answer: let the runtime wait for the stream (and report a dead one)
+                const hipError_t e = hipStreamSynchronize(c->stream);
+                v = c->h_agc_verdict[0];
+                if (e != hipSuccess || v < 0) {
+                    c->pend.valid = false; c->poisoned = true;
+                    return fail(IQGPU_EHIP, "the AGC verdict of a fused launch never arrived: %s", e != hipSuccess ? hipGetErrorString(e) : "stream idle, word unwritten");
+                }
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    c->pend.valid = false;
+    if (v == 0) return IQGPU_OK;
+    KernelTimer kt(c, IQGPU_K_AGC);
+    const hipError_t e = launch_agc_fallback(c, c->pend.fb, c->pend.ga);
+    if (e != hipSuccess) { c->poisoned = true; return fail(IQGPU_EHIP, "AGC fallback launch failed: %s", hipGetErrorString(e)); }
+    if (ran) *ran = true;
     return IQGPU_OK;
 }
 

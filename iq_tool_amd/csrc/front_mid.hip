@@ -78,13 +78,18 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // L3 = floor(3 step / 2^24) of the step class (lo_0 .. lo_2 = 0, 1, 3).
 // STEAL (run stealing, kernels.hpp): the run's end is whatever the wave's descriptor `desc` says when a tile is claimed -- one
 // returning agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
-template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL>
+// CF32OUT: the outputs leave as cf32 (a user filter behind the resampler: the -usb / -lsb presets) instead of packed cs16
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, int64_t T_emit1, unsigned long long *const desc)
 {
     typedef MidGeom<NL> G;
     constexpr int NS = G::NS;
+#ifdef IQGPU_DIAG_LEAN
+    constexpr bool kLean = true;                            // DIAGNOSTIC: the order without anything fetched ahead at 12 waves per CU
+#else
     constexpr bool kLean = kMidWaves > 12 || NL == 8;       // (8 per lane at 3 waves per SIMD: 168 VGPRs leave no room to fetch a phase ahead)
+#endif
     constexpr int LO[5] = {0, 1, 3, L3, L4};
     auto addr_rt = [](int rc) { return NL == 6 ? 8 * rc : (rc >> 3) * 80 + (rc & 7) * 8; };
     char *XE = w.XE, *HB = w.XE;
@@ -192,10 +197,24 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // (the empty asm with a memory clobber orders the LDS accesses around it already when the instruction stream is first laid
     //  out -- sched_barrier by itself only stops the machine scheduler, and the loads had floated above it before that)
 #define FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef IQGPU_DIAG_NOGATHER
+    // DIAGNOSTIC build (timing only, wrong bytes): the tap gather runs ONCE per run and the taps stay in their registers -- what a
+    // polyphase stage that re-reads a slot only when its arm moves on could save at most (round 5, profiles/r05_headline.md)
+    bool diag_first = true;
+    auto taps = [&](v2f (&t)[8], unsigned row) {
+        if (diag_first) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + tap_pair_off(i));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t[i]));
+    };
+#else
     auto taps = [&](v2f (&t)[8], unsigned row) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = *(lds_v2f *)(size_t)(row + tap_pair_off(i));
     };
+#endif
     // ---- pointwise, chunk by chunk: unpack, mix, -> XE / XO (on top of the half-band stream: its window reads are issued)
     auto VL_point = [&]() {
         if (lane < 48) *(float *)(XE + sl_dst) = sl_e;
@@ -262,6 +281,14 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
             }
             agc_T += 1;
         }
+        if constexpr (CF32OUT) {
+            // the lane's NS - 1 or NS outputs are consecutive: 8-byte aligned cf32, NS - 1 of them always
+            typedef float f32x2 __attribute__((ext_vector_type(2), aligned(8)));
+            char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 8;
+#pragma unroll
+            for (int j = 0; j < NS - 1; ++j) *(f32x2 *)(ob + 8 * j) = f32x2{y[j].x, y[j].y};
+            if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(f32x2 *)(ob + 8 * (NS - 1)) = f32x2{y[NS - 1].x, y[NS - 1].y};
+        } else {
         uint32_t pk[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) pk[j] = pack_cs16(cf2{y[j].x, y[j].y});
@@ -272,6 +299,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         if constexpr (NS == 4) *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
         else *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
         if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 4 * (NS - 1)) = pk[NS - 1];
+        }
         // (all in 32 bits: delta0 + n_est step < SPAN <=> delta0 < span_rem, and nt step - SPAN is step - span_rem or -span_rem)
         const bool more = delta0 < span_rem;
         k_tile0 += n_est + (more ? 1u : 0u);
@@ -329,6 +357,21 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         taps(tp[0], trow[0]); taps(tp[1], trow[1]);
         pp_slots2<NL, 0, 1>(Hw, own, tp[0], tp[1], y[0], y[1]);
         FENCE();
+#ifdef IQGPU_DIAG_NOGATHER
+        if constexpr (NS == 4) {                      // (four register sets: every slot keeps its own)
+#ifdef IQGPU_DIAG_NOGATHER2
+            // ... or slots 0 and 1 only: slots 2 and 3 are gathered every tile as in the shipped kernel (fits 168 VGPRs without spills)
+            { const bool keep_first = diag_first; diag_first = true; taps(tq[0], trow[2]); taps(tq[1], trow[3]); diag_first = keep_first; }
+#else
+            taps(tq[0], trow[2]); taps(tq[1], trow[3]);
+#endif
+            pp_slots2<NL, 3, L3>(Hw, own, tq[0], tq[1], y[2], y[3]);
+            keep(y[NS - 1]);
+            V_emit();
+            diag_first = false;
+            return;
+        }
+#endif
         taps(tp[0], trow[2]); taps(tp[1], trow[3]);
         if constexpr (NS == 5) taps(tq[0], trow[4]);
         pp_slots2<NL, 3, L3>(Hw, own, tp[0], tp[1], y[2], y[3]);
@@ -387,7 +430,13 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     auto claimed_end = [&]() { return a.w_edge_ta + (int64_t)__builtin_amdgcn_readfirstlane((int)(cv >> 32)); };
     for (int64_t T = T_begin; T < T_emit0; ++T) tile(T, false, false);     // warm-up tiles
     if (STEAL) claim();
+#ifdef IQGPU_DIAG_NOGATHER
+    if (!kLean) { taps(tq[0], trow[2]); taps(tq[1], trow[3]); }
+#endif
     tile(T_emit0, false, true);                                              // the first emitting tile: no polyphase in front of it yet
+#ifdef IQGPU_DIAG_NOGATHER
+    if (!kLean) diag_first = false;
+#endif
     if (STEAL) T_emit1 = claimed_end();
     for (int64_t T = T_emit0 + 1; T < T_emit1; ++T) {                       // steady state
         if (STEAL) claim();
@@ -473,7 +522,7 @@ __device__ __forceinline__ bool steal_run(const FrontArgs &a, const int64_t gw, 
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
-template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL>
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false>
 __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 {
     typedef MidGeom<NL> G;
@@ -547,14 +596,14 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
     unsigned n_stolen = 0;
     if constexpr (!STEAL) {
-        if (have) run_mid<NL, NONCO, L3, L4, AGC, false>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, nullptr);
+        if (have) run_mid<NL, NONCO, L3, L4, AGC, false, CF32OUT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, nullptr);
     } else {
         for (;;) {
             // (the lane index made opaque per run: nothing a run derives from it is then hoisted out of this loop and held --
             //  spilled -- across the tile loop of every run)
             int ln = (int)__lane_id();
             asm volatile("" : "+v"(ln));
-            if (have) run_mid<NL, NONCO, L3, L4, AGC, true>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
+            if (have) run_mid<NL, NONCO, L3, L4, AGC, true, CF32OUT>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
             if (a.w_run_stride > 0) {
                 // fixed-length runs: the workgroup's next one (an LDS add: no memory traffic, nothing to reset between launches)
                 unsigned k = 0u;
@@ -641,13 +690,15 @@ static bool mid_class(uint32_t step, int nl, int *l3, int *l4)
 // outputs per lane of the k_front_mid instantiation for these arguments: 6 (8 on request); 0 = not this kernel's shape
 int front_mid_nl(const FrontArgs &a)
 {
-    if (!(a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && a.out_fmt == IQGPU_FMT_CS16 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
+    // (cf32 out: a user filter behind the resampler takes the samples -- the -usb / -lsb presets; six outputs per lane, no fused AGC)
+    const bool cf32_out = a.out_fmt == IQGPU_FMT_CF32 && !a.agc_fused;
+    if (!(a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && (a.out_fmt == IQGPU_FMT_CS16 || cf32_out) && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
           a.pnco_mode == 0 && !(a.dbg & (kDbgNoFast | kDbgNoFat)))) return 0;
     int l3, l4;
     for (int nl : {8, 6}) {
         // 8 per lane is an experiment (IQGPU_MID8=1): in 168 VGPRs it has no room to fetch a phase ahead, and without that it runs
         // 0.440 ms against 0.384 for 6 per lane on the NRSC-5 chain; with the fused AGC it does not fit at all
-        if (nl == 8 && (!(a.dbg & kDbgMid8) || a.agc_fused)) continue;
+        if (nl == 8 && (!(a.dbg & kDbgMid8) || a.agc_fused || cf32_out)) continue;
         if (!mid_class(a.step, nl, &l3, &l4)) continue;
         if (a.agc_fused && !(a.agc_shift == 1 && a.agc_chunk_frames >= 128 * nl)) continue;
         return nl;
@@ -667,22 +718,27 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
     const size_t lds = mid_lds_bytes(nl, nonco);
     // (fixed-length runs dealt out inside a workgroup need the multi-run instantiation, which exists for six outputs per lane only:
     //  any other shape gets one static run per wave, however the caller filled w_run_stride)
-    if (nl != 6 || a.w_steal == nullptr) a.w_run_stride = 0;
+    if (nl != 6 || a.w_steal == nullptr || a.out_fmt == IQGPU_FMT_CF32) { a.w_run_stride = 0; if (a.out_fmt == IQGPU_FMT_CF32) a.w_steal = nullptr; }
     const int64_t n_items = a.w_n_edge + (a.w_run_stride > 0 && a.w_run_stride < a.w_n_stream ? a.w_run_stride : a.w_n_stream);
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, STEAL)                                                            \
+#define IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, STEAL, CF)                                                        \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_mid<NL, NONCO, L3, L4, AGC, STEAL>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC, STEAL>), dim3(grid), dim3(kMidThreads), lds, s, a); \
+        { const hipError_t e = cache.ensure((const void *)k_front_mid<NL, NONCO, L3, L4, AGC, STEAL, CF>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_mid<NL, NONCO, L3, L4, AGC, STEAL, CF>), dim3(grid), dim3(kMidThreads), lds, s, a); \
     } while (0)
     /* run stealing: six outputs per lane only, and only when the host provides descriptors and asks for it */
     const bool steal = a.w_steal != nullptr && (a.w_steal_rounds > 0 || a.w_run_stride > 0);
+    /* cf32 out (a user filter behind the resampler): six per lane, static runs, no fused AGC */
+    const bool cf = a.out_fmt == IQGPU_FMT_CF32;
+    if (cf && (nl != 6 || a.agc_fused)) return hipErrorInvalidValue;
+    if (cf) { a.w_steal = nullptr; a.w_run_stride = 0; }
 #define IQGPU_LAUNCH_MID(NL, NONCO, L3, L4, AGC)                                                                    \
     do {                                                                                                              \
-        if (NL == 6 && steal) IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, (NL == 6));                                 \
-        else IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, false);                                                      \
+        if (NL == 6 && cf) IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, false, false, (NL == 6));                           \
+        else if (NL == 6 && steal) IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, (NL == 6), false);                     \
+        else IQGPU_LAUNCH_MID1(NL, NONCO, L3, L4, AGC, false, false);                                               \
     } while (0)
 #define IQGPU_LAUNCH_MID2(NL, L3, L4)                                                                               \
     do {                                                                                                              \

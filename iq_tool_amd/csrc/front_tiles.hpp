@@ -189,7 +189,8 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
     const float inv_step = 1.0f / (float)step;
     uint64_t k_tile0 = first_k_at((uint64_t)(t_emit0 * 256) << 24, a.phi0, step);
     uint32_t delta0 = (uint32_t)(a.phi0 + k_tile0 * (uint64_t)step - ((uint64_t)(t_emit0 * 256) << 24));   // < step
-    const int obps = FAST ? 4 : out_bytes(a.out_fmt);
+    // (the streaming FAST instantiations write cs16; their EDGE siblings may be asked for cf32 as well: k_front_mid in front of a user filter)
+    const int obps = (FAST && !EDGE) ? 4 : out_bytes(a.out_fmt);
     const bool unit_gain = FAST || a.gain == 1.0f;
     // FAST: the same outputs-per-tile count and lane phases without a division in the loop
     const uint32_t n_est = (uint32_t)(((uint64_t)1 << 32) / step);
@@ -575,7 +576,7 @@ __device__ __forceinline__ void run_tiles(const FrontArgs &a, const WaveLds &w, 
                         }
                         if (defer) pk[r] = out_b8 ? pack_b8(cf2{yy.x, yy.y}, a.out_fmt == IQGPU_FMT_CU8) : pack_cs16(cf2{yy.x, yy.y});
                         else if (defer_f) pf[r] = cf2{yy.x, yy.y};
-                        else pack_store_at(obase, kk, FAST ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
+                        else pack_store_at(obase, kk, (FAST && !EDGE) ? (int)IQGPU_FMT_CS16 : a.out_fmt, cf2{yy.x, yy.y});
                     }
                     kk += hit[r] ? 1u : 0u;
                 }

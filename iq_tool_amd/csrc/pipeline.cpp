@@ -40,11 +40,22 @@ int pipe_advance(iqgpu_chain *c, uint64_t upto)
         iqgpu_chain::PipeSlot &ps = c->pipe[c->pipe_launched % iqgpu_chain::kPipeSlots];
         HIP_TRY(hipSetDevice(c->device));
         int rc = IQGPU_OK;
+        if (c->pend.valid && c->pipe_launched > 0) {
+            // the batch launched last still owes its AGC verdict: read it before this one is queued behind it.  When the fallback
+            // runs it rewrites that batch's output: its "kernels done" event moves behind the fallback, so that the D2H copy waits
+            bool ran = false;
+            rc = agc_resolve_pending(c, &ran); if (rc) return rc;
+            if (ran) HIP_TRY(hipEventRecord(c->pipe[(c->pipe_launched - 1) % iqgpu_chain::kPipeSlots].k_done, c->stream));
+        }
         if (ps.frames_in) {
             HIP_TRY(hipEventSynchronize(ps.in_done));
             size_t produced = 0;
             c->iq_pinned = true; c->iq_pin_mag = ps.iq_mag; c->iq_pin_phase = ps.iq_phase;
+            // (the host orders every stage of a batch: the AGC verdict of a fused launch is read on the host -- by the next batch's
+            //  launch or by this batch's D2H copy, whichever comes first -- and the fallback kernels are launched only when it is set)
+            c->defer_fallback = true;
             rc = process_device_impl(c, ps.d_in.p, ps.frames_in, ps.d_out.p, ps.d_out.cap, &produced);
+            c->defer_fallback = false;
             c->iq_pinned = false;
             if (!rc && produced != ps.n_emit) rc = fail(IQGPU_EHIP, "internal: batch produced %zu frames, planned %zu", produced,
                 ps.n_emit);
@@ -69,6 +80,13 @@ int pipe_drain(iqgpu_chain *c, uint64_t upto)
         HIP_TRY(hipSetDevice(c->device));
         if (ps.n_emit) {
             HIP_TRY(hipEventSynchronize(ps.k_done));
+            if (c->pend.valid && c->pipe_copied + 1 == c->pipe_launched) {
+                // the last batch launched is this one and its verdict is still out (no later launch has asked for it): read it now;
+                // a fallback rewrites the batch's output, so the copy waits for it
+                bool ran = false;
+                const int vrc = agc_resolve_pending(c, &ran); if (vrc) return vrc;
+                if (ran) HIP_TRY(hipStreamSynchronize(c->stream));
+            }
             HIP_TRY(hipMemcpyAsync(ps.out, ps.d_out.p, ps.n_emit * bytes_per_frame(c->desc.out_format), hipMemcpyDeviceToHost, d2h));
         }
         ++c->pipe_copied;

@@ -215,7 +215,7 @@ int Call::stage_front()
         }
         const int mid_nl = mid ? front_mid_nl(a) : 0;
         a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (mid_nl == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
-        if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s>", mid_nl, c->nco_mode ? "nco" : "nonco");
+        if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "");
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : launch_front_s1(a, c->stream)); }
         if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
@@ -296,6 +296,7 @@ extern "C" int iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, 
 {
     if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
     int rc = pipe_advance(c, c->pipe_seq); if (rc) return rc;     // batches submitted earlier come first (same stream)
+    rc = agc_resolve_pending(c); if (rc) return rc;               // ... with whatever their last fused launch still owes
     return process_device_impl(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out);
 }
 static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
@@ -343,6 +344,8 @@ static int process_one(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
     if (c->poisoned) return fail(IQGPU_EHIP,
         "an earlier call failed half way through: the stream state is undefined until iqgpu_chain_reset()");
     HIP_TRY(hipSetDevice(c->device));
+    // a fused launch of an earlier call may still owe its fallback: before anything of this call is queued behind it
+    { const int prc = agc_resolve_pending(c); if (prc) return prc; }
 
     Call k{};
     k.c = c; k.d_raw_in = d_raw_in; k.frames_in = frames_in; k.d_out = d_out;
@@ -423,8 +426,12 @@ extern "C" int iqgpu_chain_process(iqgpu_chain *c, const void *raw_in, size_t fr
     rc = c->stage_out.ensure(n_emit * obps + 16); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->stage_in.p, raw_in, frames_in * ibps, hipMemcpyHostToDevice, c->stream));
     size_t produced = 0;
+    // the host waits for this call's bytes anyway: the AGC verdict is read here and the fallback launched only when it is set
+    c->defer_fallback = true;
     rc = process_device_impl(c, c->stage_in.p, frames_in, c->stage_out.p, c->stage_out.cap, &produced);
+    c->defer_fallback = false;
     if (rc) return rc;
+    rc = agc_resolve_pending(c); if (rc) return rc;
     if (produced) HIP_TRY(hipMemcpyAsync(out, c->stage_out.p, produced * obps, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *frames_out = produced;

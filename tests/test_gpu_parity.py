@@ -986,7 +986,9 @@ def test_more_fixed_runs_than_resident_waves(gpu, monkeypatch, block_samples):
 def test_eight_per_lane_experiment_under_fixed_runs(gpu, monkeypatch):
     """IQGPU_MID8=1 with block_samples = 262144: only the six-per-lane instantiation can deal fixed-length runs out
     inside a workgroup; the 8-per-lane one must keep one static run per wave over as many rounds of workgroups as the runs need --
-    every streaming run processed, no part of the output left unwritten.  Bytes of the default geometry."""
+    every streaming run processed, no part of the output left unwritten.  Bytes of the default geometry.  (As the plan stands the
+    8-per-lane instantiation is never launched at all: its 1024-frame tiles leave more than front_mid_max_edge_waves() edge runs at
+    either end of a call and the plan falls back to k_front_s1 -- whichever kernel the switch ends up on must give the same bytes.)"""
     n = (1 << 25) + 4321
     raw = np.tile(synth.raw_stream(1 << 22, 2.4e6, 79, "cs16"), 9)[:2 * n]
     ref_ch = gpu.Chain(**NRSC5)
@@ -996,7 +998,7 @@ def test_eight_per_lane_experiment_under_fixed_runs(gpu, monkeypatch):
     for bs in (0, 262144):
         ch = gpu.Chain(**dict(NRSC5, block_samples=bs))
         got = ch.process(raw)
-        assert ch.front_kernel() == "k_front_mid<8,nco>", ch.front_kernel()
+        assert ch.front_kernel() in ("k_front_mid<8,nco>", "k_front_s1"), ch.front_kernel()
         assert got.size == ref.size
         assert np.array_equal(got, ref), (bs, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
 
@@ -1440,9 +1442,9 @@ def test_block_samples_does_not_change_results(gpu, name, kw):
 # round 2: pipelined host entry point (iqgpu_chain_submit / _collect), iq factors changed mid-stream,
 # the one-round run plan of the wave-autonomous kernels
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("batch", [16384, 262144, 100003])
+@pytest.mark.parametrize("batch", [16384, 262144, 100003, 1048576])      # 1048576 = the stub's 64-chunk batch
 def test_submit_collect_equals_process(gpu, oracle, batch):
-    raw = synth.raw_stream(1 << 21, 2.4e6, 1, "cs16")
+    raw = synth.raw_stream((1 << 21) if batch < 1048576 else 11 * 1048576 + 12345, 2.4e6, 1, "cs16")
     kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
     want = gpu.Chain(**kw).process(raw)
     got = gpu.Chain(**kw).process_pipelined(raw, batch)
@@ -1763,6 +1765,51 @@ def test_agc_fused_path_equals_unfused_and_oracle(gpu, oracle, monkeypatch, case
         want = run_oracle(oracle, raw, **okw) if case != "odd_chunk" else None
         if want is not None:
             int_close(fused, want, min_same=0.995)
+
+
+@pytest.mark.parametrize("batch", [16 * 16384, 64 * 16384, 5 * 16384 + 321])
+def test_agc_verdict_on_the_host_equals_the_queued_fallback(gpu, monkeypatch, batch):
+    """Round 5: on submit / collect (and iqgpu_chain_process) the verifier's verdict is read by the HOST from a pinned word and the
+    fallback kernels are launched only when it is set; iqgpu_chain_process_device keeps them queued behind every fused launch.
+    A stream whose envelope makes verdicts FAIL after the lock -- a ratchet burst, then a fade past the hang time, gain creeping
+    chunk by chunk -- through all three, in batches small enough that a rejected batch has successors already copied in and its
+    own D2H copy pending: identical bytes, identical AGC state, and the unfused kernels' too."""
+    from iq_tool_amd.chain import DeviceBuffer
+    n = int(2.4e6 * 9)
+    raw = _enveloped_stream(n, 47, [(0.0, 0.4), (3.0, 0.64), (3.3, 0.4), (4.0, 0.12)])
+    kw = dict(NRSC5, agc=True)
+
+    ch = gpu.Chain(**kw)
+    piped = ch.process_pipelined(raw, batch)
+    st_piped = ch.agc_state()
+
+    ch = gpu.Chain(**kw)
+    sync = np.concatenate([ch.process(raw[2 * p:2 * min(n, p + batch)]) for p in range(0, n, batch)])
+    st_sync = ch.agc_state()
+
+    ch = gpu.Chain(**kw)
+    d_in, d_out = DeviceBuffer(4 * batch), DeviceBuffer(4 * ch.max_out_frames(batch))
+    outs = []
+    for p in range(0, n, batch):
+        k = min(n, p + batch) - p
+        d_in.upload(raw[2 * p:2 * (p + k)])
+        got = ch.process_device(d_in.ptr, k, d_out.ptr, d_out.nbytes)
+        ch.synchronize()
+        outs.append(d_out.download(4 * got, np.int16).copy())
+    dev = np.concatenate(outs)
+    st_dev = ch.agc_state()
+
+    monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+    ch = gpu.Chain(**kw)
+    plain = np.concatenate([ch.process(raw[2 * p:2 * min(n, p + batch)]) for p in range(0, n, batch)])
+    st_plain = ch.agc_state()
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE")
+
+    assert st_plain["locked"] and st_plain["gain"] != 1.0
+    for name, got, st in (("submit/collect", piped, st_piped), ("process", sync, st_sync), ("process_device", dev, st_dev)):
+        assert got.size == plain.size, name
+        assert np.array_equal(got, plain), (name, int((got != plain).sum()), int(np.flatnonzero(got != plain)[0]))
+        assert st == st_plain, (name, st, st_plain)
 
 
 def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):
