@@ -276,7 +276,7 @@ def step_flops(info, frames, n_res, n_emit, desc_kw, ntaps, taps_complex):
     direct = n_emit * ntaps * (8 if taps_complex else 4)
     executed = direct
     if ntaps >= 96:
-        lg = 8
+        lg = 10
         while (1 << lg) < 4 * (ntaps - 1) and (1 << lg) < 4096:
             lg += 1
         while (1 << lg) < 2 * (ntaps - 1):

@@ -377,7 +377,9 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             // N = 4 (L-1) rounded up to a power of two in [256, 4096], larger (up to 16384, in place in LDS) only
             // when the taps need it; measured with k_fftconv16 (round 4: first and last pass in registers) on config 3 (1025 taps):
             // N 2048 0.25 ms, 4096 0.15, 8192 0.16, 16384 0.21; on config 4 (4097 taps): N 8192 0.105 ms, 16384 0.114
-            int lg = 8;
+            // (from 1024 points up: the radix-16 kernel.  Round 5: the 97-tap band-pass of the cs16 -usb / -lsb presets ran the
+            //  radix-4 ping-pong kernel at N = 512 and took 1.49 ms for 83 M outputs; at N = 1024 it takes a fifth of that)
+            int lg = (c->dbg & kDbgFftNoR16) ? 8 : 10;
             while ((size_t)(1 << lg) < 4 * (Lt - 1) && (1 << lg) < 4096) ++lg;
             while ((size_t)(1 << lg) < 2 * (Lt - 1)) ++lg;
             if (const char *e = getenv("IQGPU_FFT_LOG2N")) { const int v = atoi(e); if (v >= 1 && (1 << v) <= kMaxFftN && (size_t)(1
@@ -404,6 +406,14 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             }
             CREATE_RC(upload(&c->d_twiddle, tw.data(), tw.size()));
             CREATE_RC(upload(&c->d_hfreq, hf.data(), hf.size()));
+        }
+        // the digital AGC behind a post-resample filter on the overlap-save path: gain and per-chunk peaks in k_fftconv16's epilogue past
+        // the lock.  A block of the filter must not hold more than one chunk boundary: a chunk's outputs (less the block quantisation's
+        // slack) have to outnumber a workgroup's
+        if (c->agc && c->agc_rms_alpha == 0.0f && c->decim && !c->late && !c->force_generic && c->fp.enabled && c->fp.post_resample && c->d_hfreq &&
+            fftconv_agc_fusable(c->fft_log2n, (int)c->fp.taps.size(), c->dbg)) {
+            const double chunk_out = (double)c->agc_chunk * (double)c->ratio - (double)c->fp.block - 2.0;
+            c->agc_fusable_filter = chunk_out >= (double)(1 << c->fft_log2n);
         }
         CREATE_TRY(hipMalloc((void **)&c->d_dc_state, sizeof(cd2)));
         CREATE_TRY(hipMemset(c->d_dc_state, 0, sizeof(cd2)));

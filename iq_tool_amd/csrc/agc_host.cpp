@@ -99,10 +99,41 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
     ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
     if (defer) {
-        c->pend.valid = true; c->pend.fb = fb; c->pend.ga = ga;
+        c->pend.valid = true; c->pend.filter = false; c->pend.fb = fb; c->pend.ga = ga;
         return IQGPU_OK;
     }
     HIP_TRY(launch_agc_fallback(c, fb, ga));
+    return IQGPU_OK;
+}
+
+// ... the same behind a filter launch whose epilogue applied the gain: the fallback is that launch again with cf32 output into the
+// AGC's buffer (no history move: the fused launch made it) and the unfused AGC kernels
+int Call::stage_agc_verify_and_fallback_filter(const FftConvArgs &spec)
+{
+    const bool defer = c->defer_fallback && c->h_agc_verdict != nullptr;
+    AgcArgs va = agc_args();
+    va.verify_flag = c->d_agc_flag;
+    va.peak_approx = 1;                                  // float peaks, as k_front_mid's
+    va.peak2_fallback = (unsigned long long *)c->agc_peak_b.p;
+    va.verdict_host = defer ? c->d_agc_verdict : nullptr;
+    KernelTimer kt(c, IQGPU_K_AGC);
+    if (defer) c->h_agc_verdict[0] = -1;
+    HIP_TRY(launch_agc_verify(va, c->stream));
+    FftConvArgs fc = spec;
+    fc.agc_fused = 0; fc.agc_state = nullptr; fc.agc_peak2 = nullptr;
+    fc.out_fmt = IQGPU_FMT_CF32; fc.out = c->abuf.p;
+    fc.move_dst = nullptr; fc.move_src = nullptr; fc.move_n = 0;
+    fc.run_if = c->d_agc_flag;
+    AgcArgs ga = va;
+    ga.peak2_fallback = nullptr; ga.verdict_host = nullptr;
+    ga.peak2 = (unsigned long long *)c->agc_peak_b.p;
+    ga.run_if = c->d_agc_flag; ga.verify_flag = nullptr;
+    if (defer) {
+        c->pend.valid = true; c->pend.filter = true; c->pend.fc = fc; c->pend.ga = ga;
+        return IQGPU_OK;
+    }
+    HIP_TRY(launch_fftconv(fc, c->stream));
+    HIP_TRY(launch_agc(ga, c->stream));
     return IQGPU_OK;
 }
 
@@ -136,7 +167,9 @@ int agc_resolve_pending(iqgpu_chain *c, bool *ran)
     c->pend.valid = false;
     if (v == 0) return IQGPU_OK;
     KernelTimer kt(c, IQGPU_K_AGC);
-    const hipError_t e = launch_agc_fallback(c, c->pend.fb, c->pend.ga);
+    hipError_t e;
+    if (c->pend.filter) { e = launch_fftconv(c->pend.fc, c->stream); if (e == hipSuccess) e = launch_agc(c->pend.ga, c->stream); }
+    else e = launch_agc_fallback(c, c->pend.fb, c->pend.ga);
     if (e != hipSuccess) { c->poisoned = true; return fail(IQGPU_EHIP, "AGC fallback launch failed: %s", hipGetErrorString(e)); }
     if (ran) *ran = true;
     return IQGPU_OK;
@@ -154,6 +187,7 @@ size_t agc_unfused_head(const iqgpu_chain *c, size_t frames_in, bool *locks)
     g.frames_in = (int64_t)frames_in; g.chunk_frames = c->agc_chunk;
     g.n_chunks = (int)(((int64_t)frames_in + c->agc_chunk - 1) / c->agc_chunk);
     g.mode = 1; g.rem = c->rem; g.S = c->S; g.phi = c->phi; g.step = c->rp.step;
+    if (c->fp.enabled && c->fp.block) { g.block = c->fp.block; g.fpending = c->fpending; }     // (a filter behind the resampler emits whole blocks)
     int64_t lo = 0, hi = g.n_chunks;                        // first chunk whose start time exceeds the lock time
     while (lo < hi) {
         const int64_t mid = (lo + hi) / 2;

@@ -156,7 +156,10 @@ struct iqgpu_chain {
     // h_agc_verdict[0]: -1 = a verdict is awaited, 0 / 1 = k_agc_classify's answer
     volatile int32_t *h_agc_verdict = nullptr; int32_t *d_agc_verdict = nullptr;   // the same word, host and device address
     bool defer_fallback = false;                // set around process_device_impl by the host-ordered entry points
-    struct PendingVerdict { bool valid = false; bool mid = false; FrontArgs fb; AgcArgs ga; } pend;
+    struct PendingVerdict { bool valid = false; bool filter = false; FrontArgs fb; FftConvArgs fc; AgcArgs ga; } pend;
+    // ... and the AGC fused into the user filter's epilogue (k_fftconv16) where a filter stands between the resampler and the AGC:
+    // the shipped -usb / -lsb presets
+    bool agc_fusable_filter = false;
     DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
     InterpArgs ia{};              // geometry of the r >= 1 path
     int ihist = 0;
@@ -262,7 +265,8 @@ struct Call {
     int64_t s2_in_tiles = 0;                 //   ... and this the number of 512-frame input tiles of the call
     int wtile, casc_K, rem_k;
     float iq_mag = 0.0f, iq_phase = 0.0f;    // the correction factors this call applies (snapshot under aux_mu)
-    bool agc_fused = false;                  // this call: gain applied in the front kernel, verified behind it
+    bool agc_fused = false;                  // this call: gain applied in the front kernel -- or, with a filter behind it, in the filter's epilogue -- and verified behind it
+    bool front_fused() const { return agc_fused && !filt; }
     FrontArgs cplan;                         // run geometry of the wave-autonomous kernel that sees the raw input
     cf2 *fcur = nullptr, *icur = nullptr;    // filter-input / k_interp-input buffers of this call
 
@@ -308,6 +312,7 @@ struct Call {
     int stage_late_resampler();
     int stage_agc();
     int stage_agc_verify_and_fallback(const FrontArgs &spec);
+    int stage_agc_verify_and_fallback_filter(const FftConvArgs &spec);
     AgcArgs agc_args() const;
 };
 

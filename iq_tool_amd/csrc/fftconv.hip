@@ -319,6 +319,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int N = 1 << LOG2N, T = N / 16;                        // blockDim.x = T
+    if (a.run_if && *a.run_if == 0) return;                          // (the cf32 fallback behind a fused launch whose verdict stood)
     const int tid = threadIdx.x;
     const int L1 = a.ntaps - 1, V = N - L1;
     constexpr int NP = N + (N >> 5) + 2;
@@ -361,6 +362,16 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
     fft16_lds<LOG2N, true>(X, a.twiddle, tid, io);
     const int64_t left = a.n_emit - o0;
     const int nv = left < (int64_t)V ? (int)left : V;
+    // fused AGC of the locked phase: the chunk of the block's first output and where the next one starts, in closed form from the
+    // block index alone (wave-uniform: the scalar unit's work); at most two chunks meet in a block (launch_fftconv's condition)
+    float agc_g = 1.0f, m0 = 0.0f, m1 = 0.0f;
+    int64_t agc_c0 = 0, agc_c1 = 0, agc_b1 = 0;
+    if (a.agc_fused) {
+        agc_g = a.agc_state->gain;
+        agc_c0 = agc_chunk_of_output(a.agc_geom, o0);
+        agc_b1 = agc_out_end(a.agc_geom, agc_c0);
+        agc_c1 = agc_b1 < o0 + nv ? agc_chunk_of_output(a.agc_geom, agc_b1) : agc_c0 + 1;      // (chunks without an output lie between)
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = tid + r * T - L1;                              // output i of the block is point L1 + i of the result
@@ -370,8 +381,27 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
         const int64_t k = o0 + i;
         if (a.pnco_mode != 0)
             y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
+        if (a.agc_fused) {
+            // agc_apply: the chunk's peak over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
+            const float m2 = fmaf(y.x, y.x, y.y * y.y);
+            if (k < agc_b1) m0 = fmaxf(m0, m2); else m1 = fmaxf(m1, m2);
+            y = cf2{y.x * agc_g, y.y * agc_g};
+        }
         pack_store(a.out, k, a.out_fmt, y);
     }
+    if (a.agc_fused) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+        if ((tid & 63) == 0) {
+            if (m0 > 0.0f) atomicMax(a.agc_peak2 + agc_c0, (unsigned long long)__double_as_longlong((double)m0));
+            if (m1 > 0.0f) atomicMax(a.agc_peak2 + agc_c1, (unsigned long long)__double_as_longlong((double)m1));
+        }
+    }
+}
+
+bool fftconv_agc_fusable(int log2n, int ntaps, uint32_t dbg)
+{
+    return log2n >= 10 && (1 << log2n) <= kMaxFftN && (1 << log2n) > ntaps - 1 && !(dbg & (kDbgFftNoR16 | kDbgAgcNoFuse));
 }
 
 template <int LOG2N>
@@ -385,6 +415,7 @@ static hipError_t launch_fftconv16(const FftConvArgs &a, unsigned nb, size_t lds
 
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s)
 {
+    if ((a.agc_fused || a.run_if) && !(a.log2n >= 10 && !(a.dbg & kDbgFftNoR16))) return hipErrorInvalidValue;   // (the radix-16 kernel only)
     if (a.n_emit > 0 && a.log2n >= 10 && !(a.dbg & kDbgFftNoR16)) {
         const int N = 1 << a.log2n, V = N - (a.ntaps - 1);
         if (V <= 0 || N > kMaxFftN) return hipErrorInvalidValue;

@@ -326,6 +326,62 @@ struct FirArgs {
 hipError_t launch_fir(const FirArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
+// the chunk map of the output AGC (agc.hip; the fused epilogue of k_fftconv16 needs it too)
+// ---------------------------------------------------------------------------------------------
+// How one process() call maps its input chunks (chunk_frames input frames each, counted from the
+// start of the call) to ranges of its output: closed form, so kernels and host agree without a table.
+struct AgcGeom {
+    int64_t  frames_in;
+    int64_t  chunk_frames;
+    int32_t  n_chunks;
+    int32_t  mode;         // 0 = one output per input, 1 = decimating front kernel, 2 = k_interp path
+    int32_t  rem;          // mode 1: samples of the open 2^S group before the call
+    int32_t  S;            // mode 1: group shift; mode 2: interpolator stages
+    uint64_t phi;          // resampler phase at the start of the call
+    uint32_t step;
+    uint32_t block;        // fftfilt block size (0 = none)
+    uint64_t fpending;     // samples waiting in front of the block filter
+};
+// outputs of the call produced by its chunks 0 .. c (c = -1 -> 0)
+IQGPU_HD inline int64_t agc_out_end(const AgcGeom &g, int64_t c)
+{
+    if (c < 0) return 0;
+    int64_t f = (c + 1) * g.chunk_frames;
+    if (f > g.frames_in) f = g.frames_in;
+    uint64_t n = (uint64_t)f;
+    if (g.mode == 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // pre filter, then resampler
+    if (g.mode != 0) {
+        const uint64_t span = (g.mode == 1 ? (((uint64_t)g.rem + n) >> g.S) : n) << 24;
+        n = span > g.phi ? (span - g.phi + g.step - 1) / g.step : 0;
+        if (g.mode == 2) n <<= g.S;
+    }
+    if (g.mode != 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // filter behind the resampler
+    return (int64_t)n;
+}
+
+// the chunk of the call that output k (< the call's n_emit) belongs to: the smallest c with agc_out_end(g, c) > k, in closed form
+// (the inverse of the chain above, one division by the chunk length) -- modes 0 and 1, what the fused AGC behind a user filter needs
+IQGPU_HD inline int64_t agc_chunk_of_output(const AgcGeom &g, int64_t k)
+{
+    // outputs of the resampler (or input frames, mode 0) that must exist before output k does
+    uint64_t n_min = (uint64_t)k + 1;
+    if (g.block) {
+        const uint64_t need = ((uint64_t)k / g.block + 1) * g.block;        // emitted count that covers k: a whole number of blocks
+        n_min = need > g.fpending ? need - g.fpending : 0;
+    }
+    uint64_t f_min = n_min;                                                   // input frames of the call that must have arrived
+    if (g.mode == 1) {
+        if (n_min == 0) return 0;
+        const uint64_t x = (n_min - 1) * (uint64_t)g.step + g.phi;           // complete groups G with G 2^24 > x
+        const uint64_t g_min = (x >> 24) + 1;
+        const uint64_t have = g_min << g.S;
+        f_min = have > (uint64_t)g.rem ? have - (uint64_t)g.rem : 0;
+    }
+    if (f_min == 0) return 0;
+    return (int64_t)((f_min + (uint64_t)g.chunk_frames - 1) / (uint64_t)g.chunk_frames) - 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fftconv: FFT-kind user filter as overlap-save block convolution in LDS (fftconv.hip)
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxFftN = 16384;    // k_fftconv16 transforms in place: N cf32 = 128 KiB (+ pad) of LDS
@@ -349,8 +405,19 @@ struct FftConvArgs {
     cf2       *move_dst;      // as FirArgs: the next call's buffer front, copied by the last workgroup
     const cf2 *move_src;
     int64_t    move_n;
+    // fused output AGC of the locked phase (round 5; k_fftconv16 only): the shipped -usb / -lsb presets run filter -> digital AGC ->
+    // pack.  As in the front kernels the epilogue multiplies by the gain it finds in *agc_state before the pack and leaves max |y|^2
+    // per chunk (float, as k_front_mid: peak_approx) in agc_peak2; k_agc_classify confirms every chunk afterwards or raises the flag
+    // behind which the same launch with cf32 output (run_if) and the unfused AGC kernels redo the call.  A workgroup's outputs lie in
+    // at most two chunks (the host fuses only when a chunk's outputs outnumber a workgroup's).
+    int32_t    agc_fused;
+    const AgcState *agc_state;
+    unsigned long long *agc_peak2;
+    AgcGeom    agc_geom;
+    const int32_t *run_if;    // not NULL: the launch does nothing unless *run_if != 0 (the fallback behind a fused launch)
 };
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s);
+bool fftconv_agc_fusable(int log2n, int ntaps, uint32_t dbg);   // which filters have the epilogue (the radix-16 kernel)
 
 // ---------------------------------------------------------------------------------------------
 // k_interp: msresamp for r >= 1 -- arbitrary polyphase, then S half-band interpolators,
@@ -392,37 +459,6 @@ hipError_t launch_interp(const InterpArgs &a, int n_cu, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // Output AGC, "digital" profile (agc.hip): per-chunk peak -> gain scan over chunks -> scale + pack
 // ---------------------------------------------------------------------------------------------
-// How one process() call maps its input chunks (chunk_frames input frames each, counted from the
-// start of the call) to ranges of its output: closed form, so kernels and host agree without a table.
-struct AgcGeom {
-    int64_t  frames_in;
-    int64_t  chunk_frames;
-    int32_t  n_chunks;
-    int32_t  mode;         // 0 = one output per input, 1 = decimating front kernel, 2 = k_interp path
-    int32_t  rem;          // mode 1: samples of the open 2^S group before the call
-    int32_t  S;            // mode 1: group shift; mode 2: interpolator stages
-    uint64_t phi;          // resampler phase at the start of the call
-    uint32_t step;
-    uint32_t block;        // fftfilt block size (0 = none)
-    uint64_t fpending;     // samples waiting in front of the block filter
-};
-// outputs of the call produced by its chunks 0 .. c (c = -1 -> 0)
-IQGPU_HD inline int64_t agc_out_end(const AgcGeom &g, int64_t c)
-{
-    if (c < 0) return 0;
-    int64_t f = (c + 1) * g.chunk_frames;
-    if (f > g.frames_in) f = g.frames_in;
-    uint64_t n = (uint64_t)f;
-    if (g.mode == 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // pre filter, then resampler
-    if (g.mode != 0) {
-        const uint64_t span = (g.mode == 1 ? (((uint64_t)g.rem + n) >> g.S) : n) << 24;
-        n = span > g.phi ? (span - g.phi + g.step - 1) / g.step : 0;
-        if (g.mode == 2) n <<= g.S;
-    }
-    if (g.mode != 2 && g.block) n = ((g.fpending + n) / g.block) * g.block;      // filter behind the resampler
-    return (int64_t)n;
-}
-
 struct AgcState {          // == iqgpu_agc_state
     int32_t  locked;
     float    peak_memory;

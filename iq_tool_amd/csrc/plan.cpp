@@ -124,7 +124,7 @@ void Call::plan_geometry()
             for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
             cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);
         }
-        cplan.agc_fused = agc_fused ? 1 : 0; cplan.agc_shift = c->S; cplan.agc_chunk_frames = c->agc_chunk;
+        cplan.agc_fused = front_fused() ? 1 : 0; cplan.agc_shift = c->S; cplan.agc_chunk_frames = c->agc_chunk;
         cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
         cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
         cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;
@@ -173,7 +173,7 @@ void Call::plan_geometry()
         // to leave behind, keep the two kernels (same bytes either way).
         s2 = false;
         const int64_t n_mid = (int64_t)frames_in >> 1;
-        if (casc && casc_K == 1 && c->rem == 0 && cplan.raw_aligned && !agc_fused && !(c->dbg & kDbgNoS2) && front_s2_shape(cplan) &&
+        if (casc && casc_K == 1 && c->rem == 0 && cplan.raw_aligned && !front_fused() && !(c->dbg & kDbgNoS2) && front_s2_shape(cplan) &&
             (int64_t)frames_in >= (int64_t)c->hist_cap && n_mid >= (int64_t)c->hist2_cap) {
             FrontArgs p2{};
             p2.frames_in = n_mid; p2.rem0 = 0; p2.hist_cap = c->hist2_cap; p2.in_fmt = IQGPU_FMT_CF32; p2.out_fmt = filt ? (int)IQGPU_FMT_CF32 : fin_fmt;

@@ -176,25 +176,25 @@ int Call::stage_front()
             a2.pnco_mode = a.pnco_mode; a2.pnco_theta0 = a.pnco_theta0; a2.pnco_dtheta = a.pnco_dtheta;
             a2.out_fmt = a.out_fmt; a2.out = a.out;
             a2.w_total_tiles = ((int64_t)rem_1 + n_mid + kWTile - 1) / kWTile;
-            a2.agc_fused = agc_fused ? 1 : 0;
+            a2.agc_fused = front_fused() ? 1 : 0;
             if (s2) copy_plan(a2);
             else plan_front_s1(a2, wave_slots(front_s1_waves(a2)), fixed_tpw(), 1, 1);
             for (int q = 0; q < 20; ++q) a2.hb0[q] = 0.5f * c->rp.stages[(size_t)K].branch[(size_t)q];
             a2.sink = c->d_sink;
-            if (agc_fused) {
+            if (front_fused()) {
                 a2.agc_fused = 1; a2.agc_state = c->d_agc_state; a2.agc_peak2 = (unsigned long long *)c->agc_peak.p;
                 a2.agc_chunk_frames = c->agc_chunk; a2.agc_shift = c->S; a2.agc_rem = c->rem;
                 HIP_TRY(clean_agc_peaks());
             }
             { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(s2 ? launch_front_s2(a1, a2, c->stream) : launch_front_s1(a2, c->stream)); }
-            if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a2); if (rc) return rc; }
+            if (front_fused()) { const int rc = stage_agc_verify_and_fallback(a2); if (rc) return rc; }
             c->hist2_cur ^= 1;
         }
     } else if (fast_s1) {
         // wave-autonomous kernel: one half-band stage (m = 10), or none
         copy_plan(a);
         if (!fast_s0) for (int q = 0; q < 20; ++q) a.hb0[q] = 0.5f * c->rp.stages[0].branch[(size_t)q];
-        if (agc_fused) {
+        if (front_fused()) {
             a.agc_fused = 1; a.agc_state = c->d_agc_state; a.agc_peak2 = (unsigned long long *)c->agc_peak.p;
             a.agc_chunk_frames = c->agc_chunk; a.agc_shift = c->S; a.agc_rem = c->rem;
             HIP_TRY(clean_agc_peaks());
@@ -218,7 +218,7 @@ int Call::stage_front()
         if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "");
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : launch_front_s1(a, c->stream)); }
-        if (agc_fused) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
+        if (front_fused()) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
     } else {
         KernelTimer kt(c, IQGPU_K_FRONT);
         HIP_TRY(launch_front(a, n_blocks, c->stream));
@@ -253,8 +253,12 @@ int Call::stage_filter()
         ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
         ca.out_fmt = fa.out_fmt; ca.out = fa.out;
         ca.move_dst = fa.move_dst; ca.move_src = fa.move_src; ca.move_n = fa.move_n;
-        KernelTimer kt(c, IQGPU_K_FILTER);
-        HIP_TRY(launch_fftconv(ca, c->stream));
+        if (agc_fused) {       // (past the lock, the filter between the resampler and the AGC: gain and per-chunk peaks in its epilogue)
+            ca.agc_fused = 1; ca.agc_state = c->d_agc_state; ca.agc_peak2 = (unsigned long long *)c->agc_peak.p; ca.agc_geom = agc_geom();
+            HIP_TRY(clean_agc_peaks());
+        }
+        { KernelTimer kt(c, IQGPU_K_FILTER); HIP_TRY(launch_fftconv(ca, c->stream)); }
+        if (agc_fused) { const int rc = stage_agc_verify_and_fallback_filter(ca); if (rc) return rc; }
     } else {
         KernelTimer kt(c, IQGPU_K_FILTER);
         HIP_TRY(launch_fir(fa, c->stream));
@@ -306,12 +310,16 @@ int process_device_impl(iqgpu_chain *c, const void *d_raw_in, size_t frames_in,
                                void *d_out, size_t out_capacity_bytes, size_t *frames_out)
 {
     if (!c || !frames_out) return fail(IQGPU_EINVAL, "iqgpu_chain_process_device: NULL argument");
-    if (!c->agc_fusable || frames_in == 0) return process_one(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out, false);
+    if (!(c->agc_fusable || c->agc_fusable_filter) || frames_in == 0) return process_one(c, d_raw_in, frames_in, d_out, out_capacity_bytes, frames_out, false);
     // output AGC on the specialised front kernel: the scanning phase (and the chunk that locks) through the unfused
     // kernels, everything behind it fused
     *frames_out = 0;
     bool locks = false;
-    const size_t head = agc_unfused_head(c, frames_in, &locks);
+    size_t head = agc_unfused_head(c, frames_in, &locks);
+    // with a user filter between the resampler and the AGC the call that holds the lock stays whole: cutting it at the locking chunk
+    // would move the filter's overlap-save windows on the stream (other roundings: the bytes of the unfused path would be missed by a
+    // code here and there); the fused epilogue starts with the next call
+    if (c->agc_fusable_filter && head > 0 && head < frames_in) head = frames_in;
     const size_t ibps = bytes_per_frame(c->desc.in_format), obps = bytes_per_frame(c->desc.out_format);
     if ((size_t)plan_call(c, frames_in).n_emit * obps > out_capacity_bytes)
         return fail(IQGPU_ECAPACITY, "output buffer too small: need %zu bytes, have %zu", (size_t)plan_call(c, frames_in).n_emit * obps,

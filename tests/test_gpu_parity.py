@@ -849,6 +849,46 @@ def test_fat_kernel_equals_the_sixteen_wave_kernel(gpu, oracle, monkeypatch, tar
     int_close(ref, run_oracle(oracle, raw, **kw))
 
 
+@pytest.mark.parametrize("shift_hz,pass_range,agc", [(0.0, (102e3, 215e3), True), (0.0, (-215e3, -102e3), False), (200e3, (-60e3, 40e3), False)])
+def test_mid_kernel_in_front_of_a_user_filter(gpu, oracle, monkeypatch, shift_hz, pass_range, agc):
+    """Round 5: the shipped cs16-fm-nrsc5-usb / -lsb presets put a complex band-pass BEHIND the resampler, so the front kernel leaves
+    cf32 in the filter's input buffer: k_front_mid<.., cf32> (its edge waves on the cf32 path of run_tiles) instead of the fall
+    back to k_front_s1.  Same products in the same order: the bytes behind the filter (and the digital AGC of the preset) must be
+    those of the k_front_s1 build of the same chain -- whole calls, ragged splits across the size rule -- and close to the oracle."""
+    a, b = pass_range
+    n = 2_800_001
+    raw = synth.raw_stream(n, 2.4e6, 33, "cs16")
+    kw = dict(NRSC5, shift_hz=shift_hz, filters=(("passband", (a + b) / 2.0, b - a),), agc=agc)
+    # (with the preset's digital AGC only whole reader chunks per call keep the reference's chunk partition, and the scanning phase of
+    #  a 2.8 M-frame stream never ends: one call)
+    splits = [[n]] if agc else [[n], [1_300_000, 16384 * 3, n - 1_300_000 - 16384 * 3]]
+    monkeypatch.setenv("IQGPU_NO_FAT", "1")
+    ch = gpu.Chain(**kw)
+    ref = ch.process(raw)
+    assert ch.front_kernel() == "k_front_s1"
+    monkeypatch.delenv("IQGPU_NO_FAT")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # calls of any length on k_front_mid
+    for sp in splits:
+        ch = gpu.Chain(**kw)
+        outs, pos = [], 0
+        for k in sp:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+            assert ch.front_kernel() == "k_front_mid<6,%s,cf32>" % ("nco" if shift_hz else "nonco"), ch.front_kernel()
+        got = np.concatenate(outs)
+        if len(sp) == 1:
+            assert got.size == ref.size
+            assert np.array_equal(got, ref), (sp, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+        else:
+            # (the overlap-save windows of the filter fall differently on the stream when the calls do: +-1 code against the one-call run)
+            m = min(got.size, ref.size)
+            assert m > 0.99 * ref.size
+            d = np.abs(got[:m].astype(np.int64) - ref[:m].astype(np.int64))
+            assert d.max() <= 1 and (d == 0).mean() > 0.99
+    monkeypatch.delenv("IQGPU_FORCE_FAT")
+    if not agc:
+        int_close(ref, run_oracle(oracle, raw, **kw), min_same=0.995)
+
+
 @pytest.mark.parametrize("target_hz", [744187.5, 2.4e6 / 3.25, 696000.0])
 @pytest.mark.parametrize("variant", ["fat", "mid"])
 def test_tap_placement_does_not_change_a_bit(gpu, monkeypatch, target_hz, variant):
@@ -1810,6 +1850,61 @@ def test_agc_verdict_on_the_host_equals_the_queued_fallback(gpu, monkeypatch, ba
         assert got.size == plain.size, name
         assert np.array_equal(got, plain), (name, int((got != plain).sum()), int(np.flatnonzero(got != plain)[0]))
         assert st == st_plain, (name, st, st_plain)
+
+
+@pytest.mark.parametrize("fmt,target_hz", [("cs16", 744187.5), ("cu8", 1488375.0)])
+@pytest.mark.parametrize("case", ["steady", "ratchet_and_creep"])
+def test_agc_fused_in_the_filter_epilogue(gpu, oracle, monkeypatch, fmt, target_hz, case):
+    """Round 5: the shipped -usb / -lsb presets run resampler -> complex band-pass -> digital AGC -> pack.  Past the lock the gain is
+    applied and the per-chunk peaks are taken in k_fftconv16's epilogue (float peaks, k_agc_classify's tolerance band, the chunk of a
+    block from agc_chunk_of_output); a rejected call is redone by the same filter launch with cf32 output and the unfused kernels.
+    Bytes and AGC state must equal the unfused path's (IQGPU_AGC_NOFUSE) -- whole-chunk calls through process(), the pipelined
+    entry point (verdict on the host) and process_device (fallback queued) -- and stay close to the oracle."""
+    n = int(2.4e6 * 8)
+    env = [(0.0, 0.5)] if case == "steady" else [(0.0, 0.4), (3.0, 0.66), (3.3, 0.4), (4.2, 0.1)]
+    raw16 = _enveloped_stream(n, 48, env)
+    if fmt == "cu8":
+        raw = ((raw16.astype(np.int32) >> 8) + 128).astype(np.uint8)        # the same envelope as an 8-bit capture
+    else:
+        raw = raw16
+    kw = dict(in_format=fmt, out_format=fmt, input_rate_hz=2.4e6, target_rate_hz=target_hz, agc=True,
+              filters=(("passband", 158.5e3, 113e3),))
+    batch = 40 * 16384
+    per = 2 * batch
+
+    def chunks():
+        return [raw[p:p + per] for p in range(0, raw.size, per)]
+
+    def run_sync():
+        ch = gpu.Chain(**kw)
+        out = np.concatenate([ch.process(x) for x in chunks()])
+        return out, ch.agc_state()
+
+    monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+    plain, st_plain = run_sync()
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE")
+    fused, st_fused = run_sync()
+    assert st_plain["locked"]
+    assert fused.size == plain.size
+    assert np.array_equal(fused, plain), (int((fused != plain).sum()), int(np.flatnonzero(fused != plain)[0]))
+    assert st_fused == st_plain
+    ch = gpu.Chain(**kw)
+    piped = ch.process_pipelined(raw, batch)
+    assert np.array_equal(piped, plain) and ch.agc_state() == st_plain
+    from iq_tool_amd.chain import DeviceBuffer
+    ch = gpu.Chain(**kw)
+    d_in, d_out = DeviceBuffer(per * raw.itemsize), DeviceBuffer(ch.out_bytes * ch.max_out_frames(batch))
+    outs = []
+    for x in chunks():
+        d_in.upload(x)
+        got = ch.process_device(d_in.ptr, x.size // 2, d_out.ptr, d_out.nbytes)
+        ch.synchronize()
+        outs.append(d_out.download(ch.out_bytes * got, plain.dtype).copy())
+    assert np.array_equal(np.concatenate(outs), plain) and ch.agc_state() == st_plain
+    if case == "steady":
+        och = oracle.Chain(**kw)
+        want = np.concatenate([och.process(x) for x in chunks()])
+        int_close(fused, want, min_same=0.99)
 
 
 def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):

@@ -499,3 +499,48 @@ def test_numa_binding_follows_the_device_through_a_stand_in_sysfs(tmp_path):
     # UUID lists are not interpreted: nothing is bound and the caller is told
     r = run(ROCR_VISIBLE_DEVICES="GPU-deadbeef")
     assert r["0"]["node"] == -1 and "not a list of indices" in r["0"]["err"] and r["0"]["cpus"] == allowed
+
+
+def test_agc_chunk_of_output_inverts_the_chunk_map(tmp_path):
+    """kernels.hpp agc_chunk_of_output (the closed form the fused AGC epilogue of k_fftconv16 finds its chunk with) against a scan of
+    agc_out_end over random geometries: resampler phases and steps, open decimation groups, block-quantised filters with samples
+    pending, chunk lengths that are no power of two, calls that end inside a chunk -- every output of every call."""
+    src = tmp_path / "inv.cpp"
+    src.write_text(textwrap.dedent(r"""
+        #include <cstdio>
+        #include <cstdlib>
+        #include "kernels.hpp"
+        using namespace iqgpu;
+        int main() {
+            unsigned long long checked = 0;
+            srand(5);
+            for (int trial = 0; trial < 400; ++trial) {
+                AgcGeom g{};
+                g.mode = trial % 5 == 0 ? 0 : 1;
+                g.S = g.mode ? rand() % 4 : 0;
+                g.rem = g.mode ? rand() % (1 << g.S) : 0;
+                g.step = (uint32_t)((1.0 + (rand() % 1000) / 1000.0 * 0.999) * 16777216.0);
+                g.phi = (uint64_t)(rand() % 1000) * g.step / 1000;
+                g.block = trial % 3 == 0 ? 0u : (64u << (rand() % 4));
+                g.fpending = g.block ? (uint64_t)(rand() % g.block) : 0;
+                g.chunk_frames = 900 + rand() % 20000;
+                g.frames_in = 1 + rand() % 200000;
+                g.n_chunks = (int)((g.frames_in + g.chunk_frames - 1) / g.chunk_frames);
+                const int64_t n_emit = agc_out_end(g, g.n_chunks - 1);
+                int c = 0;
+                for (int64_t k = 0; k < n_emit; ++k) {
+                    while (agc_out_end(g, c) <= k) ++c;                    // the scan: smallest c with out_end(c) > k
+                    const int64_t got = agc_chunk_of_output(g, k);
+                    if (got != c) { printf("trial %d k %lld: %lld != %d\n", trial, (long long)k, (long long)got, c); return 1; }
+                    ++checked;
+                }
+            }
+            printf("ok %llu\n", checked);
+            return 0;
+        }"""))
+    exe = tmp_path / "inv"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "iq_tool_amd", "csrc"),
+                    str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+    assert int(out.stdout.split()[1]) > 1_000_000
