@@ -77,7 +77,7 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     const bool defer = c->defer_fallback && c->h_agc_verdict != nullptr;
     AgcArgs va = agc_args();
     va.verify_flag = c->d_agc_flag;
-    va.peak_approx = mid ? 1 : 0;
+    va.peak_approx = (mid || p0) ? 1 : 0;
     va.peak2_fallback = (unsigned long long *)c->agc_peak_b.p;
     va.verdict_host = defer ? c->d_agc_verdict : nullptr;
     KernelTimer kt(c, IQGPU_K_AGC);
@@ -87,12 +87,14 @@ int Call::stage_agc_verify_and_fallback(const FrontArgs &spec)
     fb.agc_fused = 0; fb.agc_state = nullptr; fb.agc_peak2 = nullptr; fb.w_steal = nullptr; fb.w_run_stride = 0;
     fb.out_fmt = IQGPU_FMT_CF32; fb.out = c->abuf.p;
     fb.run_if = c->d_agc_flag;
-    if (fat || mid) {
-        // the fused launch ran on k_front_fat / k_front_mid with its own tile geometry: the fallback is k_front_s1's (512-frame tiles)
-        fb.w_total_tiles = ((int64_t)fb.rem0 + fb.frames_in + kWTile - 1) / kWTile;
-        int warm = (int)((c->rp.history_in + kWTile - 1) / kWTile);
+    if (fat || mid || p0) {
+        // the fused launch ran on k_front_fat / k_front_mid / k_front_p0 with its own geometry: the fallback is k_front_s1's (512-frame
+        // tiles; 256 without a half-band stage)
+        const int ft = p0 ? 256 : kWTile;
+        fb.w_total_tiles = ((int64_t)fb.rem0 + fb.frames_in + ft - 1) / ft;
+        int warm = (int)((c->rp.history_in + ft - 1) / ft);
         if (warm < 1) warm = 1;
-        plan_front_s1(fb, wave_slots(front_s1_waves(fb)), fixed_tpw(), warm, 1, kWTile);
+        plan_front_s1(fb, wave_slots(front_s1_waves(fb)), fixed_tpw(), warm, 1, ft);
     }
     AgcArgs ga = va;
     ga.peak2_fallback = nullptr; ga.verdict_host = nullptr;

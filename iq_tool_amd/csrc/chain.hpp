@@ -261,6 +261,7 @@ struct Call {
     bool casc, fast_s0, fast_s1;             // which front path runs
     bool fat = false;                        // fast_s1 as k_front_fat (front_fat.hip): 8 waves per CU, 1024-frame tiles
     bool mid = false;                        // ... or as k_front_mid (front_mid.hip): 12 waves per CU, 768-frame tiles
+    bool p0 = false;                         // fast_s0 as k_front_p0 (front_p0.hip): output-major steps, taps kept in registers
     bool s2 = false;                         // casc with both stages fused into k_front_s2 (front_s2.hip); cplan is then the LAST stage's plan
     int64_t s2_in_tiles = 0;                 //   ... and this the number of 512-frame input tiles of the call
     int wtile, casc_K, rem_k;
@@ -290,6 +291,7 @@ struct Call {
         dst.w_n_edge1 = cplan.w_n_edge1; dst.w_n_edge = cplan.w_n_edge;
         dst.w_wpw = cplan.w_wpw; dst.w_wsum = cplan.w_wsum;
         for (int i = 0; i < 4; ++i) dst.w_wt[i] = cplan.w_wt[i];
+        dst.p0_k_a = cplan.p0_k_a; dst.p0_k_b = cplan.p0_k_b; dst.p0_f_max = cplan.p0_f_max;
     }
     int raw_aligned() const { return (((uintptr_t)d_raw_in) & 15u) == 0 ? 1 : 0; }
     // the per-chunk peaks a fused front launch accumulates into start from zero: k_agc_classify zeroes what it has read (agc_peak

@@ -143,6 +143,9 @@ struct FrontArgs {
                                                // lanes that sample per round (<= 64)
     int64_t     w_edge_ta, w_edge_tb;   // edge tiles: [0, ta) and [tb, total)
     int64_t     w_n_edge1, w_n_edge;    // edge runs in the first region / in both
+    // k_front_p0 (front_p0.hip): the streaming outputs of the launch [p0_k_a, p0_k_b) (call-relative), dealt out as steps of 320 --
+    // w_n_stream runs of w_run_q steps, one more for the first w_run_r; the last frame a window load may start at
+    int64_t     p0_k_a, p0_k_b, p0_f_max;
     float       hb0[24];      // branch taps of stage 0 (pre-scaled by 0.5) for s_load access
     // fused output AGC of the locked phase (front_wave.hip, agc.hip): the kernel multiplies by the gain in *agc_state
     // before the pack and records max |y|^2 per chunk; k_agc_verify then confirms that no chunk changes the gain
@@ -237,6 +240,13 @@ int front_mid_tile(int nl);              // its tile: 128 nl frames
 // the half-wave's bank pairs prices lower, the fold's two extra instructions per slot counted)
 int front_tap_fold(uint32_t step, int nl);
 hipError_t launch_front_mid(const FrontArgs &a, hipStream_t s);
+// chains without a half-band stage as an output-major polyphase kernel with register-resident taps (front_p0.hip)
+int front_p0_waves();
+int front_p0_max_edge_waves();
+int front_p0_edge_tpw();
+bool front_p0_shape(const FrontArgs &a);        // needs S, formats, gain, iq / dc / nco switches, step, agc_fused, agc_chunk_frames, agc_shift, dbg
+void plan_front_p0(FrontArgs &a, int64_t wave_slots);   // after plan_front_s1 (256-frame tiles): needs phi0, step, frames_in, in_fmt
+hipError_t launch_front_p0(const FrontArgs &a, hipStream_t s);
 // two-stage chains (S = 2) with both half-bands and the polyphase in one kernel (front_s2.hip): a1 = the chain as k_cascade sees
 // it (K = 1), a2 = the last stage as k_front_s1 sees it, planned in ITS tiles (512 intermediate samples = 1024 input frames)
 int front_s2_waves();

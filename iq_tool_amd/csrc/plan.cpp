@@ -167,6 +167,21 @@ void Call::plan_geometry()
             warm = (int)((c->rp.history_in + wtile - 1) / wtile); if (warm < 1) warm = 1;
             plan_front_s1(cplan, wave_slots(front_s1_waves(cplan)), fixed_tpw(), warm, 1, wtile);
         }
+        // S == 0 (the cu8-nrsc5 presets): k_front_p0 on calls long enough to give every one of its 8 x CUs waves a few steps of 320
+        // outputs (shorter calls keep k_front_s1<S0>: same bytes).  Planned as k_front_s1's 256-frame tiles -- the edge runs are its
+        // run_tiles -- with the streaming tiles' OUTPUTS dealt out as steps
+        p0 = false;
+        if (fast_s0 && !casc) {
+            cplan.phi0 = c->phi;
+            if (front_p0_shape(cplan) && ((int64_t)frames_in >= ((int64_t)1 << 22) || (c->dbg & kDbgForceFat))) {
+                FrontArgs q = cplan;
+                plan_front_s1(q, wave_slots(front_p0_waves()), 0, warm, front_p0_edge_tpw(), 256);
+                if (q.w_n_edge <= front_p0_max_edge_waves() && q.w_edge_tb > q.w_edge_ta) {
+                    plan_front_p0(q, wave_slots(front_p0_waves()));
+                    if (q.w_n_stream > 0) { cplan = q; p0 = true; }
+                }
+            }
+        }
         // S == 2: both stages in ONE kernel (k_front_s2, front_s2.hip), planned in tiles of the LAST stage -- 512 intermediate samples
         // = 1024 input frames -- on the intermediate stream's own geometry.  Its streaming waves read the input as whole 16-byte
         // words from the start of a decimation group; calls that do not start on one, or are shorter than the histories they have

@@ -217,7 +217,7 @@ int Call::stage_front()
         a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (mid_nl == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
         if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "");
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
-            : launch_front_s1(a, c->stream)); }
+            : p0 ? launch_front_p0(a, c->stream) : launch_front_s1(a, c->stream)); }
         if (front_fused()) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }
     } else {
         KernelTimer kt(c, IQGPU_K_FRONT);
@@ -225,7 +225,7 @@ int Call::stage_front()
     }
     if (c->decim) c->hist_cur ^= 1;
     snprintf(c->front_kernel, sizeof(c->front_kernel), "%s",
-             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? mid_name
+             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? mid_name : p0 ? "k_front_p0"
              : fast_s1 ? "k_front_s1" : c->late ? "k_front+k_interp" : "k_front");
     return IQGPU_OK;
 }

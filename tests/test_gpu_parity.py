@@ -484,6 +484,63 @@ def test_s0_chain_cu8_nrsc5_preset_shape(gpu, oracle, monkeypatch, variant):
         int_close(slow, got, min_same=0.998)
 
 
+@pytest.mark.parametrize("in_format,out_format,target_hz,extra", [
+    ("cu8", "cu8", 1488375.0, {}),                                   # the cu8-nrsc5 preset: step 1.6125, arms repeat every 320 outputs
+    ("cu8", "cu8", 1488375.0, dict(agc=True)),                       # ... with its digital AGC (fused past the lock)
+    ("cu8", "cu8", 1488375.0, dict(filters=(("passband", 158.5e3, 113e3),))),   # cu8-nrsc5-usb: cf32 into the filter
+    ("cs8", "cs16", 2.4e6 / 1.75, {}),                               # step class (5, 7): every slot reloads every step
+    ("cs16", "cu8", 2.4e6 / 1.7, {}),                                # (5, 6)
+    ("cs16", "cs16", 2.4e6 / 1.96, {}),                              # the top of the range
+    ("cu8", "cs8", 2.4e6 / 1.601, {}),                               # ... and the bottom
+])
+def test_p0_kernel_equals_the_sample_major_kernel(gpu, oracle, monkeypatch, in_format, out_format, target_hz, extra):
+    """Round 5: chains without a half-band stage on k_front_p0 (front_p0.hip: output-major steps of 320, every lane loads and unpacks
+    the window of its five outputs itself, the slots' shifted tap rows stay in registers and are re-read under a mask only when a
+    slot's arm moves on) against k_front_s1<.., S0> (IQGPU_NO_FAT: 256-frame tiles through LDS): the same products in the same
+    order, so the BYTES must be equal -- whole calls, ragged splits that change kernel from call to call, a reset -- then the oracle."""
+    n = 4_700_001 if not extra.get("agc") else int(2.4e6 * 4.5)
+    raw = synth.raw_stream(n, 2.4e6, 51, in_format)
+    per = raw.size // n
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=2.4e6, target_rate_hz=target_hz, **extra)
+    agc = bool(extra.get("agc"))
+    c16 = 16384
+    splits = [[n]] + ([[c16 * 100, c16 * 60, n - c16 * 160]] if agc else [[1_500_000, 1, 4095, 2_000_001, n - 3_504_097], [3_000_003, n - 3_000_003]])
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos, names = [], 0, []
+        for k in split:
+            outs.append(ch.process(raw[per * pos:per * (pos + k)])); pos += k
+            names.append(ch.front_kernel())
+        st = ch.agc_state() if agc else None
+        ch.reset()
+        outs.append(ch.process(raw[:per * 1_200_000]))
+        return np.concatenate(outs), names, st
+
+    monkeypatch.setenv("IQGPU_NO_FAT", "1")
+    refs = [run(sp) for sp in splits]
+    assert all(nm == "k_front_s1" for r in refs for nm in r[1])
+    monkeypatch.delenv("IQGPU_NO_FAT")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # calls of any length (the size rule keeps calls below 2^22 frames on k_front_s1)
+    for sp, (ref, _, st_ref) in zip(splits, refs):
+        got, names, st = run(sp)
+        assert "k_front_p0" in names, names
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (sp, names, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+        assert st == st_ref
+    monkeypatch.delenv("IQGPU_FORCE_FAT")
+    # by the size rule alone: the long call takes k_front_p0, the bytes stay
+    ch = gpu.Chain(**kw)
+    one = ch.process(raw)
+    assert ch.front_kernel() == "k_front_p0" and np.array_equal(one, refs[0][0][:one.size])
+    if not agc:
+        want = run_oracle(oracle, raw, **kw)
+        if out_format == "cf32":
+            assert np.abs(cf(one) - cf(want)).max() <= 2 * TOL
+        else:
+            int_close(one, want, min_same=0.995)
+
+
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
     n = 1 << 20
     raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
