@@ -21,10 +21,18 @@
 //     lanes costs about a cycle of the LDS pipe, tools/lds_mask_bench.hip, against 5.8 for the full gather).  For a step without
 //     such a period every slot reloads every time: the full gather, and still no sample traffic in LDS.
 //
+// STATUS (round 5): parity-green (bytes of k_front_s1 on seven chains, fused AGC and a filter behind included) and NOT faster than
+// k_front_s1<S0> yet -- 0.585 against 0.575 ms per 2^28 cu8 frames on the cu8-nrsc5 preset, 0.61 against 0.64 in front of the -usb
+// filter: with two waves per SIMD the steps' dependent phases (masked tap reads -> unpack -> multiply-adds -> stores, a vmcnt wait
+// wherever hipcc re-uses a store's registers) are not covered, VALU 50 % and LDS 26 % busy, waves waiting 47 % of their cycles
+// (profiles/r05_presets.md).  OPT-IN: IQGPU_P0=1 selects it; the default for these chains stays k_front_s1.
+//
 // Two waves per SIMD (80 VGPRs of taps + 44 of window + the frames of the step after next in flight).  Edge tiles -- the stream
 // history in front of the call, the tail that becomes the next call's history -- are run by the scalar-load instantiation of
 // run_tiles (front_tiles.hpp, 256-frame tiles) on a few extra waves, as in the other wave-autonomous kernels; the streaming part is
 // the outputs whose position lies in tiles [w_edge_ta, w_edge_tb).  Fused digital AGC as in k_front_mid (float peaks per chunk).
+#include <type_traits>
+
 #include "front_tiles.hpp"
 #include "front_fat_common.hpp"
 
@@ -48,9 +56,11 @@ template <int FMT>
 __device__ __forceinline__ v2f p0_unpack(const uint32_t *r, const int i)
 {
     if (FMT == IQGPU_FMT_CU8) {
-        const uint32_t h = r[i >> 1] >> (16 * (i & 1));
-        // ((float)u - 127.5) * (1 / 128): both steps exact in float (src/sample_convert.c:75-96; gain 1)
-        return v2f{((float)(h & 0xffu) - 127.5f) * (1.0f / 128.0f), ((float)((h >> 8) & 0xffu) - 127.5f) * (1.0f / 128.0f)};
+        // ((float)u - 127.5) * (1 / 128) (src/sample_convert.c:75-96; gain 1): both steps are exact in float, and so is
+        // u * 2^-7 - 127.5 * 2^-7 in one fused multiply-add -- the same value, one packed instruction per frame
+        const uint32_t w = r[i >> 1];
+        const v2f u = (i & 1) ? v2f{(float)((w >> 16) & 0xffu), (float)(w >> 24)} : v2f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
+        return __builtin_elementwise_fma(u, v2f{1.0f / 128.0f, 1.0f / 128.0f}, v2f{-127.5f / 128.0f, -127.5f / 128.0f});
     } else if (FMT == IQGPU_FMT_CS8) {
         const uint32_t h = r[i >> 1] >> (16 * (i & 1));
         return v2f{(float)(signed char)(h & 0xffu) * (1.0f / 128.0f), (float)(signed char)((h >> 8) & 0xffu) * (1.0f / 128.0f)};
@@ -60,11 +70,12 @@ __device__ __forceinline__ v2f p0_unpack(const uint32_t *r, const int i)
 }
 
 // Steps [s_begin, s_end) of the launch's streaming outputs [k_a, k_b) (call-relative output indices).
-// FMT: cu8 / cs8 (2 bytes per frame) or cs16; OUTB: bytes per output frame (2: cu8 / cs8, 4: cs16, 8: cf32)
-template <int FMT, int L3, int L4, int OUTB, bool AGC>
+// FMT: cu8 / cs8 (2 bytes per frame) or cs16; OUTF: the output format (cu8 / cs8: 2 bytes per frame, cs16: 4, cf32: 8)
+template <int FMT, int L3, int L4, int OUTF, bool AGC>
 __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_lds, const int lane, const int64_t s_begin, const int64_t s_end)
 {
     constexpr int BPS = (FMT == IQGPU_FMT_CS16) ? 4 : 2;
+    constexpr int OUTB = OUTF == IQGPU_FMT_CF32 ? 8 : OUTF == IQGPU_FMT_CS16 ? 4 : 2;
     constexpr int NW = (BPS == 2) ? 12 : 24;                 // raw words per window: 24 frames loaded, 22 used
     constexpr int NS = 5;
     constexpr int LO[5] = {0, 1, 3, L3, L4};
@@ -75,8 +86,11 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
 
     // phase of the lane's first output of step s_begin: phi + k step, in samples << 24 from the call's first frame
     uint64_t P = a.phi0 + (uint64_t)(a.p0_k_a + s_begin * kP0Step + 5 * lane) * (uint64_t)step;
-    // the frames of a step are fetched two steps ahead (two waves per SIMD cover little latency by themselves)
-    uint32_t r0[NW], r1[NW];
+    // the frames of a step are fetched NB steps ahead, behind the stores of the step that frees their buffer (two waves per SIMD cover
+    // little latency by themselves; and vmcnt counts in order: a wait for a store -- hipcc places one wherever a register that a
+    // store reads is written again -- must not stand behind younger loads, or every step waits for the frames it has just asked for)
+    constexpr int NB = 2;                                    // (three buffers leave the instantiations with the fused AGC short of registers)
+    uint32_t rb[NB][NW];
     auto fetch = [&](uint64_t Pq, uint32_t (&r)[NW]) {
         int64_t f0 = (int64_t)(Pq >> 24) - 13;
         // (lanes of the last step that own no output any more would read past what the plan guarantees: pulled back)
@@ -88,8 +102,8 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
             r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
     };
-    fetch(P, r0);
-    fetch(P + adv, r1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fetch(P + (uint64_t)b * adv, rb[b]);
 
     v2f t[NS][8];                                            // the slots' shifted tap rows, kept from step to step
     uint32_t held[NS];                                       // ... and the (position, arm) each was loaded for
@@ -117,7 +131,9 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         if (lane == 0 && m > 0.0f) atomicMax(a.agc_peak2 + c, (unsigned long long)__double_as_longlong((double)m));
     };
 
-    for (int64_t s = s_begin; s < s_end; ++s) {
+    // PARTIAL: the launch's last step, whose outputs from p0_k_b on do not exist (its own copy of the code: the loop has no such test)
+    auto one_step = [&](auto partial, const int64_t s, uint32_t (&rc)[NW]) {
+        constexpr bool PARTIAL = decltype(partial)::value;
         const uint32_t F = (uint32_t)P & 0xffffffu;           // phase of the lane's first output inside its sample
         const int64_t p0 = (int64_t)(P >> 24);
         // ---- which tap rows changed: re-read those under their lanes' mask
@@ -137,13 +153,9 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         v2f Hw[14], own[9];
         Hw[0] = v2f{0.f, 0.f};
 #pragma unroll
-        for (int i = 1; i < 14; ++i) Hw[i] = p0_unpack<FMT>(r0, i - 1);
+        for (int i = 1; i < 14; ++i) Hw[i] = p0_unpack<FMT>(rc, i - 1);
 #pragma unroll
-        for (int m = 0; m < 9; ++m) own[m] = p0_unpack<FMT>(r0, 13 + m);
-        // (the frames of the step after next take the registers the unpack has just freed)
-#pragma unroll
-        for (int q = 0; q < NW; ++q) r0[q] = r1[q];
-        fetch(P + 2 * adv, r1);
+        for (int m = 0; m < 9; ++m) own[m] = p0_unpack<FMT>(rc, 13 + m);
         // ---- five outputs: the chains of the other kernels, slot by slot
         v2f y[NS];
         pp_slots3<9, 0, 1, 3>(Hw, own, t[0], t[1], t[2], y[0], y[1], y[2]);
@@ -161,7 +173,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
-                const bool valid = k0 + j < a.p0_k_b;
+                const bool valid = !PARTIAL || k0 + j < a.p0_k_b;
                 const bool late = mine + (Pj[j] >> 24) >= b_rel;
                 if (valid) { if (late) m1 = fmaxf(m1, m2); else m0 = fmaxf(m0, m2); }
                 crossed = crossed || (valid && late);
@@ -174,7 +186,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         }
         // ---- pack + store: the lane's five outputs are consecutive
         char *ob = (char *)a.out + k0 * OUTB;
-        const bool whole = k0 + NS <= a.p0_k_b;
+        const bool whole = !PARTIAL;
         if (OUTB == 8) {
             typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
             typedef float f2v __attribute__((ext_vector_type(2), aligned(8)));
@@ -200,7 +212,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
             typedef uint32_t u32a2 __attribute__((aligned(2)));
             uint32_t pk[NS];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) pk[j] = pack_b8(cf2{y[j].x, y[j].y}, a.out_fmt == IQGPU_FMT_CU8);
+            for (int j = 0; j < NS; ++j) pk[j] = pack_b8(cf2{y[j].x, y[j].y}, OUTF == IQGPU_FMT_CU8);
             if (whole) {
                 *(u32a2 *)ob = pk[0] | (pk[1] << 16);
                 *(u32a2 *)(ob + 4) = pk[2] | (pk[3] << 16);
@@ -210,12 +222,26 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
                 for (int j = 0; j < NS; ++j) if (k0 + j < a.p0_k_b) *(uint16_t *)(ob + 2 * j) = (uint16_t)pk[j];
             }
         }
+        // the frames of step s + NB take the buffer this step has emptied (the buffers take turns, NB steps per trip of the loop:
+        // moving a queue up by register copies would wait for the load it copies)
+        fetch(P + (uint64_t)NB * adv, rc);
         P += adv; Pw += adv;
+    };
+    // the launch's very last step may be partial: it is taken out of the loop (s_last = the run's end when the run holds it)
+    const bool has_partial = s_end * kP0Step > a.p0_k_b - a.p0_k_a;
+    const int64_t s_full = has_partial ? s_end - 1 : s_end;
+    int64_t s = s_begin;
+    for (; s + NB <= s_full; s += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) one_step(std::false_type{}, s + b, rb[b]);
     }
+    int b = 0;
+    for (; s < s_full; ++s, ++b) one_step(std::false_type{}, s, rb[0]);            // (NB = 2: at most one whole step is left over, in the first buffer)
+    if (has_partial) { if (b == 0) one_step(std::true_type{}, s, rb[0]); else one_step(std::true_type{}, s, rb[1]); }
     if (AGC) flush_peak(m0, agc_c);
 }
 
-template <int FMT, int L3, int L4, int OUTB, bool AGC>
+template <int FMT, int L3, int L4, int OUTF, bool AGC>
 __global__ __launch_bounds__(kP0Threads) void k_front_p0(const FrontArgs a)
 {
     constexpr int BPS = (FMT == IQGPU_FMT_CS16) ? 4 : 2;
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(kP0Threads) void k_front_p0(const FrontArgs a)
         if (r >= a.w_n_stream) return;
         const int64_t s0 = r * a.w_run_q + (r < a.w_run_r ? r : a.w_run_r), s1 = s0 + a.w_run_q + (r < a.w_run_r ? 1 : 0);
         const unsigned tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_p0<FMT, L3, L4, OUTB, AGC>(a, tap_lds, lane, s0, s1);
+        run_p0<FMT, L3, L4, OUTF, AGC>(a, tap_lds, lane, s0, s1);
     }
 }
 
@@ -309,20 +335,20 @@ hipError_t launch_front_p0(const FrontArgs &a, hipStream_t s)
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kP0Waves - 1) / kP0Waves);
     if (grid == 0) return hipSuccess;
-    const int outb = a.out_fmt == IQGPU_FMT_CF32 ? 8 : a.out_fmt == IQGPU_FMT_CS16 ? 4 : 2;
-#define IQGPU_LAUNCH_P0(FMT, L3, L4, OUTB, AGC)                                                                     \
+#define IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, AGC)                                                                     \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_p0<FMT, L3, L4, OUTB, AGC>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_p0<FMT, L3, L4, OUTB, AGC>), dim3(grid), dim3(kP0Threads), lds, s, a);          \
+        { const hipError_t e = cache.ensure((const void *)k_front_p0<FMT, L3, L4, OUTF, AGC>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_p0<FMT, L3, L4, OUTF, AGC>), dim3(grid), dim3(kP0Threads), lds, s, a);          \
     } while (0)
+#define IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, OUTF)                                                                      \
+    do { if (a.agc_fused) IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, true); else IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, false); } while (0)
 #define IQGPU_LAUNCH_P0_OUT(FMT, L3, L4)                                                                            \
     do {                                                                                                              \
-        if (outb == 8) IQGPU_LAUNCH_P0(FMT, L3, L4, 8, false);                                                      \
-        else if (outb == 4 && a.agc_fused) IQGPU_LAUNCH_P0(FMT, L3, L4, 4, true);                                   \
-        else if (outb == 4) IQGPU_LAUNCH_P0(FMT, L3, L4, 4, false);                                                 \
-        else if (a.agc_fused) IQGPU_LAUNCH_P0(FMT, L3, L4, 2, true);                                                \
-        else IQGPU_LAUNCH_P0(FMT, L3, L4, 2, false);                                                                \
+        if (a.out_fmt == IQGPU_FMT_CF32) IQGPU_LAUNCH_P0(FMT, L3, L4, IQGPU_FMT_CF32, false);                       \
+        else if (a.out_fmt == IQGPU_FMT_CS16) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS16);                     \
+        else if (a.out_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CU8);                       \
+        else IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS8);                                                       \
     } while (0)
 #define IQGPU_LAUNCH_P0_CLS(FMT)                                                                                    \
     do {                                                                                                              \
@@ -335,6 +361,7 @@ hipError_t launch_front_p0(const FrontArgs &a, hipStream_t s)
     else IQGPU_LAUNCH_P0_CLS(IQGPU_FMT_CS16);
 #undef IQGPU_LAUNCH_P0_CLS
 #undef IQGPU_LAUNCH_P0_OUT
+#undef IQGPU_LAUNCH_P0_AGC
 #undef IQGPU_LAUNCH_P0
     return hipGetLastError();
 }
