@@ -21,11 +21,14 @@
 //     lanes costs about a cycle of the LDS pipe, tools/lds_mask_bench.hip, against 5.8 for the full gather).  For a step without
 //     such a period every slot reloads every time: the full gather, and still no sample traffic in LDS.
 //
-// STATUS (round 5): parity-green (bytes of k_front_s1 on seven chains, fused AGC and a filter behind included) and NOT faster than
-// k_front_s1<S0> yet -- 0.585 against 0.575 ms per 2^28 cu8 frames on the cu8-nrsc5 preset, 0.61 against 0.64 in front of the -usb
-// filter: with two waves per SIMD the steps' dependent phases (masked tap reads -> unpack -> multiply-adds -> stores, a vmcnt wait
-// wherever hipcc re-uses a store's registers) are not covered, VALU 50 % and LDS 26 % busy, waves waiting 47 % of their cycles
-// (profiles/r05_presets.md).  OPT-IN: IQGPU_P0=1 selects it; the default for these chains stays k_front_s1.
+// Measured (round 5, profiles/r05_presets.md): cu8-nrsc5 front end 0.561 -> 0.441 ms per 2^28 cu8 frames, 0.66 -> 0.61 ms with cf32
+// output in front of the -usb / -lsb filter (where the 1.3 GB of cf32 it writes set the pace).  What it took beyond the design:
+// the tap re-reads of step s + 1 are issued at the END of step s (their LDS round trip runs beside the stores and the next unpack:
+// 0.585 -> 0.465 ms); the frames of step s + 2 are fetched BEHIND the stores of step s (vmcnt counts in order, and hipcc waits
+// for a store wherever its registers are written again); the folded arm placement (consecutive lanes are 16 arms apart for
+// this step: linear planes put a slot's re-reading lanes into two bank pairs); the chunk sorting of the fused AGC only in the
+// one step in thirty that holds a boundary.  Bound today by VALU + LDS added up (two waves per SIMD hardly overlap them): 368
+// VALU instructions and 179 LDS cycles per step.  IQGPU_NO_P0=1 keeps k_front_s1<S0>.
 //
 // Two waves per SIMD (80 VGPRs of taps + 44 of window + the frames of the step after next in flight).  Edge tiles -- the stream
 // history in front of the call, the tail that becomes the next call's history -- are run by the scalar-load instantiation of
@@ -131,24 +134,33 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         if (lane == 0 && m > 0.0f) atomicMax(a.agc_peak2 + c, (unsigned long long)__double_as_longlong((double)m));
     };
 
-    // PARTIAL: the launch's last step, whose outputs from p0_k_b on do not exist (its own copy of the code: the loop has no such test)
-    auto one_step = [&](auto partial, const int64_t s, uint32_t (&rc)[NW]) {
-        constexpr bool PARTIAL = decltype(partial)::value;
-        const uint32_t F = (uint32_t)P & 0xffffffu;           // phase of the lane's first output inside its sample
-        const int64_t p0 = (int64_t)(P >> 24);
-        // ---- which tap rows changed: re-read those under their lanes' mask
-        uint32_t Pj[NS];
+    // which tap rows the step at phase Pq needs anew: re-read those under their lanes' mask.  Issued at the END of the step before
+    // (its multiply-adds have let go of the registers), so that the reads' round trip runs beside that step's stores and the next
+    // one's unpack instead of in front of its first multiply-add
+    auto reload = [&](const uint64_t Pq) {
+        const uint32_t Fq = (uint32_t)Pq & 0xffffffu;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            Pj[j] = F + (uint32_t)j * step;
-            const uint32_t key = Pj[j] >> 16;
+            const uint32_t pj = Fq + (uint32_t)j * step;
+            const uint32_t key = pj >> 16;
             if (key != held[j]) {
-                const unsigned row = a.tap_fold ? tap_row<true>(tap_lds, Pj[j], LO[j]) : tap_row<false>(tap_lds, Pj[j], LO[j]);
+                const unsigned row = a.tap_fold ? tap_row<true>(tap_lds, pj, LO[j]) : tap_row<false>(tap_lds, pj, LO[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) t[j][i] = *(lds_v2f *)(size_t)(row + tap_pair_off(i));
                 held[j] = key;
             }
         }
+    };
+    reload(P);
+
+    // PARTIAL: the launch's last step, whose outputs from p0_k_b on do not exist (its own copy of the code: the loop has no such test)
+    auto one_step = [&](auto partial, const int64_t s, uint32_t (&rc)[NW]) {
+        constexpr bool PARTIAL = decltype(partial)::value;
+        const uint32_t F = (uint32_t)P & 0xffffffu;           // phase of the lane's first output inside its sample
+        const int64_t p0 = (int64_t)(P >> 24);
+        uint32_t Pj[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) Pj[j] = F + (uint32_t)j * step;
         // ---- the window: Hw[i] = sample p0 - 14 + i (i = 1 .. 13), own[m] = sample p0 + m (m = 0 .. 8)
         v2f Hw[14], own[9];
         Hw[0] = v2f{0.f, 0.f};
@@ -168,20 +180,30 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
                 m0 = 0.0f; agc_c += 1; agc_B += a.agc_chunk_frames;
             }
             const uint32_t b_rel = (uint32_t)(agc_B - first < 4096 ? agc_B - first : 4096);   // boundary, in samples behind `first`
-            const uint32_t mine = (uint32_t)p0 - (uint32_t)first;
-            bool crossed = false;
+            if (b_rel > 1024u) {
+                // (no chunk boundary inside this step -- all but one step in thirty: nothing to sort)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
-                const bool valid = !PARTIAL || k0 + j < a.p0_k_b;
-                const bool late = mine + (Pj[j] >> 24) >= b_rel;
-                if (valid) { if (late) m1 = fmaxf(m1, m2); else m0 = fmaxf(m0, m2); }
-                crossed = crossed || (valid && late);
-                y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
-            }
-            if (__builtin_amdgcn_ballot_w64(crossed) != 0ull) {   // the step held a boundary: chunk agc_c is complete for this run
-                flush_peak(m0, agc_c);
-                m0 = m1; m1 = 0.0f; agc_c += 1; agc_B += a.agc_chunk_frames;
+                for (int j = 0; j < NS; ++j) {
+                    const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
+                    if (!PARTIAL || k0 + j < a.p0_k_b) m0 = fmaxf(m0, m2);
+                    y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
+                }
+            } else {
+                const uint32_t mine = (uint32_t)p0 - (uint32_t)first;
+                bool crossed = false;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
+                    const bool valid = !PARTIAL || k0 + j < a.p0_k_b;
+                    const bool late = mine + (Pj[j] >> 24) >= b_rel;
+                    if (valid) { if (late) m1 = fmaxf(m1, m2); else m0 = fmaxf(m0, m2); }
+                    crossed = crossed || (valid && late);
+                    y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
+                }
+                if (__builtin_amdgcn_ballot_w64(crossed) != 0ull) {   // the step held a boundary: chunk agc_c is complete for this run
+                    flush_peak(m0, agc_c);
+                    m0 = m1; m1 = 0.0f; agc_c += 1; agc_B += a.agc_chunk_frames;
+                }
             }
         }
         // ---- pack + store: the lane's five outputs are consecutive
@@ -226,6 +248,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         // moving a queue up by register copies would wait for the load it copies)
         fetch(P + (uint64_t)NB * adv, rc);
         P += adv; Pw += adv;
+        reload(P);
     };
     // the launch's very last step may be partial: it is taken out of the loop (s_last = the run's end when the run holds it)
     const bool has_partial = s_end * kP0Step > a.p0_k_b - a.p0_k_a;

@@ -171,7 +171,7 @@ void Call::plan_geometry()
         // outputs (shorter calls keep k_front_s1<S0>: same bytes).  Planned as k_front_s1's 256-frame tiles -- the edge runs are its
         // run_tiles -- with the streaming tiles' OUTPUTS dealt out as steps
         p0 = false;
-        if (fast_s0 && !casc && (c->dbg & kDbgP0)) {
+        if (fast_s0 && !casc && !(c->dbg & kDbgNoP0)) {
             cplan.phi0 = c->phi;
             if (front_p0_shape(cplan) && ((int64_t)frames_in >= ((int64_t)1 << 22) || (c->dbg & kDbgForceFat))) {
                 FrontArgs q = cplan;

@@ -215,6 +215,9 @@ int Call::stage_front()
         }
         const int mid_nl = mid ? front_mid_nl(a) : 0;
         a.tap_fold = (uint32_t)(fat ? c->tap_fold8 : mid ? (mid_nl == 8 ? c->tap_fold8 : c->tap_fold6) : 0);
+        // (k_front_p0: consecutive lanes are five outputs apart -- for the NRSC-5 step 16 arms -- so the lanes that re-read a slot in
+        //  the same step would meet in two bank pairs of a linear plane: always the folded placement)
+        if (p0) a.tap_fold = 1u;
         if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "");
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : p0 ? launch_front_p0(a, c->stream) : launch_front_s1(a, c->stream)); }

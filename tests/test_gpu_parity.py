@@ -521,7 +521,6 @@ def test_p0_kernel_equals_the_sample_major_kernel(gpu, oracle, monkeypatch, in_f
     refs = [run(sp) for sp in splits]
     assert all(nm == "k_front_s1" for r in refs for nm in r[1])
     monkeypatch.delenv("IQGPU_NO_FAT")
-    monkeypatch.setenv("IQGPU_P0", "1")                  # opt-in (round 5: correct, not faster than k_front_s1<S0> yet)
     monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # calls of any length (the size rule keeps calls below 2^22 frames on k_front_s1)
     for sp, (ref, _, st_ref) in zip(splits, refs):
         got, names, st = run(sp)
@@ -534,10 +533,10 @@ def test_p0_kernel_equals_the_sample_major_kernel(gpu, oracle, monkeypatch, in_f
     ch = gpu.Chain(**kw)
     one = ch.process(raw)
     assert ch.front_kernel() == "k_front_p0" and np.array_equal(one, refs[0][0][:one.size])
-    monkeypatch.delenv("IQGPU_P0")
+    monkeypatch.setenv("IQGPU_NO_P0", "1")
     ch = gpu.Chain(**kw)
     ch.process(raw)
-    assert ch.front_kernel() == "k_front_s1"             # without the switch: the sample-major kernel
+    assert ch.front_kernel() == "k_front_s1"             # the switch keeps the sample-major kernel
     if not agc:
         want = run_oracle(oracle, raw, **kw)
         if out_format == "cf32":
