@@ -335,14 +335,14 @@ hipError_t launch_agc(const AgcArgs &a, hipStream_t s)
 //     if (p > 1e-6) g *= exp(-0.5 alpha ln p);  g = min(g, 1e6);   out = y
 // a nonlinear recurrence with no closed form across samples.  What makes it parallel is that it FORGETS:
 // linearised around its fixed point the state error decays like (1 - alpha / 2)^n, so a lane that starts
-// `warm` = 40 / alpha samples early from ANY state arrives within 2e-9 of the true one.
+// `warm` = 26 / alpha samples early from a state within a few per cent arrives within 1e-7 of the true one.
 //   The chunk grid belongs to the STREAM, not to the call (round 4): chunk k covers stream positions [k C, (k + 1) C), and
 //   what a lane does depends on positions and samples only, never on where the calls were cut -- the output is the same
 //   under ANY split of the stream into calls, byte for byte (test_agc_rms_is_split_invariant).
 //   k_agc_rms_spec: one LANE per chunk that overlaps the call.  A chunk that began in an earlier call continues from the
 //       carried state.  Every other chunk starts `warm` samples ahead of its first output -- in the history the chain
 //       keeps of the AGC's input (the last `warm` samples of earlier calls) where that lies before the call -- from a
-//       guess made of those samples alone (gain = 1 / rms of the first 32, unit energy); within `warm` samples of the
+//       guess made of those samples alone (gain = 1 / rms of the first 256, unit energy); within `warm` samples of the
 //       last reset it starts AT the reset, from the reset state (exact).  Each lane records the state it arrived with
 //       and the state it left.
 //   k_agc_rms_fix:  checks, in parallel, that every chunk arrived where its predecessor left (2e-6 relative
@@ -453,9 +453,14 @@ __global__ __launch_bounds__(64) void k_agc_rms_spec(const AgcRmsArgs a)
         if (a0 <= 0) { i = -a.pos0; st.g = 1.0f; st.p = 1.0f; }      // from the reset, in the reset state (agc_reset: src/agc.c:227-229)
         else {
             i = a0 - a.pos0;                                 // >= -warm = -hist_valid here
-            float m = 0.0f;
-            for (int k = 0; k < 32; ++k) { const cf2 v = a.x[i + k]; m = fmaf(v.x, v.x, fmaf(v.y, v.y, m)); }
-            m *= 1.0f / 32.0f;
+            // (round 5: the power of the first 256 samples, four independent sums -- a guess within a few per cent instead of the
+            //  ~18 % of 32 samples, which is what lets the warm-up end after 26 / alpha samples instead of 40 / alpha)
+            float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 256; k += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const cf2 v = a.x[i + k + u]; m4[u] = fmaf(v.x, v.x, fmaf(v.y, v.y, m4[u])); }
+            }
+            float m = ((m4[0] + m4[1]) + (m4[2] + m4[3])) * (1.0f / 256.0f);
             st.g = m > 1e-20f ? fminf(1.0f / sqrtf(m), 1e6f) : 1.0f;
             st.p = 1.0f;
         }
@@ -500,9 +505,14 @@ __global__ __launch_bounds__(1024) void k_agc_rms_fix(const AgcRmsArgs a)
 
 void agc_rms_geometry(float alpha, int64_t pos0, int64_t n, int64_t *chunk, int64_t *warm, int32_t *n_chunks)
 {
-    int64_t w = (int64_t)(40.0 / (double)alpha + 0.5);         // e^-20 of the guess's error is left
+    // e^-13 = 2.3e-6 of the guess's error is left after 26 / alpha samples: with the guess within a few per cent (256 samples of
+    // power) an order of magnitude inside the 2e-6 at which k_agc_rms_fix accepts a chunk's arrival (until round 4: 40 / alpha behind
+    // a 32-sample guess).  Chunks of warm / 16, at least 256: a call costs warm + chunk dependent samples of ~0.18 us whatever its
+    // length -- `local` (alpha 1e-2): 2600 + 256 = 0.5 ms (1.1 until round 4), `dx` (1e-4): 260 000 + 16 250 = 50 ms (77)
+    int64_t w = (int64_t)(26.0 / (double)alpha + 0.5);
     w = (w + 1) & ~(int64_t)1;
-    int64_t ch = w / 16; if (ch < 2048) ch = 2048;
+    if (w < 512) w = 512;                                       // (the guess reads 256 samples of the window)
+    int64_t ch = w / 16; if (ch < 256) ch = 256;
     ch &= ~(int64_t)1;
     *warm = w; *chunk = ch;
     *n_chunks = n > 0 ? (int32_t)((pos0 + n + ch - 1) / ch - pos0 / ch) : 0;     // chunks of the stream's grid that overlap [pos0, pos0 + n)
