@@ -207,11 +207,12 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const AgcState st = *a.state;
-    int bad = 0, weak = 0, last_h = -1;
+    int bad = 0, weak = 0, last_h = -1, cls_k = 0;
     if (c < a.geom.n_chunks) {
         int k = 0;
         if (st.locked) {
             const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
+            a.chunk_b[c] = b;                                      // (the verdict's chunk times: not worked out a second time by one workgroup)
             if (e > b) {                                           // empty chunks never reach agc_apply
                 const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
                 const float outp = pk * st.gain;
@@ -228,9 +229,26 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
                 else { k = 2; weak = 1; }
             }
         }
+        cls_k = k;
         a.chunk_len[c] = k;                                        // scratch: 0 empty, 1 healthy, 2 weak
         a.peak2[c] = 0ull;                                         // handed back zeroed: the next fused launch accumulates into it (no fill on the hot path)
         if (a.peak2_fallback) a.peak2_fallback[c] = 0ull;          // ... and the fallback's own array, which its k_agc_peak accumulates into
+    }
+    // the last healthy chunk at or in front of every chunk, inside this workgroup's 256 (gain[] doubles as the scratch: the fused pass
+    // has no use for it, and the fallback's k_agc_scan writes it anew) and the workgroup's last one: what the verdict's hang-time
+    // test needs.  (Round 5: until then ONE workgroup scanned all chunks, 256 at a time, for a prefix maximum of healthy chunk
+    // TIMES -- which grow with the chunk index, so the maximum is the last healthy index: 0.13 ms for the 16384 chunks of a 2^28-frame
+    // call of the cs16-am-nrsc5 preset, whose narrow output makes weak chunks the rule.)
+    {
+        __shared__ int s_wl[4];
+        int h = cls_k == 1 ? c : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(h, o); if ((int)(threadIdx.x & 63) >= o) h = v > h ? v : h; }
+        if ((threadIdx.x & 63) == 63) s_wl[threadIdx.x >> 6] = h;
+        __syncthreads();
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) h = s_wl[w] > h ? s_wl[w] : h;
+        if (c < a.geom.n_chunks) ((int32_t *)a.gain)[c] = h;
+        if (threadIdx.x == 255) a.wg_last[blockIdx.x] = h;
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 1, 1);
     if (__ballot(weak) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 2, 1);
@@ -254,36 +272,34 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
 __device__ void agc_verdict(const AgcArgs &a)
 {
     __shared__ int s_bad;
-    __shared__ double s_scan[256];
-    __shared__ double s_carry;
     const int tid = threadIdx.x, nthr = (int)blockDim.x;
     const AgcState st = *a.state;
     const int32_t *cls = a.chunk_len;
-    auto t_of = [&](int c) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)agc_out_end(a.geom, (int64_t)c - 1)) / a.rate; };
+    // (time of a chunk = outputs seen before it / rate; the counts come from the classification: 16384 chunks of two 64-bit
+    //  divisions each took this one workgroup 0.1 ms on the cs16-am-nrsc5 preset, whose narrow output makes weak chunks the rule)
+    auto t_of = [&](int c) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)a.chunk_b[c]) / a.rate; };
     const int any_bad = a.verify_flag[1], any_weak = a.verify_flag[2], last_healthy = a.verify_flag[3];
     if (tid == 0) s_bad = (!st.locked || any_bad) ? 1 : 0;
     __syncthreads();
     if (!s_bad && any_weak) {
-        // a weak chunk creeps iff its time is more than the hang time past the last healthy chunk before it
-        if (tid == 0) s_carry = st.last_strong;
-        __syncthreads();
-        for (int base = 0; base < a.geom.n_chunks; base += nthr) {
-            const int c = base + tid;
-            const int k = c < a.geom.n_chunks ? cls[c] : 0;
-            const double tc = k ? t_of(c) : 0.0;
-            s_scan[tid] = k == 1 ? tc : -1.0e300;
+        // a weak chunk creeps iff its time is more than the hang time past the last healthy chunk before it (or the state's last
+        // strong peak): the last healthy chunk inside its workgroup of the classification, else in front of that workgroup
+        __shared__ int s_wgp[1024];
+        const int n_wg = (a.geom.n_chunks + 255) / 256;
+        if (n_wg > 1024) { if (tid == 0) s_bad = 1; }              // (more than 2^18 chunks in one call: the exact kernels)
+        else {
+            for (int w = tid; w < n_wg; w += nthr) s_wgp[w] = a.wg_last[w];
             __syncthreads();
-            for (int off = 1; off < nthr; off <<= 1) {             // inclusive prefix maximum
-                const double o = tid >= off ? s_scan[tid - off] : -1.0e300;
-                __syncthreads();
-                if (o > s_scan[tid]) s_scan[tid] = o;
-                __syncthreads();
+            if (tid == 0) { int m = -1; for (int w = 0; w < n_wg; ++w) { m = s_wgp[w] > m ? s_wgp[w] : m; s_wgp[w] = m; } }
+            __syncthreads();
+            const int32_t *lh = (const int32_t *)a.gain;
+            for (int c = tid; c < a.geom.n_chunks; c += nthr) {
+                if (cls[c] != 2) continue;
+                int last = lh[c];
+                if (last < 0 && c >= 256) last = s_wgp[c / 256 - 1];
+                const double before = last >= 0 ? fmax(st.last_strong, t_of(last)) : st.last_strong;
+                if (t_of(c) - before > (double)kAgcHangTime) atomicOr(&s_bad, 1);
             }
-            const double before = tid > 0 ? fmax(s_carry, s_scan[tid - 1]) : s_carry;
-            if (k == 2 && tc - before > (double)kAgcHangTime) atomicOr(&s_bad, 1);
-            __syncthreads();
-            if (tid == 0) s_carry = fmax(s_carry, s_scan[nthr - 1]);
-            __syncthreads();
         }
     }
     __syncthreads();
