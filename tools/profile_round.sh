@@ -26,6 +26,11 @@ for cfg in 3 4 preset; do
   rocprofv3 --kernel-trace --stats -d "$OUT/stats_cfg$cfg" -o stats --output-format csv -- $TIMED --config $cfg > "$OUT/stats_cfg$cfg.log" 2>&1
   echo "stats cfg $cfg done"
 done
+# ---- the seven shipped presets (secondary.presets), and the cs16-fm-nrsc5 preset through submit / collect (verdict on the host)
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_presets" -o stats --output-format csv -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-leg --no-extra --only-presets > "$OUT/stats_presets.log" 2>&1
+echo "stats presets done"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_preset_submit" -o stats --output-format csv -- python3 $REPO/tools/gpu/r5_preset_pipe.py > "$OUT/stats_preset_submit.log" 2>&1
+echo "stats preset submit done"
 # ---- counters of the headline kernel (PMC_VARIANTS: default all three)
 for v in ${PMC_VARIANTS:-mid fat s1}; do
   variant $v
@@ -64,6 +69,11 @@ for cfg in 3 4 preset; do
   n=config$cfg; [ $cfg = preset ] && n=preset
   [ -n "$f" ] && cp "$f" "profiles/${TAG}_kernel_stats_$n.csv"
 done
+for n in presets preset_submit; do
+  f=$(find "$OUT/stats_$n" -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "profiles/${TAG}_kernel_stats_$n.csv"
+done
+cp "$OUT/stats_preset_submit.log" "profiles/${TAG}_preset_submit.log" 2>/dev/null
 {
   echo "# profiles/${TAG}_pmc_summary.txt -- rocprofv3 --pmc passes of \`$BENCH\` (BASELINE configs[1], 2^28 frames per launch),"
   echo "# one pass per counter set, never combined with tracing (tools/profile_round.sh); per-dispatch averages."
