@@ -135,7 +135,8 @@ typedef struct {
 } iqgpu_chain_info;
 
 /* Per-kernel device time accumulated by HIP events on the chain's stream (profiling mode only). */
-enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_AGC = 5, IQGPU_K_CASCADE = 6, IQGPU_K_COUNT = 8 };
+enum { IQGPU_K_DC_PREFIX = 0, IQGPU_K_DC_SCAN = 1, IQGPU_K_FRONT = 2, IQGPU_K_FILTER = 3, IQGPU_K_MOVE = 4, IQGPU_K_AGC = 5,
+    IQGPU_K_CASCADE = 6, IQGPU_K_COUNT = 8 };
 typedef struct {
     uint64_t launches[IQGPU_K_COUNT];
     double   ms[IQGPU_K_COUNT];
@@ -286,7 +287,7 @@ int    iqgpu_chain_set_profiling(iqgpu_chain *c, int enable);      /* brackets e
 int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronises, then reports and clears  */
 /* name of the front kernel the LAST process call launched ("k_front_mid<6,nco>", "k_front_mid<6,nonco>", "k_front_mid<8,nco>" (the
  * outputs per lane of the instantiation and whether it mixes), "k_front_s1", "k_front_fat", "k_front_s2", "k_cascade+k_front_s1",
- * "k_front", "k_front+k_interp"; "" before the first call): diagnostics, bench.py's roofline.kernel */
+ * "k_cascade2+k_front_s1", "k_front_p0", "k_front", "k_front+k_interp"; "" before the first call): diagnostics, bench.py's roofline.kernel */
 const char *iqgpu_chain_front_kernel(const iqgpu_chain *c);
 
 /* diagnostic hook: copies the chain's 64 KiB scratch (per-phase cycle counters in builds

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiqgpu.so")
-SOURCES = ["design.cpp", "abi.cpp", "plan.cpp", "process.cpp", "agc_host.cpp", "pipeline.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "topology.cpp", "kernels.hip", "front_wave.hip", "front_fat.hip", "front_mid.hip", "front_p0.hip", "front_s2.hip", "cascade_wave.hip", "fftconv.hip", "interp.hip", "agc.hip"]
+SOURCES = ["design.cpp", "abi.cpp", "plan.cpp", "process.cpp", "agc_host.cpp", "pipeline.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "topology.cpp", "kernels.hip", "front_wave.hip", "front_fat.hip", "front_mid.hip", "front_p0.hip", "front_s2.hip", "cascade_wave.hip", "cascade2.hip", "fftconv.hip", "interp.hip", "agc.hip"]
 HEADERS = ["design.hpp", "chain.hpp", "kernels.hpp", "dsp_device.hpp", "wave_common.hpp", "front_tiles.hpp", "cascade_tiles.hpp", "front_fat_common.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
 HARNESS_SRC = os.path.join(CSRC, "harness", "iqgpu_run.c")
 HARNESS_BIN = os.path.join(LIBDIR, "iqgpu_run")

@@ -1,0 +1,216 @@
+// cascade2.hip -- k_cascade2: k_cascade (cascade_wave.hip) for raw cu8 frames with TWO 512-frame tiles per trip of a streaming wave.
+//
+// k_cascade hands every stage one 512-frame tile per trip, so at K = 4 its late stages run half empty: stage 2 produces one output per
+// lane from 8-byte window reads, stage 3 keeps 32 lanes busy -- and an LDS instruction costs the pipe the same whatever the lanes do
+// with it (profiles/r05_pmc_summary.txt, config 4: SQ_LDS_IDX_ACTIVE 184 of the 218 CU-cycles a tile takes).  With 1024 frames per
+// trip every stage moves one step up the ladder of routines cascade_tiles.hpp already has:
+//
+//   stage 0   casc_stage_raw8  twice (the two halves of the trip's raw frames, 2 KiB of LDS behind 64 bytes of history)
+//   stage 1   casc_stage       (rows of four samples in two planes, four outputs per lane -- k_cascade's stage 0 on cf32 rows)
+//   stage 2   casc_stage_lin<., 2>   (two outputs per lane from 16-byte reads -- k_cascade's stage 1)
+//   stage 3   casc_stage_lin<., 1>   with all 64 lanes at work
+//
+// Same taps in the same order on the same samples as k_cascade: the bytes are equal (tests/test_gpu_parity.py).  The stages run skewed
+// by one trip each (one LDS round trip per trip), K more trips drain the pipe.  Edge waves run k_cascade's own tile routine on its
+// own layout inside the same slice.  A streaming run of an odd number of tiles starts one tile early (Call::plan_geometry leaves that
+// tile loadable: `lead`); nothing is stored for tiles in front of the run.
+#include "cascade_tiles.hpp"
+
+namespace iqgpu {
+
+constexpr int kCasc2MinRun = 16;       // tiles per streaming run from which the two-tile trips pay (shorter calls: latency counts, k_cascade)
+
+template <int KT> struct Casc2 {
+    static constexpr int M0 = 3, M1 = KT == 2 ? 5 : 3, M2 = KT == 3 ? 5 : 3, M3 = 5;     // liquid's 60 dB semi-lengths: 3 .. 3 5
+    static constexpr int H1 = casc_hist_rows(M1);
+    static constexpr int PS1 = plane_stride(H1 + 64 + 1);
+    static constexpr int RAW = kRawHist + 2048;                                         // 64 bytes of history, 1024 frames
+    static constexpr int ROWS = 4 * PS1;
+    static constexpr int E2 = ((casc_lin_hs(M2) + 128) * 8 + 15) & ~15, O2 = ((casc_lin_ho(M2) + 128) * 8 + 15) & ~15;
+    static constexpr int E3 = ((casc_lin_hs(M3) + 64) * 8 + 15) & ~15, O3 = ((casc_lin_ho(M3) + 64) * 8 + 15) & ~15;
+    static constexpr int BYTES = RAW + ROWS + (KT > 2 ? E2 + O2 : 0) + (KT > 3 ? E3 + O3 : 0);
+};
+
+int cascade2_wave_lds(int K)
+{
+    return K == 2 ? Casc2<2>::BYTES : K == 3 ? Casc2<3>::BYTES : K == 4 ? Casc2<4>::BYTES : 0;
+}
+
+// the chain shape: cu8 frames with nothing between the unpack and stage 0 (k_cascade's RAW0), two to four stages of liquid's lengths
+bool cascade2_shape(const FrontArgs &a)
+{
+    if (a.in_fmt != IQGPU_FMT_CU8 || a.gain != 1.0f || a.dc_enable || a.iq_enable || a.nco_mode != 0) return false;
+    if (a.dbg & (kDbgNoRaw0 | kDbgNoKT | kDbgNoCasc2)) return false;
+    if (a.casc_K < 2 || a.casc_K > 4) return false;
+    for (int k = 0; k < a.casc_K; ++k) if (a.m[k] != (k == a.casc_K - 1 ? 5 : 3)) return false;
+    return true;
+}
+
+// ... and the call: streaming runs long enough, the tile in front of the first run's warm-up loadable, the slice sized for both layouts
+bool cascade2_applies(const FrontArgs &a)
+{
+    if (!cascade2_shape(a) || a.w_n_stream <= 0 || a.w_run_q < kCasc2MinRun) return false;
+    if ((a.w_edge_ta - a.w_warm_tiles - 1) * (int64_t)kWTile - a.rem0 < 0) return false;
+    return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K);
+}
+
+template <int KT>
+__device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, const int lane, int64_t t_begin, const int64_t t_emit0, const int64_t t_end)
+{
+    using G = Casc2<KT>;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    char *RB = slice, *XE1 = RB + G::RAW, *XO1 = XE1 + 2 * G::PS1;
+    char *XE2 = XE1 + G::ROWS, *XO2 = XE2 + G::E2;
+    char *XE3 = XE2 + (G::E2 + G::O2), *XO3 = XE3 + G::E3;
+    constexpr int HS2 = casc_lin_hs(G::M2), HO2 = casc_lin_ho(G::M2), HS3 = casc_lin_hs(G::M3), HO3 = casc_lin_ho(G::M3);
+    auto ldg = [](const char *p) { return IQGPU_NT_CASC ? __builtin_nontemporal_load((const u4v *)p) : *(const u4v *)p; };
+
+    if ((t_end - t_begin) & 1) --t_begin;                  // whole trips up to the run's end
+    // lane l holds frames 8 l .. 8 l + 7 of each half of a trip
+    const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * 2 + 16 * lane;
+    u4v nA = ldg(src), nB = ldg(src + 1024);
+    const int64_t o_first = (t_emit0 * kWTile) >> KT;      // first sample of the last stage this run stores
+    const int woff1 = (G::H1 + (lane >> 1)) * 16 + (lane & 1) * G::PS1;       // the lane's write slot in stage 1's rows (plane lane & 1)
+    const int ls1 = lane < 8 * G::H1 ? lane : 8 * G::H1 - 1;
+    const int tail1 = (ls1 >= 4 * G::H1 ? G::PS1 - 16 * G::H1 : 0) + ls1 * 4;
+
+    for (int64_t T = t_begin; T < t_end + 2 * KT; T += 2) {
+        const u4v rA = nA, rB = nB;                        // the frames of trip T: to LDS at the end of this iteration
+        if (T + 2 < t_end) { src += 2048; nA = ldg(src); nB = ldg(src + 1024); }
+
+        // ------------------------------------------------------------ reads and FMAs: stage k works on trip T - 2 (k + 1)
+        __builtin_amdgcn_s_setprio(1);
+        CascWinRaw<G::M0> wA, wB;
+        casc_stage_raw8_load<G::M0>(RB, lane, wA);
+        casc_stage_raw8_load<G::M0>(RB + 1024, lane, wB);
+        const uint32_t hv = *(const uint32_t *)(RB + 2048 + (lane & (kRawHist / 4 - 1)) * 4);      // the trip's last 32 frames
+        CascWin0<G::M1> f1;
+        casc_stage_load<G::M1>(XE1, XO1, lane, f1);
+        const float se1 = *(const float *)(XE1 + 64 * 16 + tail1), so1 = *(const float *)(XO1 + 64 * 16 + tail1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        v2f y0a[4], y0b[4], y1[4], y2[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, y3[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+        float se2 = 0.f, so2 = 0.f, se3 = 0.f, so3 = 0.f;
+        casc_stage_raw8_fma<G::M0, true>(wA, a.casc_taps[0], y0a);
+        casc_stage_raw8_fma<G::M0, true>(wB, a.casc_taps[0], y0b);
+        CascWinLin<G::M2, 2> l2;
+        CascWinLin<G::M3, 1> l3;
+        if (KT > 2) {
+            casc_stage_lin_load<G::M2, 2>(XE2, XO2, lane, l2);
+            se2 = *(const float *)(XE2 + 128 * 8 + (lane < 2 * HS2 ? lane : 2 * HS2 - 1) * 4);
+            so2 = *(const float *)(XO2 + 128 * 8 + (lane < 2 * HO2 ? lane : 2 * HO2 - 1) * 4);
+        }
+        casc_stage_fma<G::M1>(f1, a.casc_taps[1], y1);
+        if (KT > 3) {
+            casc_stage_lin_load<G::M3, 1>(XE3, XO3, lane, l3);
+            se3 = *(const float *)(XE3 + 64 * 8 + (lane < 2 * HS3 ? lane : 2 * HS3 - 1) * 4);
+            so3 = *(const float *)(XO3 + 64 * 8 + (lane < 2 * HO3 ? lane : 2 * HO3 - 1) * 4);
+        }
+        if (KT > 2) casc_stage_lin_fma<G::M2, 2>(l2, a.casc_taps[2], y2);
+        if (KT > 3) casc_stage_lin_fma<G::M3, 1>(l3, a.casc_taps[3], y3);
+        __builtin_amdgcn_wave_barrier();
+
+        // ------------------------------------------------------------ the writes: histories slide, every stage hands its trip on
+        __builtin_amdgcn_s_setprio(1);
+        if (lane < kRawHist / 4) *(uint32_t *)(RB + lane * 4) = hv;
+        *(u4v *)__builtin_assume_aligned(RB + kRawHist + 16 * lane, 16) = rA;
+        *(u4v *)__builtin_assume_aligned(RB + kRawHist + 1024 + 16 * lane, 16) = rB;
+        {
+            const int tw = (lane >= 4 * G::H1 ? G::PS1 - 16 * G::H1 : 0) + lane * 4;
+            if (lane < 8 * G::H1) { *(float *)(XE1 + tw) = se1; *(float *)(XO1 + tw) = so1; }
+        }
+        st4a(XE1 + woff1, make_float4(y0a[0].x, y0a[0].y, y0a[2].x, y0a[2].y));
+        st4a(XO1 + woff1, make_float4(y0a[1].x, y0a[1].y, y0a[3].x, y0a[3].y));
+        st4a(XE1 + woff1 + 32 * 16, make_float4(y0b[0].x, y0b[0].y, y0b[2].x, y0b[2].y));
+        st4a(XO1 + woff1 + 32 * 16, make_float4(y0b[1].x, y0b[1].y, y0b[3].x, y0b[3].y));
+        const int64_t ob = ((T - 2 * KT) * kWTile) >> KT;  // first sample of the trip the last stage has just finished
+        if (KT == 2) {
+            const int64_t o = ob + 4 * lane;
+            if (o >= o_first) {
+                float4 *dst = (float4 *)(a.casc_out + o);
+                dst[0] = make_float4(y1[0].x, y1[0].y, y1[1].x, y1[1].y);
+                dst[1] = make_float4(y1[2].x, y1[2].y, y1[3].x, y1[3].y);
+            }
+        } else {
+            if (lane < 2 * HS2) *(float *)(XE2 + lane * 4) = se2;
+            if (lane < 2 * HO2) *(float *)(XO2 + lane * 4) = so2;
+            st4a(XE2 + (HS2 + 2 * lane) * 8, make_float4(y1[0].x, y1[0].y, y1[2].x, y1[2].y));
+            st4a(XO2 + (HO2 + 2 * lane) * 8, make_float4(y1[1].x, y1[1].y, y1[3].x, y1[3].y));
+            if (KT == 3) {
+                const int64_t o = ob + 2 * lane;
+                if (o >= o_first) *(float4 *)(a.casc_out + o) = make_float4(y2[0].x, y2[0].y, y2[1].x, y2[1].y);
+            } else {
+                if (lane < 2 * HS3) *(float *)(XE3 + lane * 4) = se3;
+                if (lane < 2 * HO3) *(float *)(XO3 + lane * 4) = so3;
+                *(float2 *)(XE3 + (HS3 + lane) * 8) = make_float2(y2[0].x, y2[0].y);
+                *(float2 *)(XO3 + (HO3 + lane) * 8) = make_float2(y2[1].x, y2[1].y);
+                const int64_t o = ob + lane;
+                if (o >= o_first) a.casc_out[o] = cf2{y3[0].x, y3[0].y};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade2(const FrontArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char *slice = (char *)smem + wave * a.casc_wave_lds;
+    for (int i = lane; i < a.casc_wave_lds / 16; i += 64) ((float4 *)slice)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t gw = (int64_t)blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (gw < a.w_n_edge) {
+        // k_cascade's edge runs on k_cascade's layout (no mixer in this shape: no phasor table)
+        CascLds w;
+        w.nco = nullptr;
+        char *p = slice;
+#pragma unroll
+        for (int k = 0; k < kCascMaxK; ++k) {
+            w.XE[k] = p; w.XO[k] = p;
+            if (k < KT) {
+                const int m = k == KT - 1 ? 5 : 3;
+                if (k == 0) w.XO[0] = p + 2 * plane_stride(casc_hist_rows(m) + 64 + 1);
+                else w.XO[k] = p + (((casc_lin_hs(m) + (256 >> k)) * 8 + 15) & ~15);
+                p += casc_stage_bytes(k, m);
+            }
+        }
+        int64_t t0, t1;
+        if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
+        else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
+        const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);
+        casc_tiles<2, true, false, KT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+    } else {
+        const int64_t r = gw - a.w_n_edge;
+        if (r >= a.w_n_stream) return;
+        const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
+        casc_trips<KT>(a, slice, lane, t0 - a.w_warm_tiles, t0, t1);
+    }
+}
+
+hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s)
+{
+    if (!cascade2_applies(a)) return hipErrorInvalidValue;
+    const int waves = cascade_waves(a);
+    const size_t lds = (size_t)waves * a.casc_wave_lds;
+    const int64_t n_items = a.w_n_edge + a.w_n_stream;
+    const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
+    if (grid == 0) return hipSuccess;
+#define IQGPU_LAUNCH_CASC2(KT)                                                                                         \
+    do {                                                                                                              \
+        static LdsAttrCache cache;                                                                                    \
+        { const hipError_t e = cache.ensure((const void *)k_cascade2<KT>, lds); if (e != hipSuccess) return e; }      \
+        hipLaunchKernelGGL((k_cascade2<KT>), dim3(grid), dim3(waves * 64), lds, s, a);                                \
+    } while (0)
+    if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2);
+    else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3);
+    else IQGPU_LAUNCH_CASC2(4);
+#undef IQGPU_LAUNCH_CASC2
+    return hipGetLastError();
+}
+
+} // namespace iqgpu

@@ -27,8 +27,13 @@ size_t cascade_wave_lds(const FrontArgs &a)
 {
     size_t b = 0;
     for (int k = 0; k < a.casc_K; ++k) b += (size_t)casc_stage_bytes(k, a.m[k]);
+    // (k_cascade2's streaming waves lay the same slice out for two tiles per trip: cascade2.hip)
+    if (cascade2_shape(a) && (size_t)cascade2_wave_lds(a.casc_K) > b) b = (size_t)cascade2_wave_lds(a.casc_K);
     return b;
 }
+
+// the phasor table in front of the waves' slices: only chains with a mixer in front of stage 0 keep one
+static inline int casc_nco_bytes(const FrontArgs &a) { return a.nco_mode != 0 ? 1024 * 8 : 0; }
 
 template <int BPS, bool RAW0 = false, int KT = 0>
 __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs a)
@@ -39,9 +44,9 @@ __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade(const FrontArgs 
     cf2 *s_nco = (cf2 *)smem;
     CascLds w;
     w.nco = s_nco;
-    if (((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
+    if (a.nco_mode != 0 && ((unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_nco & 8191u) != 0u) __builtin_trap();   // nco_phasor2 ORs the index into the base
     {
-        char *p = (char *)smem + 1024 * 8 + wave * a.casc_wave_lds;
+        char *p = (char *)smem + (a.nco_mode != 0 ? 1024 * 8 : 0) + wave * a.casc_wave_lds;
         char *p0 = p;
 #pragma unroll
         for (int k = 0; k < kCascMaxK; ++k) {
@@ -99,7 +104,7 @@ bool cascade_supported(const int *m_run_order, int S)
 // a single stage does not (config 3, K = 1: 0.223 against 0.221 ms) and keeps 12.
 int cascade_waves(const FrontArgs &a)
 {
-    int w = (int)((160 * 1024 - 1024 * 8) / (a.casc_wave_lds > 0 ? a.casc_wave_lds : 1));
+    int w = (int)((160 * 1024 - casc_nco_bytes(a)) / (a.casc_wave_lds > 0 ? a.casc_wave_lds : 1));
     w &= ~3;
     const int cap = a.casc_K >= 2 ? kCascMaxWaves : kWaves;
     return w > cap ? cap : (w < 4 ? 4 : w);
@@ -107,8 +112,9 @@ int cascade_waves(const FrontArgs &a)
 
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s)
 {
+    if (cascade2_applies(a)) return launch_cascade2(a, s);
     const int waves = cascade_waves(a);
-    const size_t lds = 1024 * 8 + (size_t)waves * a.casc_wave_lds;
+    const size_t lds = (size_t)casc_nco_bytes(a) + (size_t)waves * a.casc_wave_lds;
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;

@@ -64,6 +64,7 @@ struct cd2 { double x, y; };
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
 enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u,
                   kDbgNoS2 = 512u,         // IQGPU_NO_S2=1: two-stage chains keep k_cascade + k_front_s1 instead of the fused k_front_s2
+                  kDbgNoCasc2 = 4096u,     // IQGPU_NO_CASC2=1: raw cu8 cascades keep k_cascade's one tile per trip instead of k_cascade2's two
                   kDbgNoP0 = 2048u,        // IQGPU_NO_P0=1: chains without a half-band stage keep k_front_s1<S0> instead of k_front_p0
                   kDbgNoFusedMove = 1024u }; // IQGPU_NO_FUSED_MOVE=1: the filter's history moves by a copy kernel, not inside the filter kernel
 
@@ -220,6 +221,12 @@ bool cascade_supported(const int *m_run_order, int S);
 size_t cascade_wave_lds(const FrontArgs &a);
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
 int cascade_waves(const FrontArgs &a);    // needs casc_wave_lds
+// ... with two tiles per trip of a streaming wave for raw cu8 frames (cascade2.hip): the chain shape (needs in_fmt, gain, the
+// pointwise switches, casc_K, m[]); the call (needs the run geometry and casc_wave_lds too); bytes of a wave's slice
+bool cascade2_shape(const FrontArgs &a);
+bool cascade2_applies(const FrontArgs &a);
+int cascade2_wave_lds(int K);
+hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();
 hipError_t launch_front_s1(const FrontArgs &a, hipStream_t s);

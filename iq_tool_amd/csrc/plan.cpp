@@ -119,14 +119,14 @@ void Call::plan_geometry()
         cplan.frames_in = (int64_t)frames_in; cplan.rem0 = rem_k; cplan.hist_cap = c->hist_cap;
         cplan.in_fmt = c->desc.in_format; cplan.out_fmt = (casc || filt) ? (int)IQGPU_FMT_CF32 : fin_fmt;
         cplan.raw_aligned = raw_aligned();
-        if (casc) {
-            cplan.casc_K = casc_K;
-            for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
-            cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);
-        }
         cplan.agc_fused = front_fused() ? 1 : 0; cplan.agc_shift = c->S; cplan.agc_chunk_frames = c->agc_chunk;
         cplan.S = c->S; cplan.gain = c->desc.gain; cplan.iq_enable = c->desc.iq_correct_enable ? 1 : 0;
         cplan.dc_enable = c->dc ? 1 : 0; cplan.nco_mode = c->nco_mode;
+        if (casc) {
+            cplan.casc_K = casc_K;
+            for (int k = 0; k < casc_K; ++k) cplan.m[k] = c->rp.stages[(size_t)k].m;
+            cplan.casc_wave_lds = (int)cascade_wave_lds(cplan);      // (reads the pointwise switches above: cascade2_shape)
+        }
         cplan.pnco_mode = (!filt && !c->late) ? c->pnco_mode : 0;
         cplan.step = c->rp.step;
         // the preset shape on a call long enough to give every one of the 8 x CUs fat waves a run of tiles: k_front_fat
@@ -156,7 +156,9 @@ void Call::plan_geometry()
         if (ftpw > 1 && (fat || mid)) { ftpw = ftpw * kWTile / wtile; if (ftpw < 1) ftpw = 1; }
         plan_front_s1(cplan, wave_slots(casc ? cascade_waves(cplan) : fat ? front_fat_waves() : mid ? front_mid_waves()
             : front_s1_waves(cplan)),
-                      ftpw, warm, mid_align, wtile, mid_align, mid ? kMidLead : 0);
+                      ftpw, warm, mid_align, wtile, mid_align,
+                      // (k_cascade2: a streaming run of an odd number of tiles starts one tile early -- that tile has to be loadable)
+                      mid ? kMidLead : (casc && cascade2_shape(cplan)) ? kWTile : 0);
         // k_front_mid: the three waves of a SIMD get runs in proportion to the speed their age buys them (kernels.hpp, weight_runs)
         if (mid && ftpw == 0 && cplan.w_n_edge <= front_mid_max_edge_waves() && c->run_wt[0] > 0) weight_runs(cplan, front_mid_waves(),
             c->run_wt);

@@ -140,6 +140,7 @@ int Call::stage_front()
     else              { a.out_fmt = fin_fmt; a.out = fin_out; }
     a.sink = c->d_sink;
     char mid_name[48] = "k_front_mid";
+    bool casc2 = false;
 
     if (casc) {
         // ---- stages 0 .. S-2: raw -> mid (cf32 at rate / 2^K) ----
@@ -160,6 +161,7 @@ int Call::stage_front()
         if (s2) a1.w_total_tiles = s2_in_tiles;          // (the fused kernel is planned in the last stage's tiles: cplan is a2's)
         else {
             copy_plan(a1);
+            casc2 = cascade2_applies(a1);                // (launch_cascade's own test: raw cu8 frames, long runs -- cascade2.hip)
             KernelTimer kt(c, IQGPU_K_CASCADE); HIP_TRY(launch_cascade(a1, c->stream));
         }
         // ---- last stage + polyphase: a one-stage chain on the intermediate stream ----
@@ -228,7 +230,7 @@ int Call::stage_front()
     }
     if (c->decim) c->hist_cur ^= 1;
     snprintf(c->front_kernel, sizeof(c->front_kernel), "%s",
-             (casc && s2) ? "k_front_s2" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? mid_name : p0 ? "k_front_p0"
+             (casc && s2) ? "k_front_s2" : casc2 ? "k_cascade2+k_front_s1" : casc ? "k_cascade+k_front_s1" : fat ? "k_front_fat" : mid ? mid_name : p0 ? "k_front_p0"
              : fast_s1 ? "k_front_s1" : c->late ? "k_front+k_interp" : "k_front");
     return IQGPU_OK;
 }

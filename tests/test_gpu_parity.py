@@ -1160,6 +1160,54 @@ def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatc
     int_close(fast[:want.size], want, min_same=0.998)
 
 
+@pytest.mark.parametrize("in_rate,out_rate,out_format,block", [
+    (20e6, 1488375.0, "cu8", 36 * 8192),             # K = 2 (the runs come out 35 or 36 tiles long: odd ones start a tile early)
+    (20e6, 744187.5, "cs16", 40 * 8192),            # K = 3
+    (61.44e6, 1488375.0, "cu8", 36 * 8192),          # K = 4: BASELINE configs[3] in front of its filter
+    (61.44e6, 1488375.0, "cf32", 0),                # ... one run per resident wave, chosen by the size rule alone
+])
+def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_rate, out_rate, out_format, block):
+    """Round 5: k_cascade2 (cascade2.hip: raw cu8 frames, 1024 frames per trip of a streaming wave -- stage 0 twice, then the rows
+    routine, two outputs per lane, all 64 lanes in the last stage) against k_cascade (IQGPU_NO_CASC2=1: 512 frames per trip): the
+    same taps in the same order on the same samples, so the BYTES must be equal -- whole calls, a split that leaves the stream eight
+    frames into a group (the second call streams from there), one that leaves it off a 16-byte boundary (all edges), a reset --
+    then the oracle."""
+    n = (1 << 22) + 16384 * 3 + 8 if block else (1 << 26) + 16384 * 33 + 24
+    raw = synth.raw_stream(n, in_rate, 77, "cu8")
+    per = raw.size // n
+    kw = dict(in_format="cu8", out_format=out_format, input_rate_hz=in_rate, target_rate_hz=out_rate, block_samples=block)
+    h = n // 2 // 16384 * 16384
+    splits = [[n], [h + 8, n - h - 8], [h + 3, 5, n - h - 8]] if block else [[n]]
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos, names = [], 0, []
+        for k in split:
+            outs.append(ch.process(raw[per * pos:per * (pos + k)])); pos += k
+            names.append(ch.front_kernel())
+        ch.reset()
+        outs.append(ch.process(raw[:per * (1 << 21)]))
+        names.append(ch.front_kernel())
+        return np.concatenate(outs), names
+
+    monkeypatch.setenv("IQGPU_NO_CASC2", "1")
+    refs = [run(sp) for sp in splits]
+    assert all(nm == "k_cascade+k_front_s1" for r in refs for nm in r[1])
+    monkeypatch.delenv("IQGPU_NO_CASC2")
+    for sp, (ref, _) in zip(splits, refs):
+        got, names = run(sp)
+        assert names[0] == "k_cascade2+k_front_s1" and (len(sp) != 2 or names[1] == "k_cascade2+k_front_s1"), names
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (sp, names, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+    m = min(n, 1 << 22)
+    want = run_oracle(oracle, raw[:per * m], **kw)
+    got = run_gpu(gpu, raw[:per * m], **kw)
+    if out_format == "cf32":
+        assert np.abs(cf(got) - cf(want)).max() <= 2 * TOL
+    else:
+        int_close(got, want, min_same=0.998)
+
+
 @pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,extra", [
     ("cs16", 10e6, 2.4e6, "cs16", dict(dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005)),   # BASELINE configs[2] in front of its filter
     ("cs16", 10e6, 2.4e6, "cf32", dict(shift_hz=250e3)),                              # a mixer in front, cf32 out
