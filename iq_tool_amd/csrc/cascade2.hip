@@ -1,11 +1,13 @@
-// cascade2.hip -- k_cascade2: k_cascade (cascade_wave.hip) for raw cu8 frames with TWO 512-frame tiles per trip of a streaming wave.
+// cascade2.hip -- k_cascade2: k_cascade (cascade_wave.hip) for raw cu8 / cs16 frames with TWO 512-frame tiles per trip of a streaming wave.
 //
 // k_cascade hands every stage one 512-frame tile per trip, so at K = 4 its late stages run half empty: stage 2 produces one output per
 // lane from 8-byte window reads, stage 3 keeps 32 lanes busy -- and an LDS instruction costs the pipe the same whatever the lanes do
 // with it (profiles/r05_pmc_summary.txt, config 4: SQ_LDS_IDX_ACTIVE 184 of the 218 CU-cycles a tile takes).  With 1024 frames per
 // trip every stage moves one step up the ladder of routines cascade_tiles.hpp already has:
 //
-//   stage 0   casc_stage_raw8  twice (the two halves of the trip's raw frames, 2 KiB of LDS behind 64 bytes of history)
+//   stage 0   casc_stage_raw8 / casc_stage_raw16  twice (the two halves of the trip's raw frames: 2 / 4 KiB of LDS behind 64 / 128
+//             bytes of history; 16-bit frames are unpacked WITHOUT their 2^-15, which the four outputs take at the end -- a power
+//             of two commutes with every rounding on the way, so the bits are those of the scaled samples)
 //   stage 1   casc_stage       (rows of four samples in two planes, four outputs per lane -- k_cascade's stage 0 on cf32 rows)
 //   stage 2   casc_stage_lin<., 2>   (two outputs per lane from 16-byte reads -- k_cascade's stage 1)
 //   stage 3   casc_stage_lin<., 1>   with all 64 lanes at work
@@ -20,26 +22,81 @@ namespace iqgpu {
 
 constexpr int kCasc2MinRun = 16;       // tiles per streaming run from which the two-tile trips pay (shorter calls: latency counts, k_cascade)
 
-template <int KT> struct Casc2 {
+// ---- stage 0 on raw 16-bit frames (cs16, sc16q11): 4 bytes a frame, frame f of the trip at byte kRawHist16 + 4 f.  A lane's four
+// outputs need its own eight frames (two 16-byte blocks) and the 4M - 2 in front of them (M blocks): even sample n = dword 2n,
+// odd sample n = dword 2n + 1 of the lane's frames.
+constexpr int kRawHist16 = 128;
+template <int M> struct CascWinRaw16 { uint32_t W[4 * (M + 2)]; };
+template <int M>
+__device__ __forceinline__ void casc_stage_raw16_load(const char *RB, int lane, CascWinRaw16<M> &wn)
+{
+    const char *wb = RB + kRawHist16 + lane * 32 - 16 * M;
+#pragma unroll
+    for (int b = 0; b < M + 2; ++b) {
+        const uint4 v = *(const uint4 *)__builtin_assume_aligned(wb + b * 16, 16);
+        wn.W[4 * b + 0] = v.x; wn.W[4 * b + 1] = v.y; wn.W[4 * b + 2] = v.z; wn.W[4 * b + 3] = v.w;
+    }
+}
+template <int M>
+__device__ __forceinline__ void casc_stage_raw16_fma(const CascWinRaw16<M> &wn, const float *taps_sgpr, const float norm, v2f y[4])
+{
+    auto unpack = [&](uint32_t w) { return v2f{(float)(short)(w & 0xffffu), (float)(short)(w >> 16)}; };   // (x 2^15 or 2^11)
+    constexpr int Z = 4 * M;                                // dword index of the lane's first frame
+#pragma unroll
+    for (int i = 0; i < 4 * (M + 2); ++i) keep(wn.W[i]);
+    v2f E[2 * M + 3];                                       // E[k] = even sample n = k - (2M - 1)
+#pragma unroll
+    for (int k = 0; k < 2 * M + 3; ++k) E[k] = unpack(wn.W[Z + 2 * (k - (2 * M - 1))]);
+    const v2f *hbp = (const v2f *)taps_sgpr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v2f o = unpack(wn.W[Z + 2 * (i - M) + 1]);    // O[j - M], j = 4 lane + i
+        y[i] = v2f{0.5f * o.x, 0.5f * o.y};
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < M; ++q2) {
+        const v2f tp = hbp[q2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_lo_s(y[i], tp, E[2 * M - 1 + i - 2 * q2]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk_fma_hi_s(y[i], tp, E[2 * M - 1 + i - 2 * q2 - 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = v2f{y[i].x * norm, y[i].y * norm};
+}
+
+// BPF: bytes per frame, 2 (cu8) or 4 (cs16, sc16q11)
+template <int KT, int BPF> struct Casc2 {
     static constexpr int M0 = 3, M1 = KT == 2 ? 5 : 3, M2 = KT == 3 ? 5 : 3, M3 = 5;     // liquid's 60 dB semi-lengths: 3 .. 3 5
     static constexpr int H1 = casc_hist_rows(M1);
     static constexpr int PS1 = plane_stride(H1 + 64 + 1);
-    static constexpr int RAW = kRawHist + 2048;                                         // 64 bytes of history, 1024 frames
+    static constexpr int HIST = BPF == 2 ? kRawHist : kRawHist16;
+    static constexpr int HALF = 512 * BPF;                                              // bytes of one 512-frame half
+    static constexpr int RAW = HIST + 2 * HALF;
     static constexpr int ROWS = 4 * PS1;
     static constexpr int E2 = ((casc_lin_hs(M2) + 128) * 8 + 15) & ~15, O2 = ((casc_lin_ho(M2) + 128) * 8 + 15) & ~15;
     static constexpr int E3 = ((casc_lin_hs(M3) + 64) * 8 + 15) & ~15, O3 = ((casc_lin_ho(M3) + 64) * 8 + 15) & ~15;
-    static constexpr int BYTES = RAW + ROWS + (KT > 2 ? E2 + O2 : 0) + (KT > 3 ? E3 + O3 : 0);
+    static constexpr int USED = RAW + ROWS + (KT > 2 ? E2 + O2 : 0) + (KT > 3 ? E3 + O3 : 0);
+    // (16-bit frames: 20-dword windows twice and eight prefetched dwords more -- 134 registers, three waves per SIMD; the slice is
+    //  padded to where cascade_waves() stops at twelve)
+    static constexpr int BYTES = (BPF == 4 && USED < 10256) ? 10256 : USED;
+    static constexpr int WAVES = (160 * 1024 / BYTES) >= 16 ? 16 : 12;                  // what cascade_waves() makes of BYTES
 };
 
-int cascade2_wave_lds(int K)
+static inline int casc2_bpf(int fmt) { return fmt == IQGPU_FMT_CU8 ? 2 : (fmt == IQGPU_FMT_CS16 || fmt == IQGPU_FMT_SC16Q11) ? 4 : 0; }
+
+int cascade2_wave_lds(int K, int in_fmt)
 {
-    return K == 2 ? Casc2<2>::BYTES : K == 3 ? Casc2<3>::BYTES : K == 4 ? Casc2<4>::BYTES : 0;
+    const int b = casc2_bpf(in_fmt);
+    if (b == 2) return K == 2 ? Casc2<2, 2>::BYTES : K == 3 ? Casc2<3, 2>::BYTES : K == 4 ? Casc2<4, 2>::BYTES : 0;
+    if (b == 4) return K == 2 ? Casc2<2, 4>::BYTES : K == 3 ? Casc2<3, 4>::BYTES : K == 4 ? Casc2<4, 4>::BYTES : 0;
+    return 0;
 }
 
-// the chain shape: cu8 frames with nothing between the unpack and stage 0 (k_cascade's RAW0), two to four stages of liquid's lengths
+// the chain shape: cu8 / cs16 / sc16q11 frames with nothing between the unpack and stage 0, two to four stages of liquid's lengths
 bool cascade2_shape(const FrontArgs &a)
 {
-    if (a.in_fmt != IQGPU_FMT_CU8 || a.gain != 1.0f || a.dc_enable || a.iq_enable || a.nco_mode != 0) return false;
+    if (casc2_bpf(a.in_fmt) == 0 || a.gain != 1.0f || a.dc_enable || a.iq_enable || a.nco_mode != 0) return false;
     if (a.dbg & (kDbgNoRaw0 | kDbgNoKT | kDbgNoCasc2)) return false;
     if (a.casc_K < 2 || a.casc_K > 4) return false;
     for (int k = 0; k < a.casc_K; ++k) if (a.m[k] != (k == a.casc_K - 1 ? 5 : 3)) return false;
@@ -51,13 +108,13 @@ bool cascade2_applies(const FrontArgs &a)
 {
     if (!cascade2_shape(a) || a.w_n_stream <= 0 || a.w_run_q < kCasc2MinRun) return false;
     if ((a.w_edge_ta - a.w_warm_tiles - 1) * (int64_t)kWTile - a.rem0 < 0) return false;
-    return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K);
+    return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K, a.in_fmt);
 }
 
-template <int KT>
+template <int KT, int BPF>
 __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, const int lane, int64_t t_begin, const int64_t t_emit0, const int64_t t_end)
 {
-    using G = Casc2<KT>;
+    using G = Casc2<KT, BPF>;
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     char *RB = slice, *XE1 = RB + G::RAW, *XO1 = XE1 + 2 * G::PS1;
     char *XE2 = XE1 + G::ROWS, *XO2 = XE2 + G::E2;
@@ -66,24 +123,35 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
     auto ldg = [](const char *p) { return IQGPU_NT_CASC ? __builtin_nontemporal_load((const u4v *)p) : *(const u4v *)p; };
 
     if ((t_end - t_begin) & 1) --t_begin;                  // whole trips up to the run's end
-    // lane l holds frames 8 l .. 8 l + 7 of each half of a trip
-    const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * 2 + 16 * lane;
-    u4v nA = ldg(src), nB = ldg(src + 1024);
+    // lane l holds frames 8 l .. 8 l + 7 of each half of a trip (16 or 32 bytes)
+    const char *src = (const char *)a.raw + (t_begin * kWTile - a.rem0) * BPF + 8 * BPF * lane;
+    u4v nA = ldg(src), nB = ldg(src + G::HALF), nA2 = nA, nB2 = nB;
+    if (BPF == 4) { nA2 = ldg(src + 16); nB2 = ldg(src + G::HALF + 16); }
+    const float norm = a.in_fmt == IQGPU_FMT_SC16Q11 ? 1.0f / 2048.0f : 1.0f / 32768.0f;
     const int64_t o_first = (t_emit0 * kWTile) >> KT;      // first sample of the last stage this run stores
     const int woff1 = (G::H1 + (lane >> 1)) * 16 + (lane & 1) * G::PS1;       // the lane's write slot in stage 1's rows (plane lane & 1)
     const int ls1 = lane < 8 * G::H1 ? lane : 8 * G::H1 - 1;
     const int tail1 = (ls1 >= 4 * G::H1 ? G::PS1 - 16 * G::H1 : 0) + ls1 * 4;
 
     for (int64_t T = t_begin; T < t_end + 2 * KT; T += 2) {
-        const u4v rA = nA, rB = nB;                        // the frames of trip T: to LDS at the end of this iteration
-        if (T + 2 < t_end) { src += 2048; nA = ldg(src); nB = ldg(src + 1024); }
+        const u4v rA = nA, rB = nB, rA2 = nA2, rB2 = nB2;  // the frames of trip T: to LDS at the end of this iteration
+        if (T + 2 < t_end) {
+            src += 2 * G::HALF; nA = ldg(src); nB = ldg(src + G::HALF);
+            if (BPF == 4) { nA2 = ldg(src + 16); nB2 = ldg(src + G::HALF + 16); }
+        }
 
         // ------------------------------------------------------------ reads and FMAs: stage k works on trip T - 2 (k + 1)
         __builtin_amdgcn_s_setprio(1);
         CascWinRaw<G::M0> wA, wB;
-        casc_stage_raw8_load<G::M0>(RB, lane, wA);
-        casc_stage_raw8_load<G::M0>(RB + 1024, lane, wB);
-        const uint32_t hv = *(const uint32_t *)(RB + 2048 + (lane & (kRawHist / 4 - 1)) * 4);      // the trip's last 32 frames
+        CascWinRaw16<G::M0> vA, vB;
+        if (BPF == 2) {
+            casc_stage_raw8_load<G::M0>(RB, lane, wA);
+            casc_stage_raw8_load<G::M0>(RB + G::HALF, lane, wB);
+        } else {
+            casc_stage_raw16_load<G::M0>(RB, lane, vA);
+            casc_stage_raw16_load<G::M0>(RB + G::HALF, lane, vB);
+        }
+        const uint32_t hv = *(const uint32_t *)(RB + 2 * G::HALF + (lane & (G::HIST / 4 - 1)) * 4);      // the trip's last 32 frames
         CascWin0<G::M1> f1;
         casc_stage_load<G::M1>(XE1, XO1, lane, f1);
         const float se1 = *(const float *)(XE1 + 64 * 16 + tail1), so1 = *(const float *)(XO1 + 64 * 16 + tail1);
@@ -91,8 +159,13 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
         __builtin_amdgcn_s_setprio(0);
         v2f y0a[4], y0b[4], y1[4], y2[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, y3[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
         float se2 = 0.f, so2 = 0.f, se3 = 0.f, so3 = 0.f;
-        casc_stage_raw8_fma<G::M0, true>(wA, a.casc_taps[0], y0a);
-        casc_stage_raw8_fma<G::M0, true>(wB, a.casc_taps[0], y0b);
+        if (BPF == 2) {
+            casc_stage_raw8_fma<G::M0, true>(wA, a.casc_taps[0], y0a);
+            casc_stage_raw8_fma<G::M0, true>(wB, a.casc_taps[0], y0b);
+        } else {
+            casc_stage_raw16_fma<G::M0>(vA, a.casc_taps[0], norm, y0a);
+            casc_stage_raw16_fma<G::M0>(vB, a.casc_taps[0], norm, y0b);
+        }
         CascWinLin<G::M2, 2> l2;
         CascWinLin<G::M3, 1> l3;
         if (KT > 2) {
@@ -112,9 +185,13 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
 
         // ------------------------------------------------------------ the writes: histories slide, every stage hands its trip on
         __builtin_amdgcn_s_setprio(1);
-        if (lane < kRawHist / 4) *(uint32_t *)(RB + lane * 4) = hv;
-        *(u4v *)__builtin_assume_aligned(RB + kRawHist + 16 * lane, 16) = rA;
-        *(u4v *)__builtin_assume_aligned(RB + kRawHist + 1024 + 16 * lane, 16) = rB;
+        if (lane < G::HIST / 4) *(uint32_t *)(RB + lane * 4) = hv;
+        *(u4v *)__builtin_assume_aligned(RB + G::HIST + 8 * BPF * lane, 16) = rA;
+        *(u4v *)__builtin_assume_aligned(RB + G::HIST + G::HALF + 8 * BPF * lane, 16) = rB;
+        if (BPF == 4) {
+            *(u4v *)__builtin_assume_aligned(RB + G::HIST + 32 * lane + 16, 16) = rA2;
+            *(u4v *)__builtin_assume_aligned(RB + G::HIST + G::HALF + 32 * lane + 16, 16) = rB2;
+        }
         {
             const int tw = (lane >= 4 * G::H1 ? G::PS1 - 16 * G::H1 : 0) + lane * 4;
             if (lane < 8 * G::H1) { *(float *)(XE1 + tw) = se1; *(float *)(XO1 + tw) = so1; }
@@ -153,8 +230,8 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade2(const FrontArgs a)
+template <int KT, int BPF>
+__global__ __launch_bounds__((Casc2<KT, BPF>::WAVES * 64)) void k_cascade2(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -183,12 +260,12 @@ __global__ __launch_bounds__(kCascMaxWaves * 64) void k_cascade2(const FrontArgs
         if (gw < a.w_n_edge1) { t0 = gw * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_edge_ta) t1 = a.w_edge_ta; }
         else { t0 = a.w_edge_tb + (gw - a.w_n_edge1) * a.w_edge_tpw; t1 = t0 + a.w_edge_tpw; if (t1 > a.w_total_tiles) t1 = a.w_total_tiles; }
         const int seg = (gw < a.w_n_edge1) ? (int)gw : (int)(gw + a.w_n_stream);
-        casc_tiles<2, true, false, KT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
+        casc_tiles<BPF, true, false, KT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, seg);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
-        casc_trips<KT>(a, slice, lane, t0 - a.w_warm_tiles, t0, t1);
+        casc_trips<KT, BPF>(a, slice, lane, t0 - a.w_warm_tiles, t0, t1);
     }
 }
 
@@ -200,15 +277,22 @@ hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s)
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_CASC2(KT)                                                                                         \
+#define IQGPU_LAUNCH_CASC2(KT, BPF)                                                                                    \
     do {                                                                                                              \
         static LdsAttrCache cache;                                                                                    \
-        { const hipError_t e = cache.ensure((const void *)k_cascade2<KT>, lds); if (e != hipSuccess) return e; }      \
-        hipLaunchKernelGGL((k_cascade2<KT>), dim3(grid), dim3(waves * 64), lds, s, a);                                \
+        if (waves > Casc2<KT, BPF>::WAVES) return hipErrorInvalidValue;                                               \
+        { const hipError_t e = cache.ensure((const void *)k_cascade2<KT, BPF>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_cascade2<KT, BPF>), dim3(grid), dim3(waves * 64), lds, s, a);                           \
     } while (0)
-    if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2);
-    else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3);
-    else IQGPU_LAUNCH_CASC2(4);
+    if (casc2_bpf(a.in_fmt) == 2) {
+        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 2);
+        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 2);
+        else IQGPU_LAUNCH_CASC2(4, 2);
+    } else {
+        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 4);
+        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 4);
+        else IQGPU_LAUNCH_CASC2(4, 4);
+    }
 #undef IQGPU_LAUNCH_CASC2
     return hipGetLastError();
 }

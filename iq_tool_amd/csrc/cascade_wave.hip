@@ -23,12 +23,12 @@
 
 namespace iqgpu {
 
-size_t cascade_wave_lds(const FrontArgs &a)
+size_t cascade_wave_lds(const FrontArgs &a, bool two_tile_trips)
 {
     size_t b = 0;
     for (int k = 0; k < a.casc_K; ++k) b += (size_t)casc_stage_bytes(k, a.m[k]);
     // (k_cascade2's streaming waves lay the same slice out for two tiles per trip: cascade2.hip)
-    if (cascade2_shape(a) && (size_t)cascade2_wave_lds(a.casc_K) > b) b = (size_t)cascade2_wave_lds(a.casc_K);
+    if (two_tile_trips && cascade2_shape(a) && (size_t)cascade2_wave_lds(a.casc_K, a.in_fmt) > b) b = (size_t)cascade2_wave_lds(a.casc_K, a.in_fmt);
     return b;
 }
 

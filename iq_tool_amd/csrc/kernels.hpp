@@ -218,14 +218,14 @@ hipError_t launch_front(const FrontArgs &a, int n_blocks, hipStream_t s);
 // leading stages of a multi-stage decimation as a wave-autonomous kernel (cascade_wave.hip)
 constexpr int kCascMaxK = 4;
 bool cascade_supported(const int *m_run_order, int S);
-size_t cascade_wave_lds(const FrontArgs &a);
+size_t cascade_wave_lds(const FrontArgs &a, bool two_tile_trips = true);   // (false: k_cascade's own layout only)
 hipError_t launch_cascade(const FrontArgs &a, hipStream_t s);
 int cascade_waves(const FrontArgs &a);    // needs casc_wave_lds
 // ... with two tiles per trip of a streaming wave for raw cu8 frames (cascade2.hip): the chain shape (needs in_fmt, gain, the
 // pointwise switches, casc_K, m[]); the call (needs the run geometry and casc_wave_lds too); bytes of a wave's slice
 bool cascade2_shape(const FrontArgs &a);
 bool cascade2_applies(const FrontArgs &a);
-int cascade2_wave_lds(int K);
+int cascade2_wave_lds(int K, int in_fmt);
 hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)
 size_t front_s1_lds_bytes();

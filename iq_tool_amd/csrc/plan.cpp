@@ -159,6 +159,12 @@ void Call::plan_geometry()
                       ftpw, warm, mid_align, wtile, mid_align,
                       // (k_cascade2: a streaming run of an odd number of tiles starts one tile early -- that tile has to be loadable)
                       mid ? kMidLead : (casc && cascade2_shape(cplan)) ? kWTile : 0);
+        // (a raw cascade whose call turns out too short for k_cascade2's two-tile trips: k_cascade's own slice -- more waves per CU -- and
+        //  no lead)
+        if (casc && cascade2_shape(cplan) && !cascade2_applies(cplan)) {
+            cplan.casc_wave_lds = (int)cascade_wave_lds(cplan, false);
+            plan_front_s1(cplan, wave_slots(cascade_waves(cplan)), ftpw, warm, mid_align, wtile, mid_align, 0);
+        }
         // k_front_mid: the three waves of a SIMD get runs in proportion to the speed their age buys them (kernels.hpp, weight_runs)
         if (mid && ftpw == 0 && cplan.w_n_edge <= front_mid_max_edge_waves() && c->run_wt[0] > 0) weight_runs(cplan, front_mid_waves(),
             c->run_wt);

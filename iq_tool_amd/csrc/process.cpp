@@ -156,7 +156,7 @@ int Call::stage_front()
             for (size_t q = 0; q < 12; ++q) a1.casc_taps[k][q] = q < br.size() ? 0.5f * br[q] : 0.0f;
         }
         a1.casc_out = (cf2 *)c->mid.p; a1.casc_n_out = n_mid;
-        a1.casc_wave_lds = (int)cascade_wave_lds(a1);
+        a1.casc_wave_lds = s2 ? (int)cascade_wave_lds(a1) : cplan.casc_wave_lds;      // (the plan's: sized for k_cascade2 where the call takes it)
         a1.out_fmt = IQGPU_FMT_CF32; a1.pnco_mode = 0;
         if (s2) a1.w_total_tiles = s2_in_tiles;          // (the fused kernel is planned in the last stage's tiles: cplan is a2's)
         else {

@@ -1160,22 +1160,26 @@ def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatc
     int_close(fast[:want.size], want, min_same=0.998)
 
 
-@pytest.mark.parametrize("in_rate,out_rate,out_format,block", [
-    (20e6, 1488375.0, "cu8", 36 * 8192),             # K = 2 (the runs come out 35 or 36 tiles long: odd ones start a tile early)
-    (20e6, 744187.5, "cs16", 40 * 8192),            # K = 3
-    (61.44e6, 1488375.0, "cu8", 36 * 8192),          # K = 4: BASELINE configs[3] in front of its filter
-    (61.44e6, 1488375.0, "cf32", 0),                # ... one run per resident wave, chosen by the size rule alone
+@pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,block", [
+    ("cu8", 20e6, 1488375.0, "cu8", 36 * 8192),     # K = 2 (the runs come out 35 or 36 tiles long: odd ones start a tile early)
+    ("cu8", 20e6, 744187.5, "cs16", 40 * 8192),     # K = 3
+    ("cu8", 61.44e6, 1488375.0, "cu8", 36 * 8192),  # K = 4: BASELINE configs[3] in front of its filter
+    ("cu8", 61.44e6, 1488375.0, "cf32", 0),         # ... one run per resident wave, chosen by the size rule alone
+    ("cs16", 2.4e6, 46511.71875, "cs16", 36 * 8192),  # 16-bit frames, K = 4: the cs16-am-nrsc5 preset's resampler
+    ("cs16", 20e6, 1488375.0, "cs16", 40 * 8192),   # K = 2
+    ("sc16q11", 20e6, 744187.5, "cs16", 36 * 8192),   # K = 3, the other 16-bit scale
+    ("cs16", 2.4e6, 46511.71875, "cf32", 0),
 ])
-def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_rate, out_rate, out_format, block):
-    """Round 5: k_cascade2 (cascade2.hip: raw cu8 frames, 1024 frames per trip of a streaming wave -- stage 0 twice, then the rows
+def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_format, in_rate, out_rate, out_format, block):
+    """Round 5: k_cascade2 (cascade2.hip: raw cu8 / 16-bit frames, 1024 frames per trip of a streaming wave -- stage 0 twice, then the rows
     routine, two outputs per lane, all 64 lanes in the last stage) against k_cascade (IQGPU_NO_CASC2=1: 512 frames per trip): the
     same taps in the same order on the same samples, so the BYTES must be equal -- whole calls, a split that leaves the stream eight
     frames into a group (the second call streams from there), one that leaves it off a 16-byte boundary (all edges), a reset --
     then the oracle."""
     n = (1 << 22) + 16384 * 3 + 8 if block else (1 << 26) + 16384 * 33 + 24
-    raw = synth.raw_stream(n, in_rate, 77, "cu8")
+    raw = synth.raw_stream(n, in_rate, 77, in_format)
     per = raw.size // n
-    kw = dict(in_format="cu8", out_format=out_format, input_rate_hz=in_rate, target_rate_hz=out_rate, block_samples=block)
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=in_rate, target_rate_hz=out_rate, block_samples=block)
     h = n // 2 // 16384 * 16384
     splits = [[n], [h + 8, n - h - 8], [h + 3, 5, n - h - 8]] if block else [[n]]
 
