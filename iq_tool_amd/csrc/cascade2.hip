@@ -6,7 +6,7 @@
 // trip every stage moves one step up the ladder of routines cascade_tiles.hpp already has:
 //
 //   stage 0   casc_stage_raw8 / casc_stage_raw16  twice (the two halves of the trip's raw frames: 2 / 4 KiB of LDS behind 64 / 128
-//             bytes of history; 16-bit frames are unpacked WITHOUT their 2^-15, which the four outputs take at the end -- a power
+//             bytes of history, 16-bit frames in two planes of alternate 16-byte blocks; 16-bit frames are unpacked WITHOUT their 2^-15, which the four outputs take at the end -- a power
 //             of two commutes with every rounding on the way, so the bits are those of the scaled samples)
 //   stage 1   casc_stage       (rows of four samples in two planes, four outputs per lane -- k_cascade's stage 0 on cf32 rows)
 //   stage 2   casc_stage_lin<., 2>   (two outputs per lane from 16-byte reads -- k_cascade's stage 1)
@@ -22,18 +22,22 @@ namespace iqgpu {
 
 constexpr int kCasc2MinRun = 16;       // tiles per streaming run from which the two-tile trips pay (shorter calls: latency counts, k_cascade)
 
-// ---- stage 0 on raw 16-bit frames (cs16, sc16q11): 4 bytes a frame, frame f of the trip at byte kRawHist16 + 4 f.  A lane's four
-// outputs need its own eight frames (two 16-byte blocks) and the 4M - 2 in front of them (M blocks): even sample n = dword 2n,
-// odd sample n = dword 2n + 1 of the lane's frames.
-constexpr int kRawHist16 = 128;
+// ---- stage 0 on raw 16-bit frames (cs16, sc16q11): 4 bytes a frame.  A lane's four outputs need its own eight frames (two 16-byte
+// blocks) and the 4M - 2 in front of them (M blocks): even sample n = dword 2n, odd sample n = dword 2n + 1 of the lane's frames.
+// The blocks live in TWO PLANES -- block g (frames 4g .. 4g + 3 of the trip) in plane g & 1 at position g >> 1 behind 64 bytes of
+// history -- so that every window read and every write walks one plane at a 16-byte lane stride (linear, the lanes 32 bytes
+// apart: SQ_LDS_BANK_CONFLICT 84 of 352 LDS cycles per trip).
+constexpr int kRaw16Plane = 64 + 2048;                      // bytes of one plane: history, 128 blocks of the trip
 template <int M> struct CascWinRaw16 { uint32_t W[4 * (M + 2)]; };
 template <int M>
 __device__ __forceinline__ void casc_stage_raw16_load(const char *RB, int lane, CascWinRaw16<M> &wn)
 {
-    const char *wb = RB + kRawHist16 + lane * 32 - 16 * M;
+    // RB: plane 0 at the half's first block (position 0 or 64); block b of the window is block 2 lane - M + b of the half
 #pragma unroll
     for (int b = 0; b < M + 2; ++b) {
-        const uint4 v = *(const uint4 *)__builtin_assume_aligned(wb + b * 16, 16);
+        const int d = b - M;                                // block index relative to the lane's first
+        const int pl = d & 1, q = (d - pl) / 2;            // plane, position relative to the lane's
+        const uint4 v = *(const uint4 *)__builtin_assume_aligned(RB + pl * kRaw16Plane + 64 + (lane + q) * 16, 16);
         wn.W[4 * b + 0] = v.x; wn.W[4 * b + 1] = v.y; wn.W[4 * b + 2] = v.z; wn.W[4 * b + 3] = v.w;
     }
 }
@@ -70,9 +74,10 @@ template <int KT, int BPF> struct Casc2 {
     static constexpr int M0 = 3, M1 = KT == 2 ? 5 : 3, M2 = KT == 3 ? 5 : 3, M3 = 5;     // liquid's 60 dB semi-lengths: 3 .. 3 5
     static constexpr int H1 = casc_hist_rows(M1);
     static constexpr int PS1 = plane_stride(H1 + 64 + 1);
-    static constexpr int HIST = BPF == 2 ? kRawHist : kRawHist16;
-    static constexpr int HALF = 512 * BPF;                                              // bytes of one 512-frame half
-    static constexpr int RAW = HIST + 2 * HALF;
+    static constexpr int HIST = kRawHist;                                               // 64 bytes (per plane for 16-bit frames)
+    static constexpr int HALF = 512 * BPF;                                              // bytes of one 512-frame half in memory
+    static constexpr int HALF_LDS = 1024;                                               // ... and in LDS (in each plane for 16-bit frames)
+    static constexpr int RAW = BPF == 2 ? HIST + 2048 : 2 * kRaw16Plane;
     static constexpr int ROWS = 4 * PS1;
     static constexpr int E2 = ((casc_lin_hs(M2) + 128) * 8 + 15) & ~15, O2 = ((casc_lin_ho(M2) + 128) * 8 + 15) & ~15;
     static constexpr int E3 = ((casc_lin_hs(M3) + 64) * 8 + 15) & ~15, O3 = ((casc_lin_ho(M3) + 64) * 8 + 15) & ~15;
@@ -146,12 +151,13 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
         CascWinRaw16<G::M0> vA, vB;
         if (BPF == 2) {
             casc_stage_raw8_load<G::M0>(RB, lane, wA);
-            casc_stage_raw8_load<G::M0>(RB + G::HALF, lane, wB);
+            casc_stage_raw8_load<G::M0>(RB + G::HALF_LDS, lane, wB);
         } else {
             casc_stage_raw16_load<G::M0>(RB, lane, vA);
-            casc_stage_raw16_load<G::M0>(RB + G::HALF, lane, vB);
+            casc_stage_raw16_load<G::M0>(RB + G::HALF_LDS, lane, vB);
         }
-        const uint32_t hv = *(const uint32_t *)(RB + 2 * G::HALF + (lane & (G::HIST / 4 - 1)) * 4);      // the trip's last 32 frames
+        // the trip's last 32 frames (16-bit: the last four blocks of either plane, lanes 16 .. 31 in plane 1)
+        const uint32_t hv = *(const uint32_t *)(RB + (BPF == 4 && (lane & 16) ? kRaw16Plane : 0) + 2048 + (lane & 15) * 4);
         CascWin0<G::M1> f1;
         casc_stage_load<G::M1>(XE1, XO1, lane, f1);
         const float se1 = *(const float *)(XE1 + 64 * 16 + tail1), so1 = *(const float *)(XO1 + 64 * 16 + tail1);
@@ -185,12 +191,12 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
 
         // ------------------------------------------------------------ the writes: histories slide, every stage hands its trip on
         __builtin_amdgcn_s_setprio(1);
-        if (lane < G::HIST / 4) *(uint32_t *)(RB + lane * 4) = hv;
-        *(u4v *)__builtin_assume_aligned(RB + G::HIST + 8 * BPF * lane, 16) = rA;
-        *(u4v *)__builtin_assume_aligned(RB + G::HIST + G::HALF + 8 * BPF * lane, 16) = rB;
-        if (BPF == 4) {
-            *(u4v *)__builtin_assume_aligned(RB + G::HIST + 32 * lane + 16, 16) = rA2;
-            *(u4v *)__builtin_assume_aligned(RB + G::HIST + G::HALF + 32 * lane + 16, 16) = rB2;
+        if (lane < (BPF == 4 ? 32 : 16)) *(uint32_t *)(RB + (BPF == 4 && (lane & 16) ? kRaw16Plane : 0) + (lane & 15) * 4) = hv;
+        *(u4v *)__builtin_assume_aligned(RB + G::HIST + 16 * lane, 16) = rA;
+        *(u4v *)__builtin_assume_aligned(RB + G::HIST + G::HALF_LDS + 16 * lane, 16) = rB;
+        if (BPF == 4) {                                    // the lane's second block of either half: plane 1
+            *(u4v *)__builtin_assume_aligned(RB + kRaw16Plane + G::HIST + 16 * lane, 16) = rA2;
+            *(u4v *)__builtin_assume_aligned(RB + kRaw16Plane + G::HIST + G::HALF_LDS + 16 * lane, 16) = rB2;
         }
         {
             const int tw = (lane >= 4 * G::H1 ? G::PS1 - 16 * G::H1 : 0) + lane * 4;
