@@ -208,11 +208,12 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
     const int c = blockIdx.x * 256 + threadIdx.x;
     const AgcState st = *a.state;
     int bad = 0, weak = 0, last_h = -1, cls_k = 0;
+    int64_t b_c = 0;                                               // the call's outputs in front of this chunk
     if (c < a.geom.n_chunks) {
         int k = 0;
         if (st.locked) {
             const int64_t b = agc_out_end(a.geom, (int64_t)c - 1), e = agc_out_end(a.geom, c);
-            a.chunk_b[c] = b;                                      // (the verdict's chunk times: not worked out a second time by one workgroup)
+            a.chunk_b[c] = b; b_c = b;                             // (the verdict's chunk times: not worked out a second time by one workgroup)
             if (e > b) {                                           // empty chunks never reach agc_apply
                 const float pk = (float)sqrt(__longlong_as_double((long long)a.peak2[c]));
                 const float outp = pk * st.gain;
@@ -234,21 +235,41 @@ __global__ __launch_bounds__(256) void k_agc_classify(const AgcArgs a)
         a.peak2[c] = 0ull;                                         // handed back zeroed: the next fused launch accumulates into it (no fill on the hot path)
         if (a.peak2_fallback) a.peak2_fallback[c] = 0ull;          // ... and the fallback's own array, which its k_agc_peak accumulates into
     }
-    // the last healthy chunk at or in front of every chunk, inside this workgroup's 256 (gain[] doubles as the scratch: the fused pass
-    // has no use for it, and the fallback's k_agc_scan writes it anew) and the workgroup's last one: what the verdict's hang-time
-    // test needs.  (Round 5: until then ONE workgroup scanned all chunks, 256 at a time, for a prefix maximum of healthy chunk
-    // TIMES -- which grow with the chunk index, so the maximum is the last healthy index: 0.13 ms for the 16384 chunks of a 2^28-frame
-    // call of the cs16-am-nrsc5 preset, whose narrow output makes weak chunks the rule.)
+    // The hang-time test (a weak chunk creeps iff its time is more than the hang time past the last healthy chunk in front of it, or
+    // the state's last strong peak) where the chunks are: the last healthy chunk at or in front of every chunk inside this
+    // workgroup's 256 by a prefix maximum of indices (chunk times grow with the index), a weak chunk that has one tests itself; of
+    // those that have none -- they all share whatever came before the workgroup -- the LAST one decides, and only that index goes to
+    // the verdict (wg_pend), with the workgroup's last healthy index (wg_last).  (Round 5, first form: ONE workgroup walked every weak
+    // chunk -- 64 rounds of three dependent loads and four divisions on the cs16-am-nrsc5 preset, whose narrow output makes weak
+    // chunks the rule: 82 us of a 0.44 ms step.)
     {
-        __shared__ int s_wl[4];
+        __shared__ int s_wl[4], s_wp[4];
+        __shared__ long long s_b[256];
+        s_b[threadIdx.x] = b_c;
         int h = cls_k == 1 ? c : -1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(h, o); if ((int)(threadIdx.x & 63) >= o) h = v > h ? v : h; }
         if ((threadIdx.x & 63) == 63) s_wl[threadIdx.x >> 6] = h;
         __syncthreads();
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) h = s_wl[w] > h ? s_wl[w] : h;
-        if (c < a.geom.n_chunks) ((int32_t *)a.gain)[c] = h;
         if (threadIdx.x == 255) a.wg_last[blockIdx.x] = h;
+        auto t_of_b = [&](int64_t b) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)b) / a.rate; };
+        int pend = -1;
+        if (cls_k == 2) {
+            if (h >= 0) {
+                const double before = fmax(st.last_strong, t_of_b(s_b[h - (int)blockIdx.x * 256]));
+                if (t_of_b(b_c) - before > (double)kAgcHangTime) bad = 1;
+            } else pend = c;
+        }
+#pragma unroll
+        for (int k2 = 32; k2 >= 1; k2 >>= 1) { const int o = __shfl_xor(pend, k2); pend = o > pend ? o : pend; }
+        if ((threadIdx.x & 63) == 0) s_wp[threadIdx.x >> 6] = pend;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int m = s_wp[0];
+            for (int w = 1; w < 4; ++w) m = s_wp[w] > m ? s_wp[w] : m;
+            a.wg_pend[blockIdx.x] = m;
+        }
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 1, 1);
     if (__ballot(weak) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.verify_flag + 2, 1);
@@ -274,7 +295,6 @@ __device__ void agc_verdict(const AgcArgs &a)
     __shared__ int s_bad;
     const int tid = threadIdx.x, nthr = (int)blockDim.x;
     const AgcState st = *a.state;
-    const int32_t *cls = a.chunk_len;
     // (time of a chunk = outputs seen before it / rate; the counts come from the classification: 16384 chunks of two 64-bit
     //  divisions each took this one workgroup 0.1 ms on the cs16-am-nrsc5 preset, whose narrow output makes weak chunks the rule)
     auto t_of = [&](int c) { return a.clock_wall ? a.t_wall : (double)(st.seen + (uint64_t)a.chunk_b[c]) / a.rate; };
@@ -282,8 +302,8 @@ __device__ void agc_verdict(const AgcArgs &a)
     if (tid == 0) s_bad = (!st.locked || any_bad) ? 1 : 0;
     __syncthreads();
     if (!s_bad && any_weak) {
-        // a weak chunk creeps iff its time is more than the hang time past the last healthy chunk before it (or the state's last
-        // strong peak): the last healthy chunk inside its workgroup of the classification, else in front of that workgroup
+        // what the workgroups of the classification could not settle: their last weak chunk with no healthy one in front of it inside
+        // the workgroup, against the last healthy chunk of the workgroups before (or the state's last strong peak)
         __shared__ int s_wgp[1024];
         const int n_wg = (a.geom.n_chunks + 255) / 256;
         if (n_wg > 1024) { if (tid == 0) s_bad = 1; }              // (more than 2^18 chunks in one call: the exact kernels)
@@ -292,11 +312,10 @@ __device__ void agc_verdict(const AgcArgs &a)
             __syncthreads();
             if (tid == 0) { int m = -1; for (int w = 0; w < n_wg; ++w) { m = s_wgp[w] > m ? s_wgp[w] : m; s_wgp[w] = m; } }
             __syncthreads();
-            const int32_t *lh = (const int32_t *)a.gain;
-            for (int c = tid; c < a.geom.n_chunks; c += nthr) {
-                if (cls[c] != 2) continue;
-                int last = lh[c];
-                if (last < 0 && c >= 256) last = s_wgp[c / 256 - 1];
+            for (int w = tid; w < n_wg; w += nthr) {
+                const int c = a.wg_pend[w];
+                if (c < 0) continue;
+                const int last = w > 0 ? s_wgp[w - 1] : -1;
                 const double before = last >= 0 ? fmax(st.last_strong, t_of(last)) : st.last_strong;
                 if (t_of(c) - before > (double)kAgcHangTime) atomicOr(&s_bad, 1);
             }

@@ -24,6 +24,7 @@ AgcArgs Call::agc_args() const
     ga.chunk_len = (int32_t *)((float *)c->agc_gain.p + g.n_chunks); ga.state = c->d_agc_state;
     ga.chunk_b = (int64_t *)((char *)c->agc_gain.p + (size_t)g.n_chunks * 8);                 // (behind gain[] and chunk_len[]: 8-byte aligned)
     ga.wg_last = (int32_t *)((char *)c->agc_gain.p + (size_t)g.n_chunks * 16);
+    ga.wg_pend = ga.wg_last + ((size_t)g.n_chunks / 256 + 2);
     ga.target = c->agc_target; ga.rate = c->target_rate;
     ga.clock_wall = c->desc.agc_clock == IQGPU_AGC_CLOCK_WALL ? 1 : 0;
     ga.t_wall = ga.clock_wall ? monotonic_sec() : 0.0;

@@ -493,6 +493,7 @@ struct AgcArgs {
     float     *gain;          // [n_chunks]
     int32_t   *chunk_len;     // [n_chunks] outputs per chunk, written by k_agc_peak, read by k_agc_scan
     int32_t   *wg_last;       // [ceil(n_chunks / 256)] k_agc_classify: the last healthy chunk of each of its workgroups (-1: none)
+    int32_t   *wg_pend;       // [ceil(n_chunks / 256)] ... and its last weak chunk with no healthy one in front of it inside the workgroup
     int64_t   *chunk_b;       // [n_chunks] k_agc_classify: the call's outputs in front of the chunk (agc_out_end(c - 1)), for the verdict's times
     AgcState  *state;
     float      target;

@@ -91,7 +91,7 @@ int Call::prepare_buffers()
         { const void *was = c->agc_peak.p;
           int rc0 = c->agc_peak.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc0) return rc0;
           if (c->agc_peak.p != was) c->agc_peak_clean = false; }
-        int rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t) + sizeof(int64_t)) + ((size_t)g.n_chunks / 256 + 2) * sizeof(int32_t)); if (rc) return rc;
+        int rc = c->agc_gain.ensure((size_t)g.n_chunks * (sizeof(float) + sizeof(int32_t) + sizeof(int64_t)) + 2 * ((size_t)g.n_chunks / 256 + 2) * sizeof(int32_t)); if (rc) return rc;
         if (agc_fused) {   // what the fallback launches need, should the verifier reject the fused pass
             rc = c->agc_peak_b.ensure((size_t)g.n_chunks * sizeof(unsigned long long)); if (rc) return rc;
             rc = c->abuf.ensure(((size_t)p.n_emit + 1) * sizeof(cf2)); if (rc) return rc;
