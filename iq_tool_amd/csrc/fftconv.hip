@@ -313,7 +313,10 @@ __device__ __forceinline__ void fft16_lds(cf2 *buf, const cf2 *tw, int tid, cf2 
     else r16_passes<N, Ns4, false, false>(buf, tw, tid, first, io);
 }
 
-template <int LOG2N>
+// LOOP: the conditional fallback behind a fused launch (run_if): a bounded grid whose workgroups walk the blocks -- when the verdict
+// stands (the rule) a few thousand workgroups leave at once, where one workgroup per block of a 2^28-frame call -- 179 000 single
+// waves at N = 1024 -- took 20 - 45 us to come and go
+template <int LOG2N, bool LOOP = false>
 // (four waves per SIMD: 4 workgroups of N = 4096, 2 of N = 8192 -- what their LDS allows -- need 128 VGPRs or fewer)
 __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_eu(4))) void k_fftconv16(const FftConvArgs a)
 {
@@ -326,10 +329,13 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
     cf2 *X = (cf2 *)smem;
     cf2 *s_nco = X + NP;
     if (a.pnco_mode != 0) for (int i = tid; i < 1024; i += T) s_nco[i] = a.nco_tab[i];   // (read behind the barriers of the transforms)
+    const int64_t n_blocks = LOOP ? (a.n_emit + V - 1) / V : (int64_t)gridDim.x;
     if (a.move_n > 0 && blockIdx.x == gridDim.x - 1)                 // the next call's history, into the other buffer of the pair
         for (int64_t i = tid; i < a.move_n; i += T) a.move_dst[i] = a.move_src[i];
 
-    const int64_t o0 = (int64_t)blockIdx.x * V;
+  int64_t blk = blockIdx.x;
+  do {
+    const int64_t o0 = blk * V;
     cf2 io[16];                                                      // point tid + i T of the window / spectrum / result
     {
         const cf2 *srcg = a.fbuf + o0 + tid;
@@ -397,6 +403,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
             if (m1 > 0.0f) atomicMax(a.agc_peak2 + agc_c1, (unsigned long long)__double_as_longlong((double)m1));
         }
     }
+    blk += (int64_t)gridDim.x;
+    if (LOOP) __syncthreads();                                       // (the walk: the transform buffer is free again)
+  } while (LOOP && blk < n_blocks);
 }
 
 bool fftconv_agc_fusable(int log2n, int ntaps, uint32_t dbg)
@@ -407,7 +416,14 @@ bool fftconv_agc_fusable(int log2n, int ntaps, uint32_t dbg)
 template <int LOG2N>
 static hipError_t launch_fftconv16(const FftConvArgs &a, unsigned nb, size_t lds, hipStream_t s)
 {
-    static LdsAttrCache cache16;
+    static LdsAttrCache cache16, cache16l;
+    if (a.run_if) {
+        // the conditional fallback: about four rounds of resident workgroups, each walking its share of the blocks
+        const unsigned cap = 256u * 16u * 1024u / (unsigned)(1 << LOG2N) * 4u;
+        if (lds > 64 * 1024) { const hipError_t e = cache16l.ensure((const void *)k_fftconv16<LOG2N, true>, lds); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL((k_fftconv16<LOG2N, true>), dim3(nb < cap ? nb : cap), dim3((1 << LOG2N) / 16), lds, s, a);
+        return hipGetLastError();
+    }
     if (lds > 64 * 1024) { const hipError_t e = cache16.ensure((const void *)k_fftconv16<LOG2N>, lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_fftconv16<LOG2N>, dim3(nb), dim3((1 << LOG2N) / 16), lds, s, a);
     return hipGetLastError();
