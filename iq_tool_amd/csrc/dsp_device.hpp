@@ -129,6 +129,10 @@ __device__ __forceinline__ bool unpack_four_fast(const void *raw, int64_t j, int
     }
 }
 
+// max of two floats that are never NaN (|y|^2 peaks): ONE v_med3_f32 -- fmaxf costs three instructions under IEEE mode (a
+// canonicalising v_max_f32 x, x on either operand, then the maximum)
+__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+
 // src/sample_convert.c:40-57: scale, +-0.5 by sign, clamp, truncate
 __device__ __forceinline__ int pk_signed(float x, float scale, float lo, float hi)
 {
@@ -141,9 +145,9 @@ __device__ __forceinline__ int pk_signed(float x, float scale, float lo, float h
 // src/sample_convert.c:59-73: scale, offset, clamp, +0.5, truncate
 __device__ __forceinline__ unsigned pk_unsigned(float x, float scale, float off, float hi)
 {
-    float v = __fadd_rn(__fmul_rn(x, scale), off);
-    if (v > hi) v = hi;
-    if (v < 0.0f) v = 0.0f;
+    // (one v_med3_f32 instead of two compare / select pairs: the same value for every finite input -- fminf / fmaxf would add a
+    //  canonicalising v_max_f32 each under IEEE mode)
+    const float v = __builtin_amdgcn_fmed3f(__fadd_rn(__fmul_rn(x, scale), off), 0.0f, hi);
     return (unsigned)__fadd_rn(v, 0.5f);
 }
 
