@@ -58,13 +58,26 @@ template <typename T> __device__ __forceinline__ void keep(const T &v) { asm vol
 // Hw[i] = sample i - 14 (the 13 in front of the lane's own; Hw[0] unused), own[m] = sample m.
 template <int NL, int LOJ> struct PpGeom { static constexpr int HI = LOJ + 2 < NL - 1 ? LOJ + 2 : NL - 1, W = HI - LOJ + 14; };
 // step wi of a slot's chain (wi counts down from 15; a slot whose window is shorter starts later)
-template <int NL, int LOJ>
+// SEL (k_front_p0): the tap is picked out of its register pair by the instruction's op_sel bits, written out -- left to the compiler,
+// one of the five slots of a step had its 16 taps copied into {t, t} pairs first (32 v_mov_b32 per step)
+template <int NL, int LOJ, bool SEL = false>
 __device__ __forceinline__ void pp_step(const int wi, const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&t)[8], v2f &y)
 {
     constexpr int W = PpGeom<NL, LOJ>::W;
     if (wi >= W) return;
     const int m = LOJ - 13 + wi;
     const v2f h = m < 0 ? Hw[m + 14] : own[m];
+    if (SEL) {
+        const v2f tp = t[wi >> 1];
+        if (wi == W - 1) {
+            if (wi & 1) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(y) : "v"(tp), "v"(h));
+            else        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(y) : "v"(tp), "v"(h));
+        } else {
+            if (wi & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(y) : "v"(tp), "v"(h));
+            else        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(y) : "v"(tp), "v"(h));
+        }
+        return;
+    }
     const float tw = (wi & 1) ? t[wi >> 1].y : t[wi >> 1].x;
     y = wi == W - 1 ? mul2(tw, h) : fma2(tw, h, y);
 }
@@ -76,18 +89,20 @@ __device__ __forceinline__ void pp_slot1(const v2f (&Hw)[14], const v2f (&own)[N
     for (int wi = 15; wi >= 0; --wi) pp_step<NL, LA>(wi, Hw, own, ta, ya);
 }
 // two / three slots side by side: their chains are independent, so that no FMA waits for the one before it
-template <int NL, int LA, int LB>
+template <int NL, int LA, int LB, bool SEL = false>
 __device__ __forceinline__ void pp_slots2(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], const v2f (&tb)[8], v2f &ya, v2f &yb)
 {
 #pragma unroll
-    for (int wi = 15; wi >= 0; --wi) { pp_step<NL, LA>(wi, Hw, own, ta, ya); pp_step<NL, LB>(wi, Hw, own, tb, yb); }
+    for (int wi = 15; wi >= 0; --wi) { pp_step<NL, LA, SEL>(wi, Hw, own, ta, ya); pp_step<NL, LB, SEL>(wi, Hw, own, tb, yb); }
 }
-template <int NL, int LA, int LB, int LC>
+template <int NL, int LA, int LB, int LC, bool SEL = false>
 __device__ __forceinline__ void pp_slots3(const v2f (&Hw)[14], const v2f (&own)[NL], const v2f (&ta)[8], const v2f (&tb)[8], const v2f (&tc)[8],
                                           v2f &ya, v2f &yb, v2f &yc)
 {
 #pragma unroll
-    for (int wi = 15; wi >= 0; --wi) { pp_step<NL, LA>(wi, Hw, own, ta, ya); pp_step<NL, LB>(wi, Hw, own, tb, yb); pp_step<NL, LC>(wi, Hw, own, tc, yc); }
+    for (int wi = 15; wi >= 0; --wi) {
+        pp_step<NL, LA, SEL>(wi, Hw, own, ta, ya); pp_step<NL, LB, SEL>(wi, Hw, own, tb, yb); pp_step<NL, LC, SEL>(wi, Hw, own, tc, yc);
+    }
 }
 
 

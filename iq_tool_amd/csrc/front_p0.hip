@@ -170,8 +170,8 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         for (int m = 0; m < 9; ++m) own[m] = p0_unpack<FMT>(rc, 13 + m);
         // ---- five outputs: the chains of the other kernels, slot by slot
         v2f y[NS];
-        pp_slots3<9, 0, 1, 3>(Hw, own, t[0], t[1], t[2], y[0], y[1], y[2]);
-        pp_slots2<9, L3, L4>(Hw, own, t[3], t[4], y[3], y[4]);
+        pp_slots3<9, 0, 1, 3, true>(Hw, own, t[0], t[1], t[2], y[0], y[1], y[2]);
+        pp_slots2<9, L3, L4, true>(Hw, own, t[3], t[4], y[3], y[4]);
         const int64_t k0 = a.p0_k_a + s * kP0Step + 5 * lane;                  // the lane's first output (call-relative)
         if (AGC) {
             const int64_t first = (int64_t)(Pw >> 24);     // position of the step's first output: the others lie at most 520 samples behind it
