@@ -14,6 +14,7 @@
 // Twiddles come from an N-entry table in global memory (L2-resident; double-precision values
 // rounded to float -- v_sin/v_cos are not accurate enough for the 1e-5 budget).
 #include <cstdlib>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "../../include/iqgpu.h"
@@ -378,22 +379,38 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
         agc_b1 = agc_out_end(a.agc_geom, agc_c0);
         agc_c1 = agc_b1 < o0 + nv ? agc_chunk_of_output(a.agc_geom, agc_b1) : agc_c0 + 1;      // (chunks without an output lie between)
     }
+    // the output format is chosen ONCE per block (the switch inside the loop was a chain of scalar compares and branches per output:
+    // sixteen times per thread)
+    auto emit = [&](auto fmt_tag) {
+        constexpr int F = decltype(fmt_tag)::value;                  // -1: whatever a.out_fmt says (pack_store)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = tid + r * T - L1;                              // output i of the block is point L1 + i of the result
-        if (i < 0 || i >= nv) continue;
-        cf2 y = io[r];
-        y.y = -y.y;
-        const int64_t k = o0 + i;
-        if (a.pnco_mode != 0)
-            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
-        if (a.agc_fused) {
-            // agc_apply: the chunk's peak over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
-            const float m2 = fmaf(y.x, y.x, y.y * y.y);
-            if (k < agc_b1) m0 = fmax_nn(m0, m2); else m1 = fmax_nn(m1, m2);
-            y = cf2{y.x * agc_g, y.y * agc_g};
+        for (int r = 0; r < 16; ++r) {
+            const int i = tid + r * T - L1;                          // output i of the block is point L1 + i of the result
+            if (i < 0 || i >= nv) continue;
+            cf2 y = io[r];
+            y.y = -y.y;
+            const int64_t k = o0 + i;
+            if (a.pnco_mode != 0)
+                y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
+            if (a.agc_fused) {
+                // agc_apply: the chunk's peak over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
+                const float m2 = fmaf(y.x, y.x, y.y * y.y);
+                if (k < agc_b1) m0 = fmax_nn(m0, m2); else m1 = fmax_nn(m1, m2);
+                y = cf2{y.x * agc_g, y.y * agc_g};
+            }
+            if (F == IQGPU_FMT_CS16) ((uint32_t *)a.out)[k] = pack_cs16(y);
+            else if (F == IQGPU_FMT_CU8) ((uint16_t *)a.out)[k] = (uint16_t)pack_b8(y, true);
+            else if (F == IQGPU_FMT_CS8) ((uint16_t *)a.out)[k] = (uint16_t)pack_b8(y, false);
+            else if (F == IQGPU_FMT_CF32) ((cf2 *)a.out)[k] = y;
+            else pack_store(a.out, k, a.out_fmt, y);
         }
-        pack_store(a.out, k, a.out_fmt, y);
+    };
+    switch (a.out_fmt) {
+    case IQGPU_FMT_CS16: emit(std::integral_constant<int, IQGPU_FMT_CS16>{}); break;
+    case IQGPU_FMT_CU8:  emit(std::integral_constant<int, IQGPU_FMT_CU8>{}); break;
+    case IQGPU_FMT_CS8:  emit(std::integral_constant<int, IQGPU_FMT_CS8>{}); break;
+    case IQGPU_FMT_CF32: emit(std::integral_constant<int, IQGPU_FMT_CF32>{}); break;
+    default:             emit(std::integral_constant<int, -1>{}); break;
     }
     if (a.agc_fused) {
 #pragma unroll

@@ -29,24 +29,7 @@ __device__ __forceinline__ uint32_t ceil_div_small(uint32_t x, uint32_t d, float
     return f + (((uint64_t)f * d < (uint64_t)x) ? 1u : 0u);
 }
 
-// frame -> base[idx]; base is wave-uniform, idx a small per-lane offset.  cs16: same result as
-// src/sample_convert.c:40-57 for every finite input -- +-0.5 by sign is a copysign (0 gives 0 either
-// way), truncation then int16 saturation equals float clamp then truncation.
-__device__ __forceinline__ uint32_t pack_cs16(cf2 v)
-{
-    typedef float f2 __attribute__((ext_vector_type(2)));           // (both components in one packed multiply and one packed add)
-    f2 s = f2{v.x, v.y} * f2{32767.0f, 32767.0f};
-    s = s + f2{copysignf(0.5f, s.x), copysignf(0.5f, s.y)};
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 pk = __builtin_amdgcn_cvt_pk_i16((int)s.x, (int)s.y);
-    return __builtin_bit_cast(uint32_t, pk);
-}
-// cu8 / cs8: one frame as 16 bits (src/sample_convert.c:40-73, the arithmetic of pack_store)
-__device__ __forceinline__ uint32_t pack_b8(cf2 v, bool is_unsigned)
-{
-    if (is_unsigned) return pk_unsigned(v.x, 127.0f, 127.5f, 255.0f) | (pk_unsigned(v.y, 127.0f, 127.5f, 255.0f) << 8);
-    return ((unsigned)pk_signed(v.x, 127.0f, -128.0f, 127.0f) & 0xffu) | (((unsigned)pk_signed(v.y, 127.0f, -128.0f, 127.0f) & 0xffu) << 8);
-}
+// (pack_cs16 / pack_b8: dsp_device.hpp)
 __device__ __forceinline__ void pack_store_at(char *base, uint32_t idx, int fmt, cf2 v)
 {
     if (fmt == IQGPU_FMT_CS16) {
