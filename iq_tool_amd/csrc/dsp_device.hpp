@@ -129,10 +129,6 @@ __device__ __forceinline__ bool unpack_four_fast(const void *raw, int64_t j, int
     }
 }
 
-// max of two floats that are never NaN (|y|^2 peaks): ONE v_med3_f32 -- fmaxf costs three instructions under IEEE mode (a
-// canonicalising v_max_f32 x, x on either operand, then the maximum)
-__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
-
 // src/sample_convert.c:40-57: scale, +-0.5 by sign, clamp, truncate
 __device__ __forceinline__ int pk_signed(float x, float scale, float lo, float hi)
 {

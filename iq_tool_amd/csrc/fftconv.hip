@@ -395,7 +395,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) __attribute__((amdgpu_waves_per_
             if (a.agc_fused) {
                 // agc_apply: the chunk's peak over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
                 const float m2 = fmaf(y.x, y.x, y.y * y.y);
-                if (k < agc_b1) m0 = fmax_nn(m0, m2); else m1 = fmax_nn(m1, m2);
+                if (k < agc_b1) m0 = fmaxf(m0, m2); else m1 = fmaxf(m1, m2);
                 y = cf2{y.x * agc_g, y.y * agc_g};
             }
             if (F == IQGPU_FMT_CS16) ((uint32_t *)a.out)[k] = pack_cs16(y);

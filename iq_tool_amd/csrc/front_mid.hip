@@ -269,7 +269,7 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
                 if (j < NS - 1 || pos < (uint32_t)NL) {
                     // agc_apply: peak of the chunk over the samples BEFORE the gain, then samples[i] *= g (src/agc.c:169-214)
                     const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
-                    if ((uint32_t)(NL * lane) + pos < agc_qb) agc_m0 = fmax_nn(agc_m0, m2); else agc_m1 = fmax_nn(agc_m1, m2);
+                    if ((uint32_t)(NL * lane) + pos < agc_qb) agc_m0 = fmaxf(agc_m0, m2); else agc_m1 = fmaxf(agc_m1, m2);
                 }
                 y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
                 P += step;

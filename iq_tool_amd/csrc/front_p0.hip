@@ -188,7 +188,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
-                    if (!PARTIAL || k0 + j < a.p0_k_b) m0 = fmax_nn(m0, m2);
+                    if (!PARTIAL || k0 + j < a.p0_k_b) m0 = fmaxf(m0, m2);
                     y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
                 }
             } else {
@@ -199,7 +199,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
                     const float m2 = fmaf(y[j].x, y[j].x, y[j].y * y[j].y);
                     const bool valid = !PARTIAL || k0 + j < a.p0_k_b;
                     const bool late = mine + (Pj[j] >> 24) >= b_rel;
-                    if (valid) { if (late) m1 = fmax_nn(m1, m2); else m0 = fmax_nn(m0, m2); }
+                    if (valid) { if (late) m1 = fmaxf(m1, m2); else m0 = fmaxf(m0, m2); }
                     crossed = crossed || (valid && late);
                     y[j] = v2f{y[j].x * agc_g, y[j].y * agc_g};
                 }
