@@ -20,7 +20,9 @@
 
 namespace iqgpu {
 
-constexpr int kCasc2MinRun = 16;       // tiles per streaming run from which the two-tile trips pay (shorter calls: latency counts, k_cascade)
+// tiles per streaming run from which the two-tile trips are used: measured (tools/gpu/r5_casc2_min.py, cascade us per call, one- / two-tile
+// trips): 2^22 frames = 2 tiles per run 28.0 / 26.3, 2^24 34.1 / 32.0, 2^25 48.7 / 41.0, 2^27 142 / 112 (cu8, K = 4); 16-bit frames alike
+constexpr int kCasc2MinRun = 2;
 
 // ---- stage 0 on raw 16-bit frames (cs16, sc16q11): 4 bytes a frame.  A lane's four outputs need its own eight frames (two 16-byte
 // blocks) and the 4M - 2 in front of them (M blocks): even sample n = dword 2n, odd sample n = dword 2n + 1 of the lane's frames.
@@ -108,10 +110,12 @@ bool cascade2_shape(const FrontArgs &a)
     return true;
 }
 
-// ... and the call: streaming runs long enough, the tile in front of the first run's warm-up loadable, the slice sized for both layouts
+// ... and the call: streaming runs of two tiles and more, the tile in front of the first run's warm-up loadable, the slice sized for both layouts
 bool cascade2_applies(const FrontArgs &a)
 {
-    if (!cascade2_shape(a) || a.w_n_stream <= 0 || a.w_run_q < kCasc2MinRun) return false;
+    // (IQGPU_CASC2_MIN_RUN: diagnostics -- where the two-tile trips start to pay, tools/gpu/r5_casc2_min.py)
+    static const int min_run = [] { const char *e = getenv("IQGPU_CASC2_MIN_RUN"); const int v = e ? atoi(e) : 0; return v > 0 ? v : kCasc2MinRun; }();
+    if (!cascade2_shape(a) || a.w_n_stream <= 0 || a.w_run_q < min_run) return false;
     if ((a.w_edge_ta - a.w_warm_tiles - 1) * (int64_t)kWTile - a.rem0 < 0) return false;
     return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K, a.in_fmt);
 }
