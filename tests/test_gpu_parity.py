@@ -1215,6 +1215,40 @@ def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_
         int_close(got, want, min_same=0.998)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_two_tile_trips_on_random_geometry(gpu, monkeypatch, seed):
+    """k_cascade2 against k_cascade where the geometry is drawn: format, stage count, runs of 2 .. 40 tiles, ragged call splits that leave
+    the stream at any phase of a decimation group (tools/gpu/r5_casc2_stress.py draws 80 of these per run).  Bytes must be equal."""
+    rng = np.random.default_rng(seed)
+    shapes = [("cu8", 20e6, 1488375.0), ("cu8", 20e6, 744187.5), ("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 46511.71875),
+              ("cs16", 20e6, 1488375.0), ("sc16q11", 20e6, 744187.5)]
+    fmt, ri, ro = shapes[int(rng.integers(len(shapes)))]
+    block = int(rng.integers(2, 41)) * 8192
+    total = int(rng.integers(1 << 20, 3 << 20))
+    cuts, pos = [], 0
+    while pos < total:
+        k = int(rng.choice([rng.integers(1, 64), rng.integers(1 << 16, 1 << 21), 8 * rng.integers(1 << 13, 1 << 18)]))
+        k = min(k, total - pos); cuts.append(k); pos += k
+    raw = synth.raw_stream(total, ri, seed, fmt)
+    per = raw.size // total
+    kw = dict(in_format=fmt, out_format=str(rng.choice(["cs16", "cu8", "cf32"])), input_rate_hz=ri, target_rate_hz=ro, block_samples=block)
+
+    def run():
+        ch = gpu.Chain(**kw)
+        outs, p, names = [], 0, set()
+        for k in cuts:
+            outs.append(ch.process(raw[per * p:per * (p + k)])); p += k
+            names.add(ch.front_kernel())
+        return np.concatenate(outs), names
+
+    monkeypatch.setenv("IQGPU_NO_CASC2", "1")
+    ref, names1 = run()
+    monkeypatch.delenv("IQGPU_NO_CASC2")
+    got, names2 = run()
+    assert "k_cascade2+k_front_s1" not in names1
+    assert np.array_equal(got, ref), (kw, cuts, names2)
+
+
 @pytest.mark.parametrize("in_format,in_rate,out_rate,out_format,extra", [
     ("cs16", 10e6, 2.4e6, "cs16", dict(dc_block=True, iq_correct=True, iq_mag=0.01, iq_phase=-0.005)),   # BASELINE configs[2] in front of its filter
     ("cs16", 10e6, 2.4e6, "cf32", dict(shift_hz=250e3)),                              # a mixer in front, cf32 out
