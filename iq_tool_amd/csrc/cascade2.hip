@@ -1,4 +1,4 @@
-// cascade2.hip -- k_cascade2: k_cascade (cascade_wave.hip) for raw cu8 / cs16 frames with TWO 512-frame tiles per trip of a streaming wave.
+// cascade2.hip -- k_cascade2: k_cascade (cascade_wave.hip) for raw 8-bit / 16-bit frames with TWO 512-frame tiles per trip of a streaming wave.
 //
 // k_cascade hands every stage one 512-frame tile per trip, so at K = 4 its late stages run half empty: stage 2 produces one output per
 // lane from 8-byte window reads, stage 3 keeps 32 lanes busy -- and an LDS instruction costs the pipe the same whatever the lanes do
@@ -90,7 +90,7 @@ template <int KT, int BPF> struct Casc2 {
     static constexpr int WAVES = (160 * 1024 / BYTES) >= 16 ? 16 : 12;                  // what cascade_waves() makes of BYTES
 };
 
-static inline int casc2_bpf(int fmt) { return fmt == IQGPU_FMT_CU8 ? 2 : (fmt == IQGPU_FMT_CS16 || fmt == IQGPU_FMT_SC16Q11) ? 4 : 0; }
+static inline int casc2_bpf(int fmt) { return (fmt == IQGPU_FMT_CU8 || fmt == IQGPU_FMT_CS8) ? 2 : (fmt == IQGPU_FMT_CS16 || fmt == IQGPU_FMT_SC16Q11) ? 4 : 0; }
 
 int cascade2_wave_lds(int K, int in_fmt)
 {
@@ -100,7 +100,7 @@ int cascade2_wave_lds(int K, int in_fmt)
     return 0;
 }
 
-// the chain shape: cu8 / cs16 / sc16q11 frames with nothing between the unpack and stage 0, two to four stages of liquid's lengths
+// the chain shape: cu8 / cs8 / cs16 / sc16q11 frames with nothing between the unpack and stage 0, two to four stages of liquid's lengths
 bool cascade2_shape(const FrontArgs &a)
 {
     if (casc2_bpf(a.in_fmt) == 0 || a.gain != 1.0f || a.dc_enable || a.iq_enable || a.nco_mode != 0) return false;
@@ -120,7 +120,7 @@ bool cascade2_applies(const FrontArgs &a)
     return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K, a.in_fmt);
 }
 
-template <int KT, int BPF>
+template <int KT, int BPF, bool S8>
 __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, const int lane, int64_t t_begin, const int64_t t_emit0, const int64_t t_end)
 {
     using G = Casc2<KT, BPF>;
@@ -170,8 +170,8 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
         v2f y0a[4], y0b[4], y1[4], y2[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, y3[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
         float se2 = 0.f, so2 = 0.f, se3 = 0.f, so3 = 0.f;
         if (BPF == 2) {
-            casc_stage_raw8_fma<G::M0, true>(wA, a.casc_taps[0], y0a);
-            casc_stage_raw8_fma<G::M0, true>(wB, a.casc_taps[0], y0b);
+            casc_stage_raw8_fma<G::M0, !S8>(wA, a.casc_taps[0], y0a);
+            casc_stage_raw8_fma<G::M0, !S8>(wB, a.casc_taps[0], y0b);
         } else {
             casc_stage_raw16_fma<G::M0>(vA, a.casc_taps[0], norm, y0a);
             casc_stage_raw16_fma<G::M0>(vB, a.casc_taps[0], norm, y0b);
@@ -240,7 +240,8 @@ __device__ __forceinline__ void casc_trips(const FrontArgs &a, char *slice, cons
     }
 }
 
-template <int KT, int BPF>
+// S8: signed 8-bit frames (cs8: a HackRF's) instead of cu8
+template <int KT, int BPF, bool S8 = false>
 __global__ __launch_bounds__((Casc2<KT, BPF>::WAVES * 64)) void k_cascade2(const FrontArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -275,7 +276,7 @@ __global__ __launch_bounds__((Casc2<KT, BPF>::WAVES * 64)) void k_cascade2(const
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream) return;
         const int64_t t0 = w_run_start(a, r), t1 = w_run_start(a, r + 1);
-        casc_trips<KT, BPF>(a, slice, lane, t0 - a.w_warm_tiles, t0, t1);
+        casc_trips<KT, BPF, S8>(a, slice, lane, t0 - a.w_warm_tiles, t0, t1);
     }
 }
 
@@ -287,21 +288,25 @@ hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s)
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + waves - 1) / waves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_CASC2(KT, BPF)                                                                                    \
+#define IQGPU_LAUNCH_CASC2(KT, BPF, S8)                                                                                \
     do {                                                                                                              \
         static LdsAttrCache cache;                                                                                    \
         if (waves > Casc2<KT, BPF>::WAVES) return hipErrorInvalidValue;                                               \
-        { const hipError_t e = cache.ensure((const void *)k_cascade2<KT, BPF>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_cascade2<KT, BPF>), dim3(grid), dim3(waves * 64), lds, s, a);                           \
+        { const hipError_t e = cache.ensure((const void *)k_cascade2<KT, BPF, S8>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_cascade2<KT, BPF, S8>), dim3(grid), dim3(waves * 64), lds, s, a);                       \
     } while (0)
-    if (casc2_bpf(a.in_fmt) == 2) {
-        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 2);
-        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 2);
-        else IQGPU_LAUNCH_CASC2(4, 2);
+    if (a.in_fmt == IQGPU_FMT_CS8) {
+        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 2, true);
+        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 2, true);
+        else IQGPU_LAUNCH_CASC2(4, 2, true);
+    } else if (casc2_bpf(a.in_fmt) == 2) {
+        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 2, false);
+        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 2, false);
+        else IQGPU_LAUNCH_CASC2(4, 2, false);
     } else {
-        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 4);
-        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 4);
-        else IQGPU_LAUNCH_CASC2(4, 4);
+        if (a.casc_K == 2) IQGPU_LAUNCH_CASC2(2, 4, false);
+        else if (a.casc_K == 3) IQGPU_LAUNCH_CASC2(3, 4, false);
+        else IQGPU_LAUNCH_CASC2(4, 4, false);
     }
 #undef IQGPU_LAUNCH_CASC2
     return hipGetLastError();

@@ -1171,6 +1171,8 @@ def test_cascade_instantiations_equal_the_generic_kernel(gpu, oracle, monkeypatc
     ("cs16", 20e6, 1488375.0, "cs16", 40 * 8192),   # K = 2
     ("sc16q11", 20e6, 744187.5, "cs16", 36 * 8192),   # K = 3, the other 16-bit scale
     ("cs16", 2.4e6, 46511.71875, "cf32", 0),
+    ("cs8", 20e6, 744187.5, "cs8", 36 * 8192),      # signed 8-bit frames (a HackRF's 20 MS/s), K = 3
+    ("cs8", 20e6, 400e3, "cs16", 40 * 8192),        # ... K = 4
 ])
 def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_format, in_rate, out_rate, out_format, block):
     """Round 5: k_cascade2 (cascade2.hip: raw cu8 / 16-bit frames, 1024 frames per trip of a streaming wave -- stage 0 twice, then the rows
@@ -1215,13 +1217,13 @@ def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_
         int_close(got, want, min_same=0.998)
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
 def test_two_tile_trips_on_random_geometry(gpu, monkeypatch, seed):
     """k_cascade2 against k_cascade where the geometry is drawn: format, stage count, runs of 2 .. 40 tiles, ragged call splits that leave
     the stream at any phase of a decimation group (tools/gpu/r5_casc2_stress.py draws 80 of these per run).  Bytes must be equal."""
     rng = np.random.default_rng(seed)
     shapes = [("cu8", 20e6, 1488375.0), ("cu8", 20e6, 744187.5), ("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 46511.71875),
-              ("cs16", 20e6, 1488375.0), ("sc16q11", 20e6, 744187.5)]
+              ("cs16", 20e6, 1488375.0), ("sc16q11", 20e6, 744187.5), ("cs8", 20e6, 1488375.0), ("cs8", 20e6, 400e3)]
     fmt, ri, ro = shapes[int(rng.integers(len(shapes)))]
     block = int(rng.integers(2, 41)) * 8192
     total = int(rng.integers(1 << 20, 3 << 20))

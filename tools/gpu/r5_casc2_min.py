@@ -9,11 +9,11 @@ if len(sys.argv) > 1:
     import iq_tool_amd
     from iq_tool_amd import synth
     from iq_tool_amd.chain import DeviceBuffer
-    for fmt, rate, target in (("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 46511.71875)):
-        bpf = 2 if fmt == "cu8" else 4
+    for fmt, rate, target in (("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 46511.71875), ("cs8", 20e6, 400e3)):
+        bpf = 2 if fmt in ("cu8", "cs8") else 4
         raw = np.tile(synth.raw_stream(1 << 21, rate, 3, fmt), 1 << 6)
         d_in = DeviceBuffer(raw.nbytes); d_in.upload(raw)
-        for lg in range(21, 28):
+        for lg in (range(21, 28) if fmt != "cs8" else (24, 27)):
             n = 1 << lg
             ch = iq_tool_amd.Chain(in_format=fmt, out_format=fmt, input_rate_hz=rate, target_rate_hz=target)
             d_out = DeviceBuffer(ch.out_bytes * (ch.max_out_frames(n) + 64))

@@ -10,7 +10,7 @@ def cases(seed, n):
     rng = np.random.default_rng(seed)
     out = []
     shapes = [("cu8", 20e6, 1488375.0), ("cu8", 20e6, 744187.5), ("cu8", 61.44e6, 1488375.0), ("cs16", 2.4e6, 46511.71875),
-              ("cs16", 20e6, 1488375.0), ("sc16q11", 20e6, 744187.5), ("cs16", 10e6, 700e3)]
+              ("cs16", 20e6, 1488375.0), ("sc16q11", 20e6, 744187.5), ("cs16", 10e6, 700e3), ("cs8", 20e6, 744187.5), ("cs8", 20e6, 400e3)]
     for _ in range(n):
         fmt, ri, ro = shapes[int(rng.integers(len(shapes)))]
         block = int(rng.integers(2, 41)) * 8192
