@@ -135,7 +135,7 @@ int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (on("IQGPU_FFT_NO_R16") ? kDbgFftNoR16 : 0u) | (on("IQGPU_NO_FAT") ? kDbgNoFat : 0u) |
                  (on("IQGPU_FORCE_FAT") ? kDbgForceFat : 0u) | (on("IQGPU_FAT") ? kDbgUseFat : 0u) | (on("IQGPU_MID8") ? kDbgMid8 : 0u) |
                  (on("IQGPU_NO_S2") ? kDbgNoS2 : 0u) | (on("IQGPU_NO_FUSED_MOVE") ? kDbgNoFusedMove : 0u) | (on("IQGPU_NO_P0") ? kDbgNoP0 : 0u) |
-                 (on("IQGPU_NO_CASC2") ? kDbgNoCasc2 : 0u);
+                 (on("IQGPU_NO_CASC2") ? kDbgNoCasc2 : 0u) | (on("IQGPU_NO_MID_8BIT") ? kDbgNoMid8bit : 0u);
         if (const char *tf = getenv("IQGPU_TAP_FOLD")) c->tap_fold_env = atoi(tf) != 0 ? 1 : 0;
         if (const char *v = getenv("IQGPU_STEAL")) c->steal = v[0] == '1';
         if (const char *v = getenv("IQGPU_STEAL_MIN")) { const int x = atoi(v); if (x >= 2 && x < 100000) c->steal_min = x; }

@@ -79,7 +79,9 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // STEAL (run stealing, kernels.hpp): the run's end is whatever the wave's descriptor `desc` says when a tile is claimed -- one
 // returning agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
 // CF32OUT: the outputs leave as cf32 (a user filter behind the resampler: the -usb / -lsb presets) instead of packed cs16
-template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false>
+// INF / OUT8 (late round 5): 8-bit frames in (IQGPU_FMT_CU8 / _CS8 instead of _CS16: unpacked to normalised floats, so nothing rides on
+// the table or the taps) and 8-bit frames out (1 = cu8, 2 = cs8; 0 = cs16 or cf32 as CF32OUT says)
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false, int INF = IQGPU_FMT_CS16, int OUT8 = 0>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, int64_t T_emit1, unsigned long long *const desc)
 {
@@ -144,15 +146,24 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // coalesced loads, HBM sees them once) instead of writing them to LDS for another lane to read: no XO stream at all.
     RawChunk nxt[G::NC], nxo[G::NC];
     v2f cs_n[G::NC][2], cs_o[NL];
+    constexpr bool IN8 = INF != IQGPU_FMT_CS16;          // 2-byte frames: the same frames per lane from 8-byte loads
+    constexpr int VB = IN8 ? 2 : 4;
     auto load_even = [&](int64_t T) {
-        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * 4 + 16 * lane;
+        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * VB + 4 * VB * lane;
 #pragma unroll
-        for (int c = 0; c < G::NC; ++c) load_chunk<4>(src + 1024 * c, nxt[c]);
+        for (int c = 0; c < G::NC; ++c) load_chunk<VB>(src + 256 * VB * c, nxt[c]);
     };
     auto load_odd = [&](int64_t T) {
-        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * 4 + 8 * NL * lane - 80;
+        const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * VB + 2 * VB * NL * lane - 20 * VB;
 #pragma unroll
-        for (int c = 0; c < G::NC; ++c) load_chunk<4>(src + 16 * c, nxo[c]);
+        for (int c = 0; c < G::NC; ++c) load_chunk<VB>(src + 4 * VB * c, nxo[c]);
+    };
+    // one frame (its 16 bits in the low half of h) as floats: 8-bit frames normalised the way unpack_chunk does it (cu8: one fused
+    // multiply-add whose product and sum are exact), 16-bit frames as integers (their 2^-15 rides on the table / the taps)
+    auto unp8 = [](uint32_t h) {
+        if (INF == IQGPU_FMT_CU8)
+            return v2f{__builtin_fmaf((float)(h & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f), __builtin_fmaf((float)((h >> 8) & 0xffu), 1.0f / 128.0f, -127.5f / 128.0f)};
+        return v2f{(float)(signed char)(h & 0xffu) * (1.0f / 128.0f), (float)(signed char)((h >> 8) & 0xffu) * (1.0f / 128.0f)};
     };
     // phase of a frame = theta0 + frame * dtheta (mod 2^32): the lane's share of the product once per run, the tile's share on the
     // scalar unit -- a v_mul_lo_u32 per chunk and tile is a quarter-rate instruction each (4 of the tile's ~340 VALU instructions,
@@ -220,9 +231,13 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         if (lane < 48) *(float *)(XE + sl_dst) = sl_e;
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
-            v2f x0 = v2f{(float)(short)(nxt[c].w[0] & 0xffffu), (float)(short)(nxt[c].w[0] >> 16)};      // 2^-15: in the table (taps when NONCO)
-            v2f x2 = v2f{(float)(short)(nxt[c].w[2] & 0xffffu), (float)(short)(nxt[c].w[2] >> 16)};
+            v2f x0, x2;
+            if (IN8) { x0 = unp8(nxt[c].w[0]); x2 = unp8(nxt[c].w[1]); }      // frames 0 and 2 of the lane's four: the low halves of its two words
+            else {
+            x0 = v2f{(float)(short)(nxt[c].w[0] & 0xffffu), (float)(short)(nxt[c].w[0] >> 16)};      // 2^-15: in the table (taps when NONCO)
+            x2 = v2f{(float)(short)(nxt[c].w[2] & 0xffffu), (float)(short)(nxt[c].w[2] >> 16)};
             keep(nxt[c].w[1]); keep(nxt[c].w[3]);       // (whole 16-byte loads: unused words declared used, or hipcc narrows them to dword loads)
+            }
             if (!NONCO) { x0 = pk_cmul(x0, cs_n[c][0]); x2 = pk_cmul(x2, cs_n[c][1]); }
             stq(XE + wq + G::CHUNKB * c, make_float4(x0.x, x0.y, x2.x, x2.y));
         }
@@ -240,13 +255,19 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     };
     // ---- centre taps: the lane's own six odd samples (words 1, 3, .. 11 of its second load), mixed with the half-scaled table
     auto V_centre = [&]() {
+        if (!IN8) {
 #pragma unroll
-        for (int c = 0; c < G::NC; ++c) { keep(nxo[c].w[0]); keep(nxo[c].w[2]); }
+            for (int c = 0; c < G::NC; ++c) { keep(nxo[c].w[0]); keep(nxo[c].w[2]); }
+        }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const uint32_t wd = nxo[(2 * i + 1) >> 2].w[(2 * i + 1) & 3];
-            const v2f o = v2f{(float)(short)(wd & 0xffffu), (float)(short)(wd >> 16)};
-            if (NONCO) { const float hc = 0.5f / 32768.0f; acc[i] = v2f{hc * o.x, hc * o.y}; }
+            v2f o;
+            if (IN8) o = unp8(nxo[i >> 1].w[i & 1] >> 16);      // frame 2 i + 1 of the lane's twelve: the high half of word i
+            else {
+                const uint32_t wd = nxo[(2 * i + 1) >> 2].w[(2 * i + 1) & 3];
+                o = v2f{(float)(short)(wd & 0xffffu), (float)(short)(wd >> 16)};
+            }
+            if (NONCO) { const float hc = IN8 ? 0.5f : 0.5f / 32768.0f; acc[i] = v2f{hc * o.x, hc * o.y}; }
             else acc[i] = pk_cmul(o, cs_o[i]);
         }
     };
@@ -288,6 +309,17 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #pragma unroll
             for (int j = 0; j < NS - 1; ++j) *(f32x2 *)(ob + 8 * j) = f32x2{y[j].x, y[j].y};
             if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(f32x2 *)(ob + 8 * (NS - 1)) = f32x2{y[NS - 1].x, y[NS - 1].y};
+        } else if constexpr (OUT8 != 0) {
+            // 2-byte frames at a 2-byte-aligned address: the lane's NS - 1 or NS outputs as dwords and a short
+            static_assert(NS == 4, "8-bit output: six outputs per lane only");
+            typedef uint32_t u32a2 __attribute__((aligned(2)));
+            uint32_t pk[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) pk[j] = pack_b8(cf2{y[j].x, y[j].y}, OUT8 == 1);
+            char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 2;
+            *(u32a2 *)ob = pk[0] | (pk[1] << 16);
+            if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(u32a2 *)(ob + 4) = pk[2] | (pk[3] << 16);
+            else *(uint16_t *)(ob + 4) = (uint16_t)pk[2];
         } else {
         uint32_t pk[NS];
 #pragma unroll
@@ -522,7 +554,7 @@ __device__ __forceinline__ bool steal_run(const FrontArgs &a, const int64_t gw, 
 }
 
 // NONCO: the same shape without a shift (no mixer; the 2^-15 rides on the half-band taps, launch_front_mid scales hb0)
-template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false>
+template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false, int INF = IQGPU_FMT_CS16, int OUT8 = 0>
 __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 {
     typedef MidGeom<NL> G;
@@ -540,7 +572,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 
     if (!NONCO) {
         const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;               // mix down: conj(phasor)
-        const float scl = 1.0f / 32768.0f;                             // the cs16 normaliser, folded into the table (exact)
+        const float scl = INF == IQGPU_FMT_CS16 ? 1.0f / 32768.0f : 1.0f;   // the cs16 normaliser, folded into the table (exact)
         for (int i = tid; i < 1024; i += kMidThreads) {
             const cf2 v = a.nco_tab[i];
             s_nco[i] = cf2{v.x * scl, sgn * v.y * scl};
@@ -579,7 +611,9 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         w.nco = s_nco; w.arb = s_arb;
         w.arb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_arb;
         const int64_t o0 = e0 * G::TILE / 512, o1 = (e1 * G::TILE + 511) / 512;
-        run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
+        // (8-bit frames in: the run-time-switched tile routine -- the table above is the plain one then)
+        if constexpr (INF == IQGPU_FMT_CS16) run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
+        else run_tiles<2, true, false, false, AGC, false>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
         if (r >= a.w_n_stream || (a.w_run_stride > 0 && r >= a.w_run_stride)) return;
@@ -596,14 +630,14 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
     w.tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
     unsigned n_stolen = 0;
     if constexpr (!STEAL) {
-        if (have) run_mid<NL, NONCO, L3, L4, AGC, false, CF32OUT>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, nullptr);
+        if (have) run_mid<NL, NONCO, L3, L4, AGC, false, CF32OUT, INF, OUT8>(a, w, lane, t0 - a.w_warm_tiles, t0, t1, nullptr);
     } else {
         for (;;) {
             // (the lane index made opaque per run: nothing a run derives from it is then hoisted out of this loop and held --
             //  spilled -- across the tile loop of every run)
             int ln = (int)__lane_id();
             asm volatile("" : "+v"(ln));
-            if (have) run_mid<NL, NONCO, L3, L4, AGC, true, CF32OUT>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
+            if (have) run_mid<NL, NONCO, L3, L4, AGC, true, CF32OUT, INF, OUT8>(a, w, ln, t0 - a.w_warm_tiles, t0, t1, a.w_steal + (size_t)gw * (size_t)a.w_steal_stride);
             if (a.w_run_stride > 0) {
                 // fixed-length runs: the workgroup's next one (an LDS add: no memory traffic, nothing to reset between launches)
                 unsigned k = 0u;
@@ -692,13 +726,16 @@ int front_mid_nl(const FrontArgs &a)
 {
     // (cf32 out: a user filter behind the resampler takes the samples -- the -usb / -lsb presets; six outputs per lane, no fused AGC)
     const bool cf32_out = a.out_fmt == IQGPU_FMT_CF32 && !a.agc_fused;
-    if (!(a.S == 1 && a.in_fmt == IQGPU_FMT_CS16 && (a.out_fmt == IQGPU_FMT_CS16 || cf32_out) && a.gain == 1.0f && !a.iq_enable && !a.dc_enable &&
-          a.pnco_mode == 0 && !(a.dbg & (kDbgNoFast | kDbgNoFat)))) return 0;
+    // (late round 5: 8-bit frames on either side -- cu8 / cs8 in, cu8 / cs8 out, any mix with cs16 and cf32 -- six outputs per lane)
+    const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8, out8 = a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
+    const bool any8 = (in8 || out8) && !(a.dbg & kDbgNoMid8bit);
+    if (!(a.S == 1 && (a.in_fmt == IQGPU_FMT_CS16 || (in8 && any8)) && (a.out_fmt == IQGPU_FMT_CS16 || cf32_out || (out8 && any8)) && a.gain == 1.0f &&
+          !a.iq_enable && !a.dc_enable && a.pnco_mode == 0 && !(a.dbg & (kDbgNoFast | kDbgNoFat)))) return 0;
     int l3, l4;
     for (int nl : {8, 6}) {
         // 8 per lane is an experiment (IQGPU_MID8=1): in 168 VGPRs it has no room to fetch a phase ahead, and without that it runs
         // 0.440 ms against 0.384 for 6 per lane on the NRSC-5 chain; with the fused AGC it does not fit at all
-        if (nl == 8 && (!(a.dbg & kDbgMid8) || a.agc_fused || cf32_out)) continue;
+        if (nl == 8 && (!(a.dbg & kDbgMid8) || a.agc_fused || cf32_out || any8)) continue;
         if (!mid_class(a.step, nl, &l3, &l4)) continue;
         if (a.agc_fused && !(a.agc_shift == 1 && a.agc_chunk_frames >= 128 * nl)) continue;
         return nl;
@@ -711,14 +748,15 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
 {
     const bool nonco = a_in.nco_mode == 0;
     FrontArgs a = a_in;
-    if (nonco) for (float &h : a.hb0) h *= 1.0f / 32768.0f;           // the cs16 normaliser rides on the half-band taps (exact: a power of two)
+    const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8, out8 = a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
+    if (nonco && !in8) for (float &h : a.hb0) h *= 1.0f / 32768.0f;  // the cs16 normaliser rides on the half-band taps (exact: a power of two)
     const int nl = front_mid_nl(a);
     int l3 = 0, l4 = 0;
     if (nl == 0 || !mid_class(a.step, nl, &l3, &l4)) return hipErrorInvalidValue;
     const size_t lds = mid_lds_bytes(nl, nonco);
     // (fixed-length runs dealt out inside a workgroup need the multi-run instantiation, which exists for six outputs per lane only:
     //  any other shape gets one static run per wave, however the caller filled w_run_stride)
-    if (nl != 6 || a.w_steal == nullptr || a.out_fmt == IQGPU_FMT_CF32) { a.w_run_stride = 0; if (a.out_fmt == IQGPU_FMT_CF32) a.w_steal = nullptr; }
+    if (nl != 6 || a.w_steal == nullptr || a.out_fmt == IQGPU_FMT_CF32 || in8 || out8) { a.w_run_stride = 0; if (a.out_fmt == IQGPU_FMT_CF32 || in8 || out8) a.w_steal = nullptr; }
     const int64_t n_items = a.w_n_edge + (a.w_run_stride > 0 && a.w_run_stride < a.w_n_stream ? a.w_run_stride : a.w_n_stream);
     const unsigned grid = (unsigned)((n_items + kMidWaves - 1) / kMidWaves);
     if (grid == 0) return hipSuccess;
@@ -747,6 +785,39 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
         else if (a.agc_fused) IQGPU_LAUNCH_MID(NL, false, L3, L4, (NL == 6));                                       \
         else IQGPU_LAUNCH_MID(NL, false, L3, L4, false);                                                            \
     } while (0)
+    if (in8 || out8) {
+        // 8-bit frames: six per lane, static runs; INF / OUT8 as the formats say, CF32OUT for a filter behind
+        if (nl != 6 || (cf && a.agc_fused)) return hipErrorInvalidValue;
+#define IQGPU_LAUNCH_MID8C(NONCO, L3, AGC, CF, INF, O8)                                                             \
+        do {                                                                                                          \
+            static LdsAttrCache cache;                                                                                \
+            { const hipError_t e = cache.ensure((const void *)k_front_mid<6, NONCO, L3, 0, AGC, false, CF, INF, O8>, lds); if (e != hipSuccess) return e; } \
+            hipLaunchKernelGGL((k_front_mid<6, NONCO, L3, 0, AGC, false, CF, INF, O8>), dim3(grid), dim3(kMidThreads), lds, s, a); \
+        } while (0)
+#define IQGPU_LAUNCH_MID8B(NONCO, L3, INF)                                                                          \
+        do {                                                                                                          \
+            if (cf) IQGPU_LAUNCH_MID8C(NONCO, L3, false, true, INF, 0);                                              \
+            else if (a.out_fmt == IQGPU_FMT_CU8 && a.agc_fused) IQGPU_LAUNCH_MID8C(NONCO, L3, true, false, INF, 1);  \
+            else if (a.out_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_MID8C(NONCO, L3, false, false, INF, 1);                \
+            else if (a.out_fmt == IQGPU_FMT_CS8 && a.agc_fused) IQGPU_LAUNCH_MID8C(NONCO, L3, true, false, INF, 2);  \
+            else if (a.out_fmt == IQGPU_FMT_CS8) IQGPU_LAUNCH_MID8C(NONCO, L3, false, false, INF, 2);                \
+            else if (INF != IQGPU_FMT_CS16 && a.agc_fused) IQGPU_LAUNCH_MID8C(NONCO, L3, true, false, INF, 0);       \
+            else if (INF != IQGPU_FMT_CS16) IQGPU_LAUNCH_MID8C(NONCO, L3, false, false, INF, 0);                     \
+            else return hipErrorInvalidValue;                                                                         \
+        } while (0)
+#define IQGPU_LAUNCH_MID8A(NONCO, L3)                                                                               \
+        do {                                                                                                          \
+            if (a.in_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CU8);                             \
+            else if (a.in_fmt == IQGPU_FMT_CS8) IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CS8);                        \
+            else IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CS16);                                                      \
+        } while (0)
+        if (l3 == 4) { if (nonco) IQGPU_LAUNCH_MID8A(true, 4); else IQGPU_LAUNCH_MID8A(false, 4); }
+        else         { if (nonco) IQGPU_LAUNCH_MID8A(true, 5); else IQGPU_LAUNCH_MID8A(false, 5); }
+#undef IQGPU_LAUNCH_MID8A
+#undef IQGPU_LAUNCH_MID8B
+#undef IQGPU_LAUNCH_MID8C
+        return hipGetLastError();
+    }
     if (nl == 6 && l3 == 4) IQGPU_LAUNCH_MID2(6, 4, 0);
     else if (nl == 6) IQGPU_LAUNCH_MID2(6, 5, 0);
     else if (l3 == 4) IQGPU_LAUNCH_MID2(8, 4, 6);

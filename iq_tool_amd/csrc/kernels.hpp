@@ -64,6 +64,7 @@ struct cd2 { double x, y; };
 // environment ONCE, in iqgpu_chain_create, and carried in the launch arguments -- the launch path itself never calls getenv
 enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT = 8u, kDbgFftNoR16 = 16u, kDbgNoFat = 32u, kDbgForceFat = 64u, kDbgUseFat = 128u, kDbgMid8 = 256u,
                   kDbgNoS2 = 512u,         // IQGPU_NO_S2=1: two-stage chains keep k_cascade + k_front_s1 instead of the fused k_front_s2
+                  kDbgNoMid8bit = 8192u,   // IQGPU_NO_MID_8BIT=1: S = 1 chains with 8-bit frames on either side keep k_front_s1 instead of k_front_mid
                   kDbgNoCasc2 = 4096u,     // IQGPU_NO_CASC2=1: raw cu8 cascades keep k_cascade's one tile per trip instead of k_cascade2's two
                   kDbgNoP0 = 2048u,        // IQGPU_NO_P0=1: chains without a half-band stage keep k_front_s1<S0> instead of k_front_p0
                   kDbgNoFusedMove = 1024u }; // IQGPU_NO_FUSED_MOVE=1: the filter's history moves by a copy kernel, not inside the filter kernel

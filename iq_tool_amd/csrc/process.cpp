@@ -220,7 +220,11 @@ int Call::stage_front()
         // (k_front_p0: consecutive lanes are five outputs apart -- for the NRSC-5 step 16 arms -- so the lanes that re-read a slot in
         //  the same step would meet in two bank pairs of a linear plane: always the folded placement)
         if (p0) a.tap_fold = 1u;
-        if (mid) snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "");
+        if (mid) {
+            const bool b8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
+            snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "",
+                     b8 ? ",8bit" : "");
+        }
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : p0 ? launch_front_p0(a, c->stream) : launch_front_s1(a, c->stream)); }
         if (front_fused()) { const int rc = stage_agc_verify_and_fallback(a); if (rc) return rc; }

@@ -950,6 +950,57 @@ def test_mid_kernel_in_front_of_a_user_filter(gpu, oracle, monkeypatch, shift_hz
         int_close(ref, run_oracle(oracle, raw, **kw), min_same=0.995)
 
 
+@pytest.mark.parametrize("in_format,out_format,shift_hz,extra", [
+    ("cu8", "cu8", 200e3, {}),                    # an RTL-SDR capture through the headline chain
+    ("cu8", "cs16", 0.0, {}),                     # ... without a mixer, 16-bit frames out
+    ("cs8", "cs8", -150e3, {}),                   # signed 8-bit frames (a HackRF's)
+    ("cs16", "cu8", 200e3, {}),                   # 16-bit in, 8-bit out
+    ("cs8", "cs16", 0.0, dict(target_rate_hz=2.4e6 / 3.25)),      # the other step class of six per lane
+    ("cu8", "cu8", 0.0, dict(agc=True)),          # the fused digital AGC on 8-bit frames
+    ("cu8", "cs16", 100e3, dict(filters=(("passband", 158.5e3, 113e3),))),   # cf32 out to a user filter behind the resampler
+])
+def test_mid_kernel_on_eight_bit_frames(gpu, oracle, monkeypatch, in_format, out_format, shift_hz, extra):
+    """Late round 5: k_front_mid with 8-bit frames on either side (the lane's four frames of a chunk from one 8-byte load, unpacked to
+    normalised floats, so nothing rides on the mixer's table or the taps; 2-byte frames out through pack_b8) against k_front_s1
+    (IQGPU_NO_MID_8BIT=1).  Same products in the same order: the bytes must be equal -- whole calls, ragged splits that change kernel
+    from call to call, a reset -- and close to the oracle."""
+    agc, filt = bool(extra.get("agc")), "filters" in extra
+    n = int(2.4e6 * 4.5) if agc else 3_300_001
+    raw = synth.raw_stream(n, 2.4e6, 61, in_format)
+    per = raw.size // n
+    kw = dict(NRSC5, in_format=in_format, out_format=out_format, shift_hz=shift_hz, **extra)
+    c16 = 16384
+    splits = [[n]] if (agc or filt) else [[n], [1_500_000, 8, 4088, n - 1_504_096], [1_000_003, n - 1_000_003]]
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos, names = [], 0, []
+        for k in split:
+            outs.append(ch.process(raw[per * pos:per * (pos + k)])); pos += k
+            names.append(ch.front_kernel())
+        st = ch.agc_state() if agc else None
+        ch.reset()
+        outs.append(ch.process(raw[:per * 1_200_000]))
+        return np.concatenate(outs), names, st
+
+    monkeypatch.setenv("IQGPU_NO_MID_8BIT", "1")
+    refs = [run(sp) for sp in splits]
+    assert all(nm == "k_front_s1" for r in refs for nm in r[1])
+    monkeypatch.delenv("IQGPU_NO_MID_8BIT")
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # calls of any length (the size rule keeps short calls on k_front_s1)
+    want_name = "k_front_mid<6,%s%s,8bit>" % ("nco" if shift_hz else "nonco", ",cf32" if filt else "")
+    for sp, (ref, _, st_ref) in zip(splits, refs):
+        got, names, st = run(sp)
+        assert want_name in names, names
+        assert got.size == ref.size
+        assert np.array_equal(got, ref), (sp, names, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+        assert st == st_ref
+    monkeypatch.delenv("IQGPU_FORCE_FAT")
+    if not agc:
+        want = run_oracle(oracle, raw, **kw)
+        int_close(refs[0][0][:want.size], want, min_same=0.995)
+
+
 @pytest.mark.parametrize("target_hz", [744187.5, 2.4e6 / 3.25, 696000.0])
 @pytest.mark.parametrize("variant", ["fat", "mid"])
 def test_tap_placement_does_not_change_a_bit(gpu, monkeypatch, target_hz, variant):

@@ -164,7 +164,7 @@ def check_claims(lines):
             if t and not t.startswith((";", ".")) or t.startswith(".LBB"):
                 funcs[cur].append(t)
     for name, ins in funcs.items():
-        if not re.search(r"ELb1ELb[01]EEEvNS_9FrontArgsE$", name):       # STEAL (the template's last bool but one; CF32OUT follows it) = false: no claims at all
+        if not re.search(r"ELb1ELb[01](ELi\d+ELi\d+)?EEEvNS_9FrontArgsE$", name):       # STEAL (the template's last bool but one; CF32OUT, INF, OUT8 follow it) = false: no claims at all
             if any(t.startswith("global_atomic_add_x2") and t.endswith("sc0") for t in ins):
                 errors.append("k_front_mid: %s (no stealing) holds a returning atomic add" % name)
             continue

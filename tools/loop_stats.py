@@ -14,7 +14,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = [("front_wave.hip", "_ZN5iqgpu10k_front_s1ILi4ELb1ELb0ELb0ELi0EEEvNS_9FrontArgsE:", 512, 130),
            ("front_fat.hip", "_ZN5iqgpu11k_front_fatILb0ELi4ELi6EEEvNS_9FrontArgsE:", 1024, 230),
-           ("front_mid.hip", "_ZN5iqgpu11k_front_midILi6ELb0ELi4ELi0ELb0EEEvNS_9FrontArgsE:", 768, 180)]
+           ("front_mid.hip", "_ZN5iqgpu11k_front_midILi6ELb0ELi4ELi0ELb0ELb0ELb0ELi11ELi0EEEvNS_9FrontArgsE:", 768, 180)]
 
 
 def loops_of(path, name):
