@@ -71,6 +71,14 @@ PRESETS = {
     "cs16-fm-nrsc5-lsb": _preset("cs16", 744187.5, (-215e3, -102e3)),
     "cs16-am-nrsc5": _preset("cs16", 46511.71875),
 }
+# the headline chain (BASELINE configs[1]: 2.4 MS/s -> 744.1875 kS/s, + 200 kHz) on the 8-bit sample formats of the common dongles -- an
+# RTL-SDR's cu8, a HackRF's cs8 -- and with 8-bit output: not presets of the reference, but what its `--raw-file-input-sample-format
+# cu8|cs8` users run (`secondary.eight_bit`)
+NEAR = {
+    "cu8-to-cu8": dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3),
+    "cs8-to-cs16": dict(in_format="cs8", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3),
+    "cs16-to-cu8": dict(in_format="cs16", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3),
+}
 BLOCK_SAMPLES = 0               # auto: one contiguous run of tiles per resident wavefront
 SEGMENT_LOG2 = 22              # synthetic segment generated on the host, tiled on the device
 
@@ -295,10 +303,10 @@ def run_case(args, dist, dev, local_rank, world, rank, config, preset, steps, wa
     from iq_tool_amd import synth
     chain_kw, rate, fmt, in_bps, workload = (dict(CHAIN, agc=True) if preset else CHAIN), 2.4e6, "cs16", 4, None
     if shipped:
-        chain_kw = PRESETS[shipped]
+        chain_kw = PRESETS[shipped] if shipped in PRESETS else NEAR[shipped]
         fmt = chain_kw["in_format"]
-        in_bps = 2 if fmt == "cu8" else 4
-        workload = "preset %s on a 2.4 MS/s %s capture" % (shipped, fmt)
+        in_bps = 2 if fmt in ("cu8", "cs8") else 4
+        workload = "%s %s on a 2.4 MS/s %s capture" % ("preset" if shipped in PRESETS else "the headline chain", shipped, fmt)
     elif config != 2:
         o = OTHER[config]
         chain_kw, rate, fmt, in_bps, workload = o["chain"], o["rate"], o["fmt"], o["bps"], o["workload"]
@@ -443,6 +451,24 @@ def shipped_presets(args, dist, dev, local_rank, world, rank):
                          "timed_stages_per_step": round(sum(v["launches"] for v in c["prof"].values()) / max(c["steps"], 1), 2),
                          "chain": "%s 2.4 MS/s -> %s %.5f kS/s, digital AGC%s" % (PRESETS[name]["in_format"], PRESETS[name]["out_format"],
                                   PRESETS[name]["target_rate_hz"] / 1e3, ", complex band-pass behind the resampler" if "filters" in PRESETS[name] else "")}
+            c["chain"].close()
+        except Exception as exc:
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
+    return out
+
+
+def eight_bit_shapes(args, dist, dev, local_rank, world, rank):
+    """the headline chain on 8-bit frames (NEAR): ms per 2^28-frame step, HBM fraction, the kernel that ran"""
+    import torch
+    out = {}
+    for name in NEAR:
+        try:
+            c = run_case(args, dist, dev, local_rank, world, rank, 2, False, args.secondary_steps, 2, args.preset_settle, 28, shipped=name)
+            out[name] = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "frames_per_step": c["frames"],
+                         "MSps": round(world * c["steps"] * c["frames"] / c["dt"] / 1e6, 1),
+                         "hbm_GBs": round(c["achieved"], 1), "frac": round(c["achieved"] / HBM_PEAK_GBS, 4), "kernel_ms": round(c["k_ms"], 4),
+                         "front_kernel": c["chain"].front_kernel()}
             c["chain"].close()
         except Exception as exc:
             out[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -712,6 +738,10 @@ def main():
                 sec["presets"] = shipped_presets(args, dist, dev, local_rank, world, rank)
             except Exception as exc:
                 sec["presets"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                sec["eight_bit"] = eight_bit_shapes(args, dist, dev, local_rank, world, rank)
+            except Exception as exc:
+                sec["eight_bit"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # ---- the CPU pipeline "in the same run" (north_star), at every N: rank 0 times it on its own host cores once the GPU legs of
     # all ranks are behind the barrier (the other ranks are done and idle; a 1-rank run needs no barrier)
     if dist is not None:
