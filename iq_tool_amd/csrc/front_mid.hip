@@ -30,6 +30,7 @@ namespace iqgpu {
 #ifndef IQGPU_MID_WAVES
 #define IQGPU_MID_WAVES 12
 #endif
+constexpr int kMidN16 = 116;                  // INF of k_front_mid: 16-bit frames normalised at the unpack (a gain, sc16q11)
 constexpr int kMidWaves = IQGPU_MID_WAVES;    // (16 is an experiment: only the shape without a mixer fits LDS and 128 VGPRs then)
 constexpr int kMidThreads = kMidWaves * 64;
 // NL = half-band outputs per lane: 6 (768-frame tiles; rows need no padding: 6 cf32 = 48 bytes = 3 slots of 16, an odd number, so a
@@ -80,7 +81,8 @@ struct MidLds { char *XE; const cf2 *nco; unsigned tap_lds; };
 // returning agent-scope add per tile, issued in front of the tile and read behind it (a tile is 3 us, the add comes back in 1).
 // CF32OUT: the outputs leave as cf32 (a user filter behind the resampler: the -usb / -lsb presets) instead of packed cs16
 // INF / OUT8 (late round 5): 8-bit frames in (IQGPU_FMT_CU8 / _CS8 instead of _CS16: unpacked to normalised floats, so nothing rides on
-// the table or the taps) and 8-bit frames out (1 = cu8, 2 = cs8; 0 = cs16 or cf32 as CF32OUT says)
+// the table or the taps), 16-bit frames with a gain or of the sc16q11 scale (kMidN16: normalised and gained by one product at the
+// unpack) and 8-bit frames out (1 = cu8, 2 = cs8; 0 = cs16 or cf32 as CF32OUT says)
 template <int NL, bool NONCO, int L3, int L4, bool AGC, bool STEAL, bool CF32OUT = false, int INF = IQGPU_FMT_CS16, int OUT8 = 0>
 __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, const int lane,
                                         const int64_t T_begin, const int64_t T_emit0, int64_t T_emit1, unsigned long long *const desc)
@@ -146,8 +148,13 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // coalesced loads, HBM sees them once) instead of writing them to LDS for another lane to read: no XO stream at all.
     RawChunk nxt[G::NC], nxo[G::NC];
     v2f cs_n[G::NC][2], cs_o[NL];
-    constexpr bool IN8 = INF != IQGPU_FMT_CS16;          // 2-byte frames: the same frames per lane from 8-byte loads
+    constexpr bool IN8 = INF == IQGPU_FMT_CU8 || INF == IQGPU_FMT_CS8;      // 2-byte frames: the same frames per lane from 8-byte loads
+    constexpr bool N16 = INF == kMidN16;                 // 16-bit frames with a gain, or sc16q11: normalised (and gained) at the unpack
+    constexpr bool NORM = IN8 || N16;                    // the samples are normalised floats: nothing rides on the table or the taps
     constexpr int VB = IN8 ? 2 : 4;
+    // (s 2^-15) g as s (g 2^-15): the scale is exact, so the one product rounds to what the reference's two do
+    const float sc16 = a.gain * (a.in_fmt == IQGPU_FMT_SC16Q11 ? 1.0f / 2048.0f : 1.0f / 32768.0f);
+    const bool gained = a.gain != 1.0f;
     auto load_even = [&](int64_t T) {
         const char *src = (const char *)a.raw + (T * G::TILE - a.rem0) * VB + 4 * VB * lane;
 #pragma unroll
@@ -232,11 +239,14 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
             v2f x0, x2;
-            if (IN8) { x0 = unp8(nxt[c].w[0]); x2 = unp8(nxt[c].w[1]); }      // frames 0 and 2 of the lane's four: the low halves of its two words
-            else {
+            if (IN8) {
+                x0 = unp8(nxt[c].w[0]); x2 = unp8(nxt[c].w[1]);      // frames 0 and 2 of the lane's four: the low halves of its two words
+                if (gained) { x0 = v2f{x0.x * a.gain, x0.y * a.gain}; x2 = v2f{x2.x * a.gain, x2.y * a.gain}; }      // (wave-uniform)
+            } else {
             x0 = v2f{(float)(short)(nxt[c].w[0] & 0xffffu), (float)(short)(nxt[c].w[0] >> 16)};      // 2^-15: in the table (taps when NONCO)
             x2 = v2f{(float)(short)(nxt[c].w[2] & 0xffffu), (float)(short)(nxt[c].w[2] >> 16)};
             keep(nxt[c].w[1]); keep(nxt[c].w[3]);       // (whole 16-byte loads: unused words declared used, or hipcc narrows them to dword loads)
+            if (N16) { x0 = v2f{x0.x * sc16, x0.y * sc16}; x2 = v2f{x2.x * sc16, x2.y * sc16}; }
             }
             if (!NONCO) { x0 = pk_cmul(x0, cs_n[c][0]); x2 = pk_cmul(x2, cs_n[c][1]); }
             stq(XE + wq + G::CHUNKB * c, make_float4(x0.x, x0.y, x2.x, x2.y));
@@ -262,12 +272,15 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             v2f o;
-            if (IN8) o = unp8(nxo[i >> 1].w[i & 1] >> 16);      // frame 2 i + 1 of the lane's twelve: the high half of word i
-            else {
+            if (IN8) {
+                o = unp8(nxo[i >> 1].w[i & 1] >> 16);           // frame 2 i + 1 of the lane's twelve: the high half of word i
+                if (gained) o = v2f{o.x * a.gain, o.y * a.gain};
+            } else {
                 const uint32_t wd = nxo[(2 * i + 1) >> 2].w[(2 * i + 1) & 3];
                 o = v2f{(float)(short)(wd & 0xffffu), (float)(short)(wd >> 16)};
+                if (N16) o = v2f{o.x * sc16, o.y * sc16};
             }
-            if (NONCO) { const float hc = IN8 ? 0.5f : 0.5f / 32768.0f; acc[i] = v2f{hc * o.x, hc * o.y}; }
+            if (NONCO) { const float hc = NORM ? 0.5f : 0.5f / 32768.0f; acc[i] = v2f{hc * o.x, hc * o.y}; }
             else acc[i] = pk_cmul(o, cs_o[i]);
         }
     };
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
 
     if (!NONCO) {
         const float sgn = a.nco_mode < 0 ? -1.0f : 1.0f;               // mix down: conj(phasor)
-        const float scl = INF == IQGPU_FMT_CS16 ? 1.0f / 32768.0f : 1.0f;   // the cs16 normaliser, folded into the table (exact)
+        const float scl = INF == IQGPU_FMT_CS16 ? 1.0f / 32768.0f : 1.0f;   // the cs16 normaliser, folded into the table (exact); every other INF: plain
         for (int i = tid; i < 1024; i += kMidThreads) {
             const cf2 v = a.nco_tab[i];
             s_nco[i] = cf2{v.x * scl, sgn * v.y * scl};
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(kMidThreads) void k_front_mid(const FrontArgs a)
         const int64_t o0 = e0 * G::TILE / 512, o1 = (e1 * G::TILE + 511) / 512;
         // (8-bit frames in: the run-time-switched tile routine -- the table above is the plain one then)
         if constexpr (INF == IQGPU_FMT_CS16) run_tiles<4, true, true, false, AGC, NONCO>(a, w, lane, o0 - 1, o0, o1, 0);
+        else if constexpr (INF == kMidN16) run_tiles<4, true, false, false, AGC, false>(a, w, lane, o0 - 1, o0, o1, 0);
         else run_tiles<2, true, false, false, AGC, false>(a, w, lane, o0 - 1, o0, o1, 0);
     } else {
         const int64_t r = gw - a.w_n_edge;
@@ -728,8 +742,11 @@ int front_mid_nl(const FrontArgs &a)
     const bool cf32_out = a.out_fmt == IQGPU_FMT_CF32 && !a.agc_fused;
     // (late round 5: 8-bit frames on either side -- cu8 / cs8 in, cu8 / cs8 out, any mix with cs16 and cf32 -- six outputs per lane)
     const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8, out8 = a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
-    const bool any8 = (in8 || out8) && !(a.dbg & kDbgNoMid8bit);
-    if (!(a.S == 1 && (a.in_fmt == IQGPU_FMT_CS16 || (in8 && any8)) && (a.out_fmt == IQGPU_FMT_CS16 || cf32_out || (out8 && any8)) && a.gain == 1.0f &&
+    // ... and 16-bit frames with a gain or of the sc16q11 scale (normalised at the unpack: front_mid_inf)
+    const bool n16 = (a.in_fmt == IQGPU_FMT_CS16 && a.gain != 1.0f) || a.in_fmt == IQGPU_FMT_SC16Q11;
+    const bool any8 = (in8 || out8 || n16) && !(a.dbg & kDbgNoMid8bit);
+    if (!(a.S == 1 && ((a.in_fmt == IQGPU_FMT_CS16 && !n16) || ((in8 || n16) && any8)) && (a.out_fmt == IQGPU_FMT_CS16 || cf32_out || (out8 && any8)) &&
+          (a.gain == 1.0f || any8) && a.gain > 0.0f && a.gain < 1e30f &&
           !a.iq_enable && !a.dc_enable && a.pnco_mode == 0 && !(a.dbg & (kDbgNoFast | kDbgNoFat)))) return 0;
     int l3, l4;
     for (int nl : {8, 6}) {
@@ -748,7 +765,9 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
 {
     const bool nonco = a_in.nco_mode == 0;
     FrontArgs a = a_in;
-    const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8, out8 = a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
+    const bool n16 = (a.in_fmt == IQGPU_FMT_CS16 && a.gain != 1.0f) || a.in_fmt == IQGPU_FMT_SC16Q11;
+    const bool in8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8 || n16, out8 = a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
+    // (in8: every input that is normalised at the unpack -- the 8-bit formats and kMidN16)
     if (nonco && !in8) for (float &h : a.hb0) h *= 1.0f / 32768.0f;  // the cs16 normaliser rides on the half-band taps (exact: a power of two)
     const int nl = front_mid_nl(a);
     int l3 = 0, l4 = 0;
@@ -809,6 +828,7 @@ hipError_t launch_front_mid(const FrontArgs &a_in, hipStream_t s)
         do {                                                                                                          \
             if (a.in_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CU8);                             \
             else if (a.in_fmt == IQGPU_FMT_CS8) IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CS8);                        \
+            else if (n16) IQGPU_LAUNCH_MID8B(NONCO, L3, kMidN16);                                                    \
             else IQGPU_LAUNCH_MID8B(NONCO, L3, IQGPU_FMT_CS16);                                                      \
         } while (0)
         if (l3 == 4) { if (nonco) IQGPU_LAUNCH_MID8A(true, 4); else IQGPU_LAUNCH_MID8A(false, 4); }

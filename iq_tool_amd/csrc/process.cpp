@@ -222,8 +222,9 @@ int Call::stage_front()
         if (p0) a.tap_fold = 1u;
         if (mid) {
             const bool b8 = a.in_fmt == IQGPU_FMT_CU8 || a.in_fmt == IQGPU_FMT_CS8 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CS8;
-            snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "",
-                     b8 ? ",8bit" : "");
+            const bool n16 = (a.in_fmt == IQGPU_FMT_CS16 && a.gain != 1.0f) || a.in_fmt == IQGPU_FMT_SC16Q11;
+            snprintf(mid_name, sizeof(mid_name), "k_front_mid<%d,%s%s%s%s>", mid_nl, c->nco_mode ? "nco" : "nonco", a.out_fmt == IQGPU_FMT_CF32 ? ",cf32" : "",
+                     b8 ? ",8bit" : "", n16 ? ",gain" : "");
         }
         { KernelTimer kt(c, IQGPU_K_FRONT); HIP_TRY(fat ? launch_front_fat(a, c->stream) : mid ? launch_front_mid(a, c->stream)
             : p0 ? launch_front_p0(a, c->stream) : launch_front_s1(a, c->stream)); }

@@ -958,11 +958,15 @@ def test_mid_kernel_in_front_of_a_user_filter(gpu, oracle, monkeypatch, shift_hz
     ("cs8", "cs16", 0.0, dict(target_rate_hz=2.4e6 / 3.25)),      # the other step class of six per lane
     ("cu8", "cu8", 0.0, dict(agc=True)),          # the fused digital AGC on 8-bit frames
     ("cu8", "cs16", 100e3, dict(filters=(("passband", 158.5e3, 113e3),))),   # cf32 out to a user filter behind the resampler
+    ("cs16", "cs16", 200e3, dict(gain=0.37)),     # 16-bit frames with a gain: normalised and gained by one product at the unpack
+    ("sc16q11", "cs16", 0.0, {}),                 # a BladeRF's Q11 frames
+    ("sc16q11", "cu8", -100e3, dict(gain=1.9, agc=True)),
+    ("cu8", "cs8", 200e3, dict(gain=2.5)),        # a gain on 8-bit frames
 ])
 def test_mid_kernel_on_eight_bit_frames(gpu, oracle, monkeypatch, in_format, out_format, shift_hz, extra):
     """Late round 5: k_front_mid with 8-bit frames on either side (the lane's four frames of a chunk from one 8-byte load, unpacked to
-    normalised floats, so nothing rides on the mixer's table or the taps; 2-byte frames out through pack_b8) against k_front_s1
-    (IQGPU_NO_MID_8BIT=1).  Same products in the same order: the bytes must be equal -- whole calls, ragged splits that change kernel
+    normalised floats, so nothing rides on the mixer's table or the taps; 2-byte frames out through pack_b8), with a gain, and on
+    sc16q11 frames (16-bit frames normalised and gained by ONE product at the unpack) against k_front_s1 (IQGPU_NO_MID_8BIT=1).  Same products in the same order: the bytes must be equal -- whole calls, ragged splits that change kernel
     from call to call, a reset -- and close to the oracle."""
     agc, filt = bool(extra.get("agc")), "filters" in extra
     n = int(2.4e6 * 4.5) if agc else 3_300_001
@@ -988,7 +992,9 @@ def test_mid_kernel_on_eight_bit_frames(gpu, oracle, monkeypatch, in_format, out
     assert all(nm == "k_front_s1" for r in refs for nm in r[1])
     monkeypatch.delenv("IQGPU_NO_MID_8BIT")
     monkeypatch.setenv("IQGPU_FORCE_FAT", "1")           # calls of any length (the size rule keeps short calls on k_front_s1)
-    want_name = "k_front_mid<6,%s%s,8bit>" % ("nco" if shift_hz else "nonco", ",cf32" if filt else "")
+    b8 = in_format in ("cu8", "cs8") or out_format in ("cu8", "cs8")
+    n16 = in_format == "sc16q11" or (in_format == "cs16" and "gain" in extra)
+    want_name = "k_front_mid<6,%s%s%s%s>" % ("nco" if shift_hz else "nonco", ",cf32" if filt else "", ",8bit" if b8 else "", ",gain" if n16 else "")
     for sp, (ref, _, st_ref) in zip(splits, refs):
         got, names, st = run(sp)
         assert want_name in names, names

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--in-rate", type=float, default=2.4e6); ap.add_argument("--out-rate", type=float, default=744187.5)
     ap.add_argument("--shift", type=float, default=0.0); ap.add_argument("--dc-block", action="store_true")
     ap.add_argument("--agc", action="store_true"); ap.add_argument("--log2-frames", type=int, default=26)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=10); ap.add_argument("--gain", type=float, default=1.0)
     a = ap.parse_args()
     import torch
     import iq_tool_amd
@@ -26,7 +26,7 @@ def main():
     seg = synth.raw_stream(1 << 20, a.in_rate, 1, a.in_format)
     d_in = torch.from_numpy(seg).cuda().repeat(frames >> 20).contiguous()
     ch = iq_tool_amd.Chain(in_format=a.in_format, out_format=a.out_format, input_rate_hz=a.in_rate, target_rate_hz=a.out_rate,
-                           shift_hz=a.shift, dc_block=a.dc_block, agc=a.agc, block_samples=0)
+                           shift_hz=a.shift, dc_block=a.dc_block, agc=a.agc, gain=a.gain, block_samples=0)
     ch.set_stream(torch.cuda.current_stream().cuda_stream)
     d_out = torch.empty(ch.max_out_frames(frames) * ch.out_bytes, dtype=torch.uint8, device="cuda")
     n_out = 0
