@@ -1001,6 +1001,14 @@ def test_mid_kernel_on_eight_bit_frames(gpu, oracle, monkeypatch, in_format, out
         assert got.size == ref.size
         assert np.array_equal(got, ref), (sp, names, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
         assert st == st_ref
+    if not (agc or filt):
+        # fixed-length runs (block_samples): more runs than resident waves -- these instantiations take them as static runs over as
+        # many rounds of workgroups as it needs
+        for bs in (65536, 4096):
+            kw["block_samples"] = bs
+            got, names, _ = run(splits[0])
+            assert want_name in names and np.array_equal(got, refs[0][0]), (bs, names)
+        kw.pop("block_samples")
     monkeypatch.delenv("IQGPU_FORCE_FAT")
     if not agc:
         want = run_oracle(oracle, raw, **kw)
