@@ -74,14 +74,15 @@ __device__ __forceinline__ v2f p0_unpack(const uint32_t *r, const int i)
 
 // Steps [s_begin, s_end) of the launch's streaming outputs [k_a, k_b) (call-relative output indices).
 // FMT: cu8 / cs8 (2 bytes per frame) or cs16; OUTF: the output format (cu8 / cs8: 2 bytes per frame, cs16: 4, cf32: 8)
-template <int FMT, int L3, int L4, int OUTF, bool AGC>
+// L2, L3, L4 = floor(2 s), floor(3 s), floor(4 s) of the step class (s = step / 2^24; floor(s) = 1)
+template <int FMT, int L3, int L4, int OUTF, bool AGC, int L2 = 3>
 __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_lds, const int lane, const int64_t s_begin, const int64_t s_end)
 {
     constexpr int BPS = (FMT == IQGPU_FMT_CS16) ? 4 : 2;
     constexpr int OUTB = OUTF == IQGPU_FMT_CF32 ? 8 : OUTF == IQGPU_FMT_CS16 ? 4 : 2;
     constexpr int NW = (BPS == 2) ? 12 : 24;                 // raw words per window: 24 frames loaded, 22 used
     constexpr int NS = 5;
-    constexpr int LO[5] = {0, 1, 3, L3, L4};
+    constexpr int LO[5] = {0, 1, L2, L3, L4};
     typedef __attribute__((address_space(3))) const v2f lds_v2f;
     typedef uint32_t u4v __attribute__((ext_vector_type(4), aligned(2)));
     const uint32_t step = a.step;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         for (int m = 0; m < 9; ++m) own[m] = p0_unpack<FMT>(rc, 13 + m);
         // ---- five outputs: the chains of the other kernels, slot by slot
         v2f y[NS];
-        pp_slots3<9, 0, 1, 3, true>(Hw, own, t[0], t[1], t[2], y[0], y[1], y[2]);
+        pp_slots3<9, 0, 1, L2, true>(Hw, own, t[0], t[1], t[2], y[0], y[1], y[2]);
         pp_slots2<9, L3, L4, true>(Hw, own, t[3], t[4], y[3], y[4]);
         const int64_t k0 = a.p0_k_a + s * kP0Step + 5 * lane;                  // the lane's first output (call-relative)
         if (AGC) {
@@ -262,17 +263,25 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
 #pragma unroll
         for (int b = 0; b < NB; ++b) one_step(std::false_type{}, s + b, rb[b]);
     }
-    int b = 0;                                              // at most NB - 1 whole steps are left over, in the first buffers in turn
+    int b = 0;
+    if constexpr (NB == 2) {
+        // (written out for the shipped two buffers: the general form below costs the instantiations with the fused AGC up to 60 spilled
+        //  registers -- a second copy of the partial step)
+        for (; s < s_full; ++s, ++b) one_step(std::false_type{}, s, rb[0]);        // at most one whole step is left over, in the first buffer
+        if (has_partial) { if (b == 0) one_step(std::true_type{}, s, rb[0]); else one_step(std::true_type{}, s, rb[1]); }
+    } else {
+        // at most NB - 1 whole steps are left over, in the first buffers in turn
 #pragma unroll
-    for (int q = 0; q < NB - 1; ++q) if (s < s_full) { one_step(std::false_type{}, s, rb[q]); ++s; b = q + 1; }
-    if (has_partial) {
+        for (int q = 0; q < NB - 1; ++q) if (s < s_full) { one_step(std::false_type{}, s, rb[q]); ++s; b = q + 1; }
+        if (has_partial) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) if (b == q) one_step(std::true_type{}, s, rb[q]);
+            for (int q = 0; q < NB; ++q) if (b == q) one_step(std::true_type{}, s, rb[q]);
+        }
     }
     if (AGC) flush_peak(m0, agc_c);
 }
 
-template <int FMT, int L3, int L4, int OUTF, bool AGC>
+template <int FMT, int L3, int L4, int OUTF, bool AGC, int L2 = 3>
 __global__ __launch_bounds__(kP0Threads) void k_front_p0(const FrontArgs a)
 {
     constexpr int BPS = (FMT == IQGPU_FMT_CS16) ? 4 : 2;
@@ -311,21 +320,27 @@ __global__ __launch_bounds__(kP0Threads) void k_front_p0(const FrontArgs a)
         if (r >= a.w_n_stream) return;
         const int64_t s0 = r * a.w_run_q + (r < a.w_run_r ? r : a.w_run_r), s1 = s0 + a.w_run_q + (r < a.w_run_r ? 1 : 0);
         const unsigned tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_p0<FMT, L3, L4, OUTF, AGC>(a, tap_lds, lane, s0, s1);
+        run_p0<FMT, L3, L4, OUTF, AGC, L2>(a, tap_lds, lane, s0, s1);
     }
 }
 
-// step classes of five slots per lane: 1.6 <= step / 2^24 < 2 (lo_3, lo_4 = floor(3 s), floor(4 s))
-static bool p0_class(uint32_t step, int *l3, int *l4)
+// step classes of five slots per lane: 1 <= s = step / 2^24 < 2, by (lo_2, lo_3, lo_4) = floor(2 s), floor(3 s), floor(4 s).  A lane's five
+// outputs span less than 4 s + 1 < 9 samples behind its first (own[9]); the slots' shifted tap rows cover position offsets 0 and 1
+// past lo_j.  (Until late round 5: 1.6 <= s only -- the bound of the eight-samples-per-lane kernel this one grew out of, which the
+// output-major form does not have: a 2.048 MS/s capture to the cu8-nrsc5 preset's 1.488375 MS/s has s = 1.376.)
+static bool p0_class(uint32_t step, int *l3, int *l4, int *l2 = nullptr)
 {
     const uint64_t one = (uint64_t)1 << 24;
-    if ((uint64_t)step >= 2 * one || (uint64_t)step * 5 < 8 * one) return false;
+    if ((uint64_t)step >= 2 * one || (uint64_t)step < one + one / 64) return false;     // (s >= 1.016: clear of the no-resampling edge)
+    const int k2 = (int)(((uint64_t)step * 2) >> 24);
     *l3 = (int)(((uint64_t)step * 3) >> 24); *l4 = (int)(((uint64_t)step * 4) >> 24);
-    return (*l3 == 4 && *l4 == 6) || (*l3 == 5 && *l4 == 6) || (*l3 == 5 && *l4 == 7);
+    if (l2) *l2 = k2;
+    if (k2 == 3) return (*l3 == 4 && *l4 == 6) || (*l3 == 5 && *l4 == 6) || (*l3 == 5 && *l4 == 7);
+    return k2 == 2 && ((*l3 == 3 && *l4 == 4) || (*l3 == 3 && *l4 == 5) || (*l3 == 4 && *l4 == 5));
 }
 
 // which chains: no half-band stage, nothing pointwise but the unpack (unit gain, no dc blocker / iq correction / mixer on either
-// side), cu8 / cs8 / cs16 in, cu8 / cs8 / cs16 / cf32 out, a five-slot step class; the fused AGC with chunks of 1024 frames and more
+// side), cu8 / cs8 / cs16 in, cu8 / cs8 / cs16 / cf32 out, a five-slot step class (1.016 <= s < 2); the fused AGC with chunks of 1024 frames and more
 bool front_p0_shape(const FrontArgs &a)
 {
     int l3, l4;
@@ -360,32 +375,35 @@ void plan_front_p0(FrontArgs &a, int64_t wave_slots)
 
 hipError_t launch_front_p0(const FrontArgs &a, hipStream_t s)
 {
-    int l3 = 0, l4 = 0;
-    if (!front_p0_shape(a) || !p0_class(a.step, &l3, &l4) || a.w_n_edge > kP0EdgeMax || a.rem0 != 0) return hipErrorInvalidValue;
+    int l2 = 0, l3 = 0, l4 = 0;
+    if (!front_p0_shape(a) || !p0_class(a.step, &l3, &l4, &l2) || a.w_n_edge > kP0EdgeMax || a.rem0 != 0) return hipErrorInvalidValue;
     const size_t lds = p0_lds_bytes();
     const int64_t n_items = a.w_n_edge + a.w_n_stream;
     const unsigned grid = (unsigned)((n_items + kP0Waves - 1) / kP0Waves);
     if (grid == 0) return hipSuccess;
-#define IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, AGC)                                                                     \
+#define IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, AGC, L2)                                                                 \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_p0<FMT, L3, L4, OUTF, AGC>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_p0<FMT, L3, L4, OUTF, AGC>), dim3(grid), dim3(kP0Threads), lds, s, a);          \
+        { const hipError_t e = cache.ensure((const void *)k_front_p0<FMT, L3, L4, OUTF, AGC, L2>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_p0<FMT, L3, L4, OUTF, AGC, L2>), dim3(grid), dim3(kP0Threads), lds, s, a);      \
     } while (0)
-#define IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, OUTF)                                                                      \
-    do { if (a.agc_fused) IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, true); else IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, false); } while (0)
-#define IQGPU_LAUNCH_P0_OUT(FMT, L3, L4)                                                                            \
+#define IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, OUTF, L2)                                                                  \
+    do { if (a.agc_fused) IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, true, L2); else IQGPU_LAUNCH_P0(FMT, L3, L4, OUTF, false, L2); } while (0)
+#define IQGPU_LAUNCH_P0_OUT(FMT, L3, L4, L2)                                                                        \
     do {                                                                                                              \
-        if (a.out_fmt == IQGPU_FMT_CF32) IQGPU_LAUNCH_P0(FMT, L3, L4, IQGPU_FMT_CF32, false);                       \
-        else if (a.out_fmt == IQGPU_FMT_CS16) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS16);                     \
-        else if (a.out_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CU8);                       \
-        else IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS8);                                                       \
+        if (a.out_fmt == IQGPU_FMT_CF32) IQGPU_LAUNCH_P0(FMT, L3, L4, IQGPU_FMT_CF32, false, L2);                   \
+        else if (a.out_fmt == IQGPU_FMT_CS16) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS16, L2);                 \
+        else if (a.out_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CU8, L2);                   \
+        else IQGPU_LAUNCH_P0_AGC(FMT, L3, L4, IQGPU_FMT_CS8, L2);                                                   \
     } while (0)
 #define IQGPU_LAUNCH_P0_CLS(FMT)                                                                                    \
     do {                                                                                                              \
-        if (l3 == 4) IQGPU_LAUNCH_P0_OUT(FMT, 4, 6);                                                                \
-        else if (l4 == 6) IQGPU_LAUNCH_P0_OUT(FMT, 5, 6);                                                           \
-        else IQGPU_LAUNCH_P0_OUT(FMT, 5, 7);                                                                        \
+        if (l2 == 2 && l3 == 3 && l4 == 4) IQGPU_LAUNCH_P0_OUT(FMT, 3, 4, 2);                                       \
+        else if (l2 == 2 && l3 == 3) IQGPU_LAUNCH_P0_OUT(FMT, 3, 5, 2);                                             \
+        else if (l2 == 2) IQGPU_LAUNCH_P0_OUT(FMT, 4, 5, 2);                                                        \
+        else if (l3 == 4) IQGPU_LAUNCH_P0_OUT(FMT, 4, 6, 3);                                                        \
+        else if (l4 == 6) IQGPU_LAUNCH_P0_OUT(FMT, 5, 6, 3);                                                        \
+        else IQGPU_LAUNCH_P0_OUT(FMT, 5, 7, 3);                                                                     \
     } while (0)
     if (a.in_fmt == IQGPU_FMT_CU8) IQGPU_LAUNCH_P0_CLS(IQGPU_FMT_CU8);
     else if (a.in_fmt == IQGPU_FMT_CS8) IQGPU_LAUNCH_P0_CLS(IQGPU_FMT_CS8);

@@ -491,7 +491,12 @@ def test_s0_chain_cu8_nrsc5_preset_shape(gpu, oracle, monkeypatch, variant):
     ("cs8", "cs16", 2.4e6 / 1.75, {}),                               # step class (5, 7): every slot reloads every step
     ("cs16", "cu8", 2.4e6 / 1.7, {}),                                # (5, 6)
     ("cs16", "cs16", 2.4e6 / 1.96, {}),                              # the top of the range
-    ("cu8", "cs8", 2.4e6 / 1.601, {}),                               # ... and the bottom
+    ("cu8", "cs8", 2.4e6 / 1.601, {}),                               # ... and the bottom of the classes with floor(2 s) = 3
+    ("cu8", "cu8", 2.4e6 * 1488375.0 / 2.048e6, {}),                 # s = 1.376: a 2.048 MS/s capture to the cu8-nrsc5 preset's rate (2, 4, 5)
+    ("cs16", "cs16", 2.4e6 / 1.29, {}),                              # (2, 3, 5)
+    ("cs8", "cs16", 2.4e6 / 1.1, {}),                                # (2, 3, 4)
+    ("cu8", "cu8", 2.4e6 / 1.55, dict(agc=True)),                    # 1.5 <= s < 1.6, with the fused AGC
+    ("cu8", "cu8", 2.4e6 / 1.376, dict(agc=True)),
 ])
 def test_p0_kernel_equals_the_sample_major_kernel(gpu, oracle, monkeypatch, in_format, out_format, target_hz, extra):
     """Round 5: chains without a half-band stage on k_front_p0 (front_p0.hip: output-major steps of 320, every lane loads and unpacks
