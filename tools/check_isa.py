@@ -11,7 +11,9 @@ script compiles front_wave.hip to gfx950 ISA and verifies for every instantiatio
   (4) neither k_front_s1 nor k_cascade (cascade_wave.hip) holds a ds_read2_b32: that is what hipcc's load vectoriser makes of
       a window load it has trimmed to the dwords in use -- two 4-byte accesses per lane at a 16-byte lane stride, which
       conflict (SQ_LDS_BANK_CONFLICT 94 -> 12 cycles per tile when the cascade's window loads were made whole).
-Exit code 0 = ok.  Run by __graft_entry__.build() and tests/test_host_logic.py."""
+  (10) no instantiation of k_front_p0 (front_p0.hip) or k_cascade2 (cascade2.hip) uses scratch or more registers than its occupancy allows.
+The sources are compiled side by side (front_mid.hip alone: 2 min 40 s).  Exit code 0 = ok.  Run by __graft_entry__.build() and
+tests/test_host_logic.py."""
 import os
 import re
 import subprocess
@@ -102,7 +104,7 @@ def check(lines):
 def check_no_read2_b32(lines, what):
     errors, cur = [], None
     for l in lines:
-        m = re.match(r"(_ZN5iqgpu\d+k_(?:front_s1|cascade)I\w+):", l)
+        m = re.match(r"(_ZN5iqgpu\d+k_(?:front_s1|cascade2?)I\w+):", l)
         if m:
             cur = m.group(1)
         elif l.startswith(".Lfunc_end"):
@@ -113,7 +115,25 @@ def check_no_read2_b32(lines, what):
     return errors
 
 
-def check_fat_mid(src, kernel, max_vgpr):
+def check_no_scratch(lines, src, kernel, max_vgpr):
+    """every instantiation of `kernel` in `src`: no scratch, at most max_vgpr registers (late round 5: k_front_p0's tail for a
+    build-switched buffer count spilled up to 60 registers in the AGC variants for a round of commits -- no parity test sees that)"""
+    errors, n = [], 0
+    text = "\n".join(lines)
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN5iqgpu\d+%sI\w+)\n(.*?)\.end_amdhsa_kernel" % kernel, text, re.S):
+        n += 1
+        v = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
+        sc = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+        if sc != 0:
+            errors.append("%s: %s spills %d bytes to scratch" % (src, m.group(1), sc))
+        if v > max_vgpr:
+            errors.append("%s: %s needs %d VGPRs (budget %d)" % (src, m.group(1), v, max_vgpr))
+    if n == 0:
+        errors.append("%s: no instantiation of %s" % (src, kernel))
+    return errors
+
+
+def check_fat_mid(src, kernel, max_vgpr, lines=None):
     """k_front_fat / k_front_mid are plain C++ whose speed hangs on what hipcc makes of it: (5) no scratch (a spill inside the
     tile loop is a memory round trip per tile), (6) the VGPR count that the occupancy they are built for allows (8 waves per CU:
     256, 12 waves: 168), (7) the tap reads stay single ds_read_b64 -- fused into ds_read2_b64 / ds_read2st64_b64 they run at
@@ -122,7 +142,7 @@ def check_fat_mid(src, kernel, max_vgpr):
     global_atomic_add_x2 issued by one lane whose result is NOT waited for on the spot (the atomic optimizer's wave reduction --
     s_bcnt1 + an immediate s_waitcnt vmcnt(0) + readfirstlane -- would put a memory round trip in front of every tile), and the
     tile loop that holds it is a scalar loop (a divergent run bound turns it into v_cmp / EXEC-mask control: s_andn2_b64 exec)."""
-    lines = compile_isa(src)
+    lines = lines if lines is not None else compile_isa(src)
     errors, cur, n = [], None, 0
     if kernel == "k_front_mid":
         errors += check_claims(lines)
@@ -220,14 +240,21 @@ def check_hot(lines_by_src):
 
 
 def main():
-    lines = compile_isa()
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(HERE, "..", "iq_tool_amd", "csrc")
+    names = ["front_wave.hip", "cascade_wave.hip", "front_s2.hip", "front_mid.hip", "front_fat.hip", "front_p0.hip", "cascade2.hip"]
+    with ThreadPoolExecutor(max_workers=min(len(names), max(2, (os.cpu_count() or 4) - 1))) as ex:     # (front_mid.hip alone takes 2 min 40 s)
+        isa = dict(zip(names, ex.map(lambda nm: compile_isa(os.path.join(csrc, nm)), names)))
+    lines = isa["front_wave.hip"]
     errors, n = check(lines)
-    errors += check_hot({"front_wave.hip": lines, "cascade_wave.hip": compile_isa(SRC_CASC),
-                         "front_s2.hip": compile_isa(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_s2.hip"))})
+    errors += check_hot({k: isa[k] for k in ("front_wave.hip", "cascade_wave.hip", "front_s2.hip")})
     errors += check_no_read2_b32(lines, "front_wave.hip")
-    errors += check_no_read2_b32(compile_isa(SRC_CASC), "cascade_wave.hip")
-    errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_mid.hip"), "k_front_mid", 168)
-    errors += check_fat_mid(os.path.join(HERE, "..", "iq_tool_amd", "csrc", "front_fat.hip"), "k_front_fat", 256)
+    errors += check_no_read2_b32(isa["cascade_wave.hip"], "cascade_wave.hip")
+    errors += check_no_read2_b32(isa["cascade2.hip"], "cascade2.hip")
+    errors += check_fat_mid(os.path.join(csrc, "front_mid.hip"), "k_front_mid", 168, isa["front_mid.hip"])
+    errors += check_fat_mid(os.path.join(csrc, "front_fat.hip"), "k_front_fat", 256, isa["front_fat.hip"])
+    errors += check_no_scratch(isa["front_p0.hip"], "front_p0.hip", "k_front_p0", 256)
+    errors += check_no_scratch(isa["cascade2.hip"], "cascade2.hip", "k_cascade2", 168)
     for e in errors:
         print("FAIL", e)
     print("check_isa: %d tap gathers checked: %s" % (n, "ok" if not errors and n > 0 else "FAILED"))
