@@ -145,7 +145,18 @@ struct S2Feed {
     }
 };
 
-template <int BPS, int M0>
+// SPEC (late round 5): the chain's switches as compile-time constants for the streaming waves of the common cs16 chains -- the same
+// statements with their branches and selects folded away (configs[2]: 168 -> 120 VGPRs, the kernel 0.248 -> 0.219 ms).  0 = whatever
+// the arguments say; 1 .. 5 = unit gain, no mixer behind the resampler, and (dc blocker + iq correction, mixer in front, output):
+//   1 = (both, none, cf32) -- BASELINE configs[2] in front of its filter --  2 = (none, none, cs16)   3 = (none, mixer, cs16)
+//   4 = (none, none, cf32)   5 = (none, mixer, cf32)
+struct S2Spec { int dcq, nco, out; };
+__host__ __device__ constexpr S2Spec s2_spec(int k)
+{
+    return k == 1 ? S2Spec{1, 0, IQGPU_FMT_CF32} : k == 2 ? S2Spec{0, 0, IQGPU_FMT_CS16} : k == 3 ? S2Spec{0, 1, IQGPU_FMT_CS16}
+         : k == 4 ? S2Spec{0, 0, IQGPU_FMT_CF32} : S2Spec{0, 1, IQGPU_FMT_CF32};
+}
+template <int BPS, int M0, int SPEC = 0>
 __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -210,7 +221,16 @@ __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
         if (r >= a2.w_n_stream) return;
         const int64_t t0 = w_run_start(a2, r), t1 = w_run_start(a2, r + 1);
         const int seg = (int)(a2.w_n_edge1 + r);
-        S2Feed<BPS, M0> feed(a1, s_nco, slice0, lane, seg);
+        FrontArgs a1c = a1;
+        if constexpr (SPEC != 0) {
+            // (what launch_front_s2 has checked the arguments to be, spelled out for the compiler; the mixer's direction stays a
+            //  run-time value: it only picks the table's sign at the top of the kernel)
+            constexpr S2Spec sp = s2_spec(SPEC);
+            a1c.gain = 1.0f; a1c.in_fmt = IQGPU_FMT_CS16; a1c.dc_enable = sp.dcq; a1c.iq_enable = sp.dcq;
+            if (!sp.nco) a1c.nco_mode = 0; else if (a1c.nco_mode == 0) a1c.nco_mode = 1;
+            a2.pnco_mode = 0; a2.out_fmt = sp.out;
+        }
+        S2Feed<BPS, M0> feed(a1c, s_nco, slice0, lane, seg);
         feed.start(t0 - a2.w_warm_tiles);
         run_tiles<8, false, false, false, false, false, S2Feed<BPS, M0>>(a2, w, lane, t0 - a2.w_warm_tiles, t0, t1, seg, &feed);
     }
@@ -250,15 +270,36 @@ hipError_t launch_front_s2(const FrontArgs &a1, const FrontArgs &a2, hipStream_t
     case IQGPU_FMT_CF32: cls = 8; break;
     default: cls = 4; break;
     }
-#define IQGPU_LAUNCH_S2(BPS, M0)                                                                                    \
+#define IQGPU_LAUNCH_S2X(BPS, M0, SPEC)                                                                              \
     do {                                                                                                              \
         static LdsAttrCache cache;                /* per instantiation */                                          \
-        { const hipError_t e = cache.ensure((const void *)k_front_s2<BPS, M0>, lds); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL((k_front_s2<BPS, M0>), dim3(grid), dim3(kS2Threads), lds, s, p);                         \
+        { const hipError_t e = cache.ensure((const void *)k_front_s2<BPS, M0, SPEC>, lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_front_s2<BPS, M0, SPEC>), dim3(grid), dim3(kS2Threads), lds, s, p);                   \
     } while (0)
+#define IQGPU_LAUNCH_S2(BPS, M0) IQGPU_LAUNCH_S2X(BPS, M0, 0)
+    // the switch sets with an instantiation of their own (cs16, unit gain, no mixer behind the resampler): s2_spec
+    int spec = 0;
+    if (cls == 4 && a1.in_fmt == IQGPU_FMT_CS16 && a1.gain == 1.0f && a2.pnco_mode == 0 && !(a1.dbg & kDbgNoFast)) {
+        for (int k = 1; k <= 5 && spec == 0; ++k) {
+            const S2Spec sp = s2_spec(k);
+            if ((a1.dc_enable != 0) == (sp.dcq != 0) && (a1.iq_enable != 0) == (sp.dcq != 0) && (a1.nco_mode != 0) == (sp.nco != 0) && a2.out_fmt == sp.out) spec = k;
+        }
+    }
+    if (spec != 0) {
+#define IQGPU_LAUNCH_S2S(M0)                                                                                         \
+        do {                                                                                                          \
+            if (spec == 1) IQGPU_LAUNCH_S2X(4, M0, 1); else if (spec == 2) IQGPU_LAUNCH_S2X(4, M0, 2);               \
+            else if (spec == 3) IQGPU_LAUNCH_S2X(4, M0, 3); else if (spec == 4) IQGPU_LAUNCH_S2X(4, M0, 4);          \
+            else IQGPU_LAUNCH_S2X(4, M0, 5);                                                                          \
+        } while (0)
+        if (a1.m[0] == 5) IQGPU_LAUNCH_S2S(5); else IQGPU_LAUNCH_S2S(3);
+#undef IQGPU_LAUNCH_S2S
+        return hipGetLastError();
+    }
     if (a1.m[0] == 5) { if (cls == 2) IQGPU_LAUNCH_S2(2, 5); else if (cls == 4) IQGPU_LAUNCH_S2(4, 5); else IQGPU_LAUNCH_S2(8, 5); }
     else              { if (cls == 2) IQGPU_LAUNCH_S2(2, 3); else if (cls == 4) IQGPU_LAUNCH_S2(4, 3); else IQGPU_LAUNCH_S2(8, 3); }
 #undef IQGPU_LAUNCH_S2
+#undef IQGPU_LAUNCH_S2X
     return hipGetLastError();
 }
 

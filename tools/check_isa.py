@@ -217,8 +217,9 @@ HOT = {
                        ("_ZN5iqgpu10k_front_s1ILi4ELb0ELb1ELb0ELi3EEEvNS_9FrontArgsE", 128)],
     "cascade_wave.hip": [("_ZN5iqgpu9k_cascadeILi4ELb0ELi1EEEvNS_9FrontArgsE", 168),               # S = 2 calls off a group boundary (12 waves)
                          ("_ZN5iqgpu9k_cascadeILi2ELb1ELi4EEEvNS_9FrontArgsE", 128)],              # config 4 (16 waves)
-    "front_s2.hip": [("_ZN5iqgpu10k_front_s2ILi4ELi5EEEvNS_6S2ArgsE", 168),                        # config 3 (12 waves)
-                     ("_ZN5iqgpu10k_front_s2ILi2ELi5EEEvNS_6S2ArgsE", 168)],
+    "front_s2.hip": [("_ZN5iqgpu10k_front_s2ILi4ELi5ELi1EEEvNS_6S2ArgsE", 168),                    # config 3 (12 waves; its switch set compiled in)
+                     ("_ZN5iqgpu10k_front_s2ILi4ELi5ELi0EEEvNS_6S2ArgsE", 168),                    # ... and with run-time switches
+                     ("_ZN5iqgpu10k_front_s2ILi2ELi5ELi0EEEvNS_6S2ArgsE", 168)],
 }
 
 
