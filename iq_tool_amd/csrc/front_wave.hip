@@ -49,22 +49,27 @@ size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveL
 //      AGC: output AGC fused (gain before the pack, exact per-chunk peaks); those of the run-time-switched kernels run 12 waves
 //      VAR: 0 = as the flags say; 1 = FAST without a mixer (NONCO); 4 = the last stage of a multi-stage chain (cf32 from k_cascade,
 //      nothing pointwise, cs16 / cu8 / cf32 out: 16 waves instead of 12); 2, 3 = the cu8-nrsc5 preset shapes (S0, no shift, unit gain,
-//      no dc blocker / iq correction, cu8 out) from cu8 resp. cs16 input with their run-time switches resolved at compile time
+//      no dc blocker / iq correction, cu8 out) from cu8 resp. cs16 input with their run-time switches resolved at compile time;
+//      5, 6 (late round 5) = the headline chain with a dc blocker (cs16 in and out, unit gain, no iq correction; 5: mixer in front, 6: none)
 template <int BPS, bool FAST, bool S0 = false, bool AGC = false, int VAR = 0>
-__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || VAR >= 2) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
+__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4)) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
 {
     constexpr bool NONCO = VAR == 1;
     FrontArgs a = a_in;
     if (VAR == 4) {        // the last stage behind k_cascade: cf32 in, nothing pointwise; cs16 or cu8 out, or cf32 for a filter behind it (VAR 4 with S0 = false only)
         a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.nco_mode = 0; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CF32;
         if (a.out_fmt != IQGPU_FMT_CU8 && a.out_fmt != IQGPU_FMT_CF32) a.out_fmt = IQGPU_FMT_CS16;
-    } else if (VAR >= 2) {        // constants instead of arguments: the compiler folds every switch they feed (128 -> 93 VGPRs, -17 % time)
+    } else if (VAR == 2 || VAR == 3) {        // constants instead of arguments: the compiler folds every switch they feed (128 -> 93 VGPRs, -17 % time)
         a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.nco_mode = 0; a.pnco_mode = 0;
         a.in_fmt = VAR == 2 ? (int)IQGPU_FMT_CU8 : (int)IQGPU_FMT_CS16; a.out_fmt = IQGPU_FMT_CU8;
     }
+    if (VAR == 5 || VAR == 6) {   // the headline chain WITH a dc blocker (5: mixer in front, 6: none): cs16 in and out, unit gain, no iq correction
+        a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 1; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CS16; a.out_fmt = IQGPU_FMT_CS16;
+        if (VAR == 6) a.nco_mode = 0; else if (a.nco_mode == 0) a.nco_mode = 1;       // (the mixer's direction stays the argument's)
+    }
     if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool k16 = FAST || (BPS == 2 && !AGC) || VAR >= 2;
+    constexpr bool k16 = FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4);
     constexpr int kThr = k16 ? kS1Threads : kWThreads, kWv = k16 ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,6 +163,13 @@ static bool front_s1_mid_var(const FrontArgs &a)
     return a.S == 1 && a.in_fmt == IQGPU_FMT_CF32 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable && a.nco_mode == 0 && a.pnco_mode == 0 &&
            (a.out_fmt == IQGPU_FMT_CS16 || a.out_fmt == IQGPU_FMT_CU8 || a.out_fmt == IQGPU_FMT_CF32) && !(a.dbg & kDbgNoFast);
 }
+// the headline chain with `--dc-block`: S = 1, cs16 in and out, unit gain, dc blocker on, no iq correction, no mixer behind: VAR 5 / 6
+static int front_s1_dc_var(const FrontArgs &a)
+{
+    if (a.S != 1 || a.in_fmt != IQGPU_FMT_CS16 || a.out_fmt != IQGPU_FMT_CS16 || a.gain != 1.0f || a.iq_enable || !a.dc_enable || a.pnco_mode != 0 ||
+        (a.dbg & kDbgNoFast)) return 0;
+    return a.nco_mode != 0 ? 5 : 6;
+}
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
 {
@@ -217,6 +229,10 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
     else if (cls == 4 && nonco && a.agc_fused) IQGPU_LAUNCH_S1Y(4, true, false, true, 1);
     else if (cls == 4 && nonco) IQGPU_LAUNCH_S1Y(4, true, false, false, 1);
     else if (cls == 4 && fast && a.agc_fused) IQGPU_LAUNCH_S1X(4, true, false, true);
+    else if (cls == 4 && front_s1_dc_var(a) == 5 && a.agc_fused) IQGPU_LAUNCH_S1Y(4, false, false, true, 5);
+    else if (cls == 4 && front_s1_dc_var(a) == 5) IQGPU_LAUNCH_S1Y(4, false, false, false, 5);
+    else if (cls == 4 && front_s1_dc_var(a) == 6 && a.agc_fused) IQGPU_LAUNCH_S1Y(4, false, false, true, 6);
+    else if (cls == 4 && front_s1_dc_var(a) == 6) IQGPU_LAUNCH_S1Y(4, false, false, false, 6);
     else if (cls == 4 && a.agc_fused) IQGPU_LAUNCH_S1X(4, false, false, true);
     else if (cls == 4 && fast) IQGPU_LAUNCH_S1(4, true, false);
     else if (cls == 4) IQGPU_LAUNCH_S1(4, false, false);

@@ -1287,6 +1287,38 @@ def test_two_tile_trips_equal_the_one_tile_cascade(gpu, oracle, monkeypatch, in_
         int_close(got, want, min_same=0.998)
 
 
+@pytest.mark.parametrize("shift_hz,agc", [(200e3, False), (0.0, False), (-150e3, True)])
+def test_dc_blocker_chain_with_its_switches_compiled_in(gpu, oracle, monkeypatch, shift_hz, agc):
+    """Late round 5: the headline chain with `--dc-block` on k_front_s1<4, .., VAR = 5 | 6> (cs16 in and out, unit gain, dc blocker on,
+    no iq correction: the chain's switches as constants) against the run-time-switched instantiation (IQGPU_NO_FAST=1): the same
+    statements, so the bytes must be equal -- ragged splits and a reset included -- and close to the oracle."""
+    n = int(2.4e6 * 4.5) if agc else 2_900_001
+    raw = synth.raw_stream(n, 2.4e6, 71, "cs16")
+    kw = dict(NRSC5, shift_hz=shift_hz, dc_block=True, agc=agc)
+    splits = [[n]] if agc else [[n], [1_300_003, 7, n - 1_300_010]]
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos = [], 0
+        for k in split:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        st = ch.agc_state() if agc else None
+        ch.reset()
+        outs.append(ch.process(raw[:2 * 900_000]))
+        return np.concatenate(outs), st
+
+    monkeypatch.setenv("IQGPU_NO_FAST", "1")
+    refs = [run(sp) for sp in splits]
+    monkeypatch.delenv("IQGPU_NO_FAST")
+    for sp, (ref, st_ref) in zip(splits, refs):
+        got, st = run(sp)
+        assert got.size == ref.size and np.array_equal(got, ref), (sp, int((got != ref).sum()))
+        assert st == st_ref
+    if not agc:
+        want = run_oracle(oracle, raw, **kw)
+        int_close(refs[0][0][:want.size], want, min_same=0.99)
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
 def test_two_tile_trips_on_random_geometry(gpu, monkeypatch, seed):
     """k_cascade2 against k_cascade where the geometry is drawn: format, stage count, runs of 2 .. 40 tiles, ragged call splits that leave

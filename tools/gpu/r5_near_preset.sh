@@ -17,3 +17,8 @@ $B --in-format cs16 --out-format cs16 --out-rate 600e3 --shift 200e3
 $B --in-format cs16 --out-format cs16 --out-rate 1.0e6 --shift 200e3
 $B --in-format cf32 --out-format cf32 --shift 200e3
 } 2>&1 | grep -v "^$" | tee gpurun_out/r5_near/out.txt
+# (late round 5: the dc-blocker chain with its switch set compiled in -- IQGPU_NO_FAST=1 keeps the run-time form)
+for e in "" "IQGPU_NO_FAST=1"; do
+  echo "[$e] $(env $e python3 tools/bench_chain.py --log2-frames 28 --steps 20 --in-format cs16 --out-format cs16 --shift 200e3 --dc-block 2>&1 | grep -v amdgpu.ids)" | tee -a gpurun_out/r5_near/out.txt
+  echo "[$e] $(env $e python3 tools/bench_chain.py --log2-frames 28 --steps 20 --in-format cs16 --out-format cs16 --dc-block 2>&1 | grep -v amdgpu.ids)" | tee -a gpurun_out/r5_near/out.txt
+done
