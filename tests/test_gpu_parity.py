@@ -1319,6 +1319,38 @@ def test_dc_blocker_chain_with_its_switches_compiled_in(gpu, oracle, monkeypatch
         int_close(refs[0][0][:want.size], want, min_same=0.99)
 
 
+@pytest.mark.parametrize("shift_hz,agc", [(200e3, False), (-300e3, True)])
+def test_cu8_preset_shape_with_a_mixer_compiled_in(gpu, oracle, monkeypatch, shift_hz, agc):
+    """Late round 5: the cu8-nrsc5 preset with `--freq-shift` (S = 0, cu8 in and out, a mixer in front) on k_front_s1<2, .., S0, VAR = 7>
+    -- the chain's switches as constants, 16 waves per CU also with the fused AGC -- against the run-time-switched instantiation
+    (IQGPU_NO_FAST=1): bytes equal, ragged splits and a reset included; close to the oracle."""
+    n = int(2.4e6 * 4.5) if agc else 2_700_001
+    raw = synth.raw_stream(n, 2.4e6, 73, "cu8")
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, shift_hz=shift_hz, agc=agc)
+    splits = [[n]] if agc else [[n], [1_100_001, 3, n - 1_100_004]]
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos = [], 0
+        for k in split:
+            outs.append(ch.process(raw[2 * pos:2 * (pos + k)])); pos += k
+        st = ch.agc_state() if agc else None
+        ch.reset()
+        outs.append(ch.process(raw[:2 * 800_000]))
+        return np.concatenate(outs), st
+
+    monkeypatch.setenv("IQGPU_NO_FAST", "1")
+    refs = [run(sp) for sp in splits]
+    monkeypatch.delenv("IQGPU_NO_FAST")
+    for sp, (ref, st_ref) in zip(splits, refs):
+        got, st = run(sp)
+        assert got.size == ref.size and np.array_equal(got, ref), (sp, int((got != ref).sum()))
+        assert st == st_ref
+    if not agc:
+        want = run_oracle(oracle, raw, **kw)
+        int_close(refs[0][0][:want.size], want, min_same=0.99)
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
 def test_two_tile_trips_on_random_geometry(gpu, monkeypatch, seed):
     """k_cascade2 against k_cascade where the geometry is drawn: format, stage count, runs of 2 .. 40 tiles, ragged call splits that leave
