@@ -51,9 +51,9 @@ size_t front_s1_lds_bytes() { return (size_t)kTabLds + (size_t)kS1Waves * kWaveL
 //      nothing pointwise, cs16 / cu8 / cf32 out: 16 waves instead of 12); 2, 3 = the cu8-nrsc5 preset shapes (S0, no shift, unit gain,
 //      no dc blocker / iq correction, cu8 out) from cu8 resp. cs16 input with their run-time switches resolved at compile time;
 //      5, 6 (late round 5) = the headline chain with a dc blocker (cs16 in and out, unit gain, no iq correction; 5: mixer in front, 6: none);
-//      7 = the cu8-nrsc5 preset shape with a mixer in front (S0, cu8 in and out): 16 waves also with the fused AGC
+//      7 = the cu8-nrsc5 preset shape with a mixer in front (S0, cu8 in and out): 16 waves also with the fused AGC; 8, 9 = with a dc blocker (and a mixer / none)
 template <int BPS, bool FAST, bool S0 = false, bool AGC = false, int VAR = 0>
-__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4) || VAR == 7) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
+__global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4) || VAR >= 7) ? kS1Threads : kWThreads) void k_front_s1(const FrontArgs a_in)
 {
     constexpr bool NONCO = VAR == 1;
     FrontArgs a = a_in;
@@ -68,13 +68,17 @@ __global__ __launch_bounds__((FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 
         a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 0; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CU8; a.out_fmt = IQGPU_FMT_CU8;
         if (a.nco_mode == 0) a.nco_mode = 1;               // (the mixer's direction stays the argument's)
     }
+    if (VAR == 8 || VAR == 9) {   // ... and WITH a dc blocker (8: mixer in front too, 9: none)
+        a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 1; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CU8; a.out_fmt = IQGPU_FMT_CU8;
+        if (VAR == 9) a.nco_mode = 0; else if (a.nco_mode == 0) a.nco_mode = 1;
+    }
     if (VAR == 5 || VAR == 6) {   // the headline chain WITH a dc blocker (5: mixer in front, 6: none): cs16 in and out, unit gain, no iq correction
         a.gain = 1.0f; a.iq_enable = 0; a.dc_enable = 1; a.pnco_mode = 0; a.in_fmt = IQGPU_FMT_CS16; a.out_fmt = IQGPU_FMT_CS16;
         if (VAR == 6) a.nco_mode = 0; else if (a.nco_mode == 0) a.nco_mode = 1;       // (the mixer's direction stays the argument's)
     }
     if (a.run_if && *a.run_if == 0) return;         // a fallback launch whose fused predecessor stood
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool k16 = FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4) || VAR == 7;
+    constexpr bool k16 = FAST || (BPS == 2 && !AGC) || (VAR >= 2 && VAR <= 4) || VAR >= 7;
     constexpr int kThr = k16 ? kS1Threads : kWThreads, kWv = k16 ? kS1Waves : kWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,15 +180,17 @@ static int front_s1_dc_var(const FrontArgs &a)
     return a.nco_mode != 0 ? 5 : 6;
 }
 // the cu8-nrsc5 preset with `--freq-shift`: S = 0, cu8 in and out, unit gain, a mixer in front, nothing else pointwise: VAR 7
-static bool front_s1_s0_mixer_var(const FrontArgs &a)
+static int front_s1_s0_mixer_var(const FrontArgs &a)
 {
-    return a.S == 0 && a.in_fmt == IQGPU_FMT_CU8 && a.out_fmt == IQGPU_FMT_CU8 && a.gain == 1.0f && !a.iq_enable && !a.dc_enable && a.nco_mode != 0 &&
-           a.pnco_mode == 0 && !(a.dbg & kDbgNoFast);
+    if (!(a.S == 0 && a.in_fmt == IQGPU_FMT_CU8 && a.out_fmt == IQGPU_FMT_CU8 && a.gain == 1.0f && !a.iq_enable && a.pnco_mode == 0 && !(a.dbg & kDbgNoFast)))
+        return 0;
+    if (a.dc_enable) return a.nco_mode != 0 ? 8 : 9;      // ... with `--dc-block`
+    return a.nco_mode != 0 ? 7 : 0;
 }
 // wavefronts per workgroup of the instantiation that launch_front_s1() will pick for these arguments
 static bool front_s1_sixteen(const FrontArgs &a)
 {
-    if (front_s1_plain_var(a) != 0 || front_s1_mid_var(a) || front_s1_s0_mixer_var(a)) return true;
+    if (front_s1_plain_var(a) != 0 || front_s1_mid_var(a) || front_s1_s0_mixer_var(a) != 0) return true;
     // 4 waves per SIMD where the instantiation fits 128 VGPRs (nearly) without scratch: the specialised one,
     // and the 8-bit-input ones (2 - 4 spilled dwords; measured -8 % on the cu8-nrsc5 shape, -4 % on cu8 -> cs16).
     // The cs16 / cf32-input run-time-switched ones spill 7 - 21 dwords there and are faster with 12 waves.
@@ -227,8 +233,12 @@ hipError_t launch_front_s1(const FrontArgs &a_in, hipStream_t s)
     else if (pvar == 2) IQGPU_LAUNCH_S1Y(2, false, true, false, 2);
     else if (pvar == 3 && a.agc_fused) IQGPU_LAUNCH_S1Y(4, false, true, true, 3);
     else if (pvar == 3) IQGPU_LAUNCH_S1Y(4, false, true, false, 3);
-    else if (front_s1_s0_mixer_var(a) && a.agc_fused) IQGPU_LAUNCH_S1Y(2, false, true, true, 7);
-    else if (front_s1_s0_mixer_var(a)) IQGPU_LAUNCH_S1Y(2, false, true, false, 7);
+    else if (front_s1_s0_mixer_var(a) == 7 && a.agc_fused) IQGPU_LAUNCH_S1Y(2, false, true, true, 7);
+    else if (front_s1_s0_mixer_var(a) == 7) IQGPU_LAUNCH_S1Y(2, false, true, false, 7);
+    else if (front_s1_s0_mixer_var(a) == 8 && a.agc_fused) IQGPU_LAUNCH_S1Y(2, false, true, true, 8);
+    else if (front_s1_s0_mixer_var(a) == 8) IQGPU_LAUNCH_S1Y(2, false, true, false, 8);
+    else if (front_s1_s0_mixer_var(a) == 9 && a.agc_fused) IQGPU_LAUNCH_S1Y(2, false, true, true, 9);
+    else if (front_s1_s0_mixer_var(a) == 9) IQGPU_LAUNCH_S1Y(2, false, true, false, 9);
     else if (a.S == 0) {
         if (cls == 2 && a.agc_fused) IQGPU_LAUNCH_S1X(2, false, true, true);
         else if (cls == 2) IQGPU_LAUNCH_S1(2, false, true);

@@ -401,6 +401,47 @@ __global__ __launch_bounds__(kThreads) void k_dc_prefix(const DcPrefixArgs a)
                 }
             }
         }
+        // 8-bit formats (late round 5: the loop below, one 8-byte load at a time, read an RTL-SDR's cu8 capture at 1.2 TB/s --
+        // 0.42 ms per 2^28 frames, more than the resampler behind it): eight chunks' loads in flight per thread, same arithmetic, same order
+        if (vb == 2 && a.raw_aligned && (((beg - pad) * 2) & 15) == 0 && n_chunks > 9) {
+            {   // the first chunk holds the padding: the general path, once
+                const int64_t u = 4 * tid;
+                float lr = 0.0f, li = 0.0f;
+                const int64_t k0 = beg + u - pad;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    cf2 x{0.0f, 0.0f};
+                    if (u + s >= pad) x = unpack_one(a.raw, k0 + s, a.in_fmt, a.gain);
+                    lr = fmaf(lr, c, x.x); li = fmaf(li, c, x.y);
+                }
+                accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
+                ch = 1;
+            }
+            const bool uns = a.in_fmt == IQGPU_FMT_CU8;
+            const char *base = (const char *)a.raw + (beg - pad + 4 * tid) * 2;
+            for (; ch + 8 <= n_chunks; ch += 8) {
+                uint2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    const u2v q = __builtin_nontemporal_load((const u2v *)(base + ((ch + i) << 11)));
+                    v[i] = make_uint2(q.x, q.y);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float lr = 0.0f, li = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const unsigned h = ((s & 2) ? v[i].y : v[i].x) >> (16 * (s & 1));
+                        float xr, xi;
+                        if (uns) { xr = up_u((float)(h & 0xffu), 127.5f, 1.0f / 128.0f, a.gain); xi = up_u((float)((h >> 8) & 0xffu), 127.5f, 1.0f / 128.0f, a.gain); }
+                        else { xr = up_s((float)(signed char)(h & 0xffu), 1.0f / 128.0f, a.gain); xi = up_s((float)(signed char)((h >> 8) & 0xffu), 1.0f / 128.0f, a.gain); }
+                        lr = fmaf(lr, c, xr); li = fmaf(li, c, xi);
+                    }
+                    accr = fmaf(accr, c1024, lr); acci = fmaf(acci, c1024, li);
+                }
+            }
+        }
         for (; ch < n_chunks; ++ch) {
             const int64_t u = (ch << 10) + 4 * tid;       // padded position of this thread's 4 samples
             float lr = 0.0f, li = 0.0f;

@@ -1319,14 +1319,14 @@ def test_dc_blocker_chain_with_its_switches_compiled_in(gpu, oracle, monkeypatch
         int_close(refs[0][0][:want.size], want, min_same=0.99)
 
 
-@pytest.mark.parametrize("shift_hz,agc", [(200e3, False), (-300e3, True)])
-def test_cu8_preset_shape_with_a_mixer_compiled_in(gpu, oracle, monkeypatch, shift_hz, agc):
+@pytest.mark.parametrize("shift_hz,agc,dc", [(200e3, False, False), (-300e3, True, False), (200e3, False, True), (0.0, False, True), (0.0, True, True)])
+def test_cu8_preset_shape_with_a_mixer_compiled_in(gpu, oracle, monkeypatch, shift_hz, agc, dc):
     """Late round 5: the cu8-nrsc5 preset with `--freq-shift` (S = 0, cu8 in and out, a mixer in front) on k_front_s1<2, .., S0, VAR = 7>
     -- the chain's switches as constants, 16 waves per CU also with the fused AGC -- against the run-time-switched instantiation
     (IQGPU_NO_FAST=1): bytes equal, ragged splits and a reset included; close to the oracle."""
     n = int(2.4e6 * 4.5) if agc else 2_700_001
     raw = synth.raw_stream(n, 2.4e6, 73, "cu8")
-    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, shift_hz=shift_hz, agc=agc)
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, shift_hz=shift_hz, agc=agc, dc_block=dc)   # (VAR 7; 8 / 9 with the dc blocker)
     splits = [[n]] if agc else [[n], [1_100_001, 3, n - 1_100_004]]
 
     def run(split):

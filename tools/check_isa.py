@@ -66,7 +66,7 @@ def check(lines):
         m = re.match(r"(_ZN5iqgpu10k_front_s1ILi(\d)ELb([01])ELb([01])ELb([01])ELi(\d)EEEvNS_9FrontArgsE):", l)
         if m:
             cur = (m.group(2) + (", fast" if m.group(3) == "1" else "") + (", s0" if m.group(4) == "1" else "") +
-                   (", agc" if m.group(5) == "1" else "") + ({"0": "", "1": ", nonco", "2": ", plain cu8", "3": ", plain cs16->cu8", "4": ", mid stage", "5": ", dc + mixer", "6": ", dc", "7": ", s0 cu8 + mixer"}[m.group(6)]))
+                   (", agc" if m.group(5) == "1" else "") + ({"0": "", "1": ", nonco", "2": ", plain cu8", "3": ", plain cs16->cu8", "4": ", mid stage", "5": ", dc + mixer", "6": ", dc", "7": ", s0 cu8 + mixer", "8": ", s0 cu8 + dc + mixer", "9": ", s0 cu8 + dc"}[m.group(6)]))
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(l)
