@@ -145,16 +145,16 @@ struct S2Feed {
     }
 };
 
-// SPEC (late round 5): the chain's switches as compile-time constants for the streaming waves of the common cs16 chains -- the same
+// SPEC (late round 5): the chain's switches as compile-time constants for the streaming waves of the common cs16 / cu8 chains -- the same
 // statements with their branches and selects folded away (configs[2]: 168 -> 120 VGPRs, the kernel 0.248 -> 0.219 ms).  0 = whatever
-// the arguments say; 1 .. 5 = unit gain, no mixer behind the resampler, and (dc blocker + iq correction, mixer in front, output):
+// the arguments say; 1 .. 7 = unit gain, no mixer behind the resampler, and (dc blocker + iq correction, mixer in front, output):
 //   1 = (both, none, cf32) -- BASELINE configs[2] in front of its filter --  2 = (none, none, cs16)   3 = (none, mixer, cs16)
-//   4 = (none, none, cf32)   5 = (none, mixer, cf32)
+//   4 = (none, none, cf32)   5 = (none, mixer, cf32)   6 = (none, none, cu8)   7 = (none, mixer, cu8)
 struct S2Spec { int dcq, nco, out; };
 __host__ __device__ constexpr S2Spec s2_spec(int k)
 {
     return k == 1 ? S2Spec{1, 0, IQGPU_FMT_CF32} : k == 2 ? S2Spec{0, 0, IQGPU_FMT_CS16} : k == 3 ? S2Spec{0, 1, IQGPU_FMT_CS16}
-         : k == 4 ? S2Spec{0, 0, IQGPU_FMT_CF32} : S2Spec{0, 1, IQGPU_FMT_CF32};
+         : k == 4 ? S2Spec{0, 0, IQGPU_FMT_CF32} : k == 5 ? S2Spec{0, 1, IQGPU_FMT_CF32} : k == 6 ? S2Spec{0, 0, IQGPU_FMT_CU8} : S2Spec{0, 1, IQGPU_FMT_CU8};
 }
 template <int BPS, int M0, int SPEC = 0>
 __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kS2Threads) void k_front_s2(const S2Args p)
             // (what launch_front_s2 has checked the arguments to be, spelled out for the compiler; the mixer's direction stays a
             //  run-time value: it only picks the table's sign at the top of the kernel)
             constexpr S2Spec sp = s2_spec(SPEC);
-            a1c.gain = 1.0f; a1c.in_fmt = IQGPU_FMT_CS16; a1c.dc_enable = sp.dcq; a1c.iq_enable = sp.dcq;
+            a1c.gain = 1.0f; a1c.in_fmt = BPS == 2 ? (int)IQGPU_FMT_CU8 : (int)IQGPU_FMT_CS16; a1c.dc_enable = sp.dcq; a1c.iq_enable = sp.dcq;
             if (!sp.nco) a1c.nco_mode = 0; else if (a1c.nco_mode == 0) a1c.nco_mode = 1;
             a2.pnco_mode = 0; a2.out_fmt = sp.out;
         }
@@ -279,20 +279,22 @@ hipError_t launch_front_s2(const FrontArgs &a1, const FrontArgs &a2, hipStream_t
 #define IQGPU_LAUNCH_S2(BPS, M0) IQGPU_LAUNCH_S2X(BPS, M0, 0)
     // the switch sets with an instantiation of their own (cs16, unit gain, no mixer behind the resampler): s2_spec
     int spec = 0;
-    if (cls == 4 && a1.in_fmt == IQGPU_FMT_CS16 && a1.gain == 1.0f && a2.pnco_mode == 0 && !(a1.dbg & kDbgNoFast)) {
-        for (int k = 1; k <= 5 && spec == 0; ++k) {
+    if ((a1.in_fmt == IQGPU_FMT_CS16 || a1.in_fmt == IQGPU_FMT_CU8) && a1.gain == 1.0f && a2.pnco_mode == 0 && !(a1.dbg & kDbgNoFast)) {
+        for (int k = 1; k <= 7 && spec == 0; ++k) {
             const S2Spec sp = s2_spec(k);
             if ((a1.dc_enable != 0) == (sp.dcq != 0) && (a1.iq_enable != 0) == (sp.dcq != 0) && (a1.nco_mode != 0) == (sp.nco != 0) && a2.out_fmt == sp.out) spec = k;
         }
     }
     if (spec != 0) {
-#define IQGPU_LAUNCH_S2S(M0)                                                                                         \
+#define IQGPU_LAUNCH_S2S(BPS, M0)                                                                                    \
         do {                                                                                                          \
-            if (spec == 1) IQGPU_LAUNCH_S2X(4, M0, 1); else if (spec == 2) IQGPU_LAUNCH_S2X(4, M0, 2);               \
-            else if (spec == 3) IQGPU_LAUNCH_S2X(4, M0, 3); else if (spec == 4) IQGPU_LAUNCH_S2X(4, M0, 4);          \
-            else IQGPU_LAUNCH_S2X(4, M0, 5);                                                                          \
+            if (spec == 1) IQGPU_LAUNCH_S2X(BPS, M0, 1); else if (spec == 2) IQGPU_LAUNCH_S2X(BPS, M0, 2);           \
+            else if (spec == 3) IQGPU_LAUNCH_S2X(BPS, M0, 3); else if (spec == 4) IQGPU_LAUNCH_S2X(BPS, M0, 4);      \
+            else if (spec == 5) IQGPU_LAUNCH_S2X(BPS, M0, 5); else if (spec == 6) IQGPU_LAUNCH_S2X(BPS, M0, 6);      \
+            else IQGPU_LAUNCH_S2X(BPS, M0, 7);                                                                        \
         } while (0)
-        if (a1.m[0] == 5) IQGPU_LAUNCH_S2S(5); else IQGPU_LAUNCH_S2S(3);
+        if (cls == 2) { if (a1.m[0] == 5) IQGPU_LAUNCH_S2S(2, 5); else IQGPU_LAUNCH_S2S(2, 3); }
+        else          { if (a1.m[0] == 5) IQGPU_LAUNCH_S2S(4, 5); else IQGPU_LAUNCH_S2S(4, 3); }
 #undef IQGPU_LAUNCH_S2S
         return hipGetLastError();
     }
