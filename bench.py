@@ -691,8 +691,10 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded 2^%d-frame cs16 segment, 3 tones + noise + DC, tiled in HBM to 2^%d frames per GPU)" % (int(np.log2(min(frames, 1 << SEGMENT_LOG2))), case["log2_frames"]),
             "config": {"workload": "BASELINE configs[1]: raw cs16 2.4 MS/s -> 744.1875 kS/s, +200 kHz NCO, 1 half-band (m=10) + 256-arm polyphase (14 taps), cs16 out",
                        "frames_per_step_per_gpu": frames, "block_samples": BLOCK_SAMPLES, "devices": devices,
-                       # every IQGPU_* variable this process saw: the library reads its diagnostic switches from the environment at
-                       # iqgpu_chain_create, so a stray export changes what the line measures -- it is at least on record
+                       # the library reads NO switch from the environment (ABI v6): "debug" is what iqgpu_debug_list reports -- the
+                       # diagnostic switches the ctypes mirror forwarded from this process's IQGPU_<NAME> variables; "env" keeps every
+                       # IQGPU_* variable the process saw (bench.py's own knobs included), so a stray export is on record
+                       "debug": iq_tool_amd._lib.debug_switches(),
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("IQGPU_")},
                        "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"
                                    + (" -- RANKS SHARE ONE GPU (IQGPU_BENCH_SHARE_GPU): launcher check, not a scaling figure" if os.environ.get("IQGPU_BENCH_SHARE_GPU") == "1" else "")},

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define IQGPU_ABI_VERSION 5
+#define IQGPU_ABI_VERSION 6
 
 /* Sample formats: numerically equal to the reference's format_t (include/common_types.h:33-37) */
 enum {
@@ -291,6 +291,14 @@ int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronis
  * "k_cascade2+k_front_s1", "k_front_p0", "k_front", "k_front+k_interp"; "" before the first call.  Diagnostics, bench.py's
  * roofline.kernel */
 const char *iqgpu_chain_front_kernel(const iqgpu_chain *c);
+
+/* Diagnostic switches (ABI v6; no reference counterpart).  The library reads NO switch from the environment: kernel selection and
+ * plan overrides used by the parity tests and the A/B tools go through this one entry point.  A chain takes the table as it
+ * stands when iqgpu_chain_create runs; later changes do not touch existing chains.  name: "no_fast", "agc_nofuse", "force_generic",
+ * "fft_log2n", ... (abi.cpp kDebugNames; an unknown name is IQGPU_EINVAL); value NULL or "" clears the switch, name NULL clears all.
+ * iqgpu_debug_list writes "name=value;name=value" of what is set (bench.py records it in config.debug). */
+int    iqgpu_debug_set(const char *name, const char *value);
+int    iqgpu_debug_list(char *buf, size_t cap);
 
 /* diagnostic hook: copies the chain's 64 KiB scratch (per-phase cycle counters in builds
  * made with -DIQGPU_STAMPS) to the host and clears it */

@@ -134,6 +134,8 @@ SYMBOLS = [
     ("iqgpu_chain_set_profiling", C.c_int, [_vp, C.c_int]),
     ("iqgpu_chain_get_profile", C.c_int, [_vp, C.POINTER(Profile)]),
     ("iqgpu_chain_front_kernel", C.c_char_p, [_vp]),
+    ("iqgpu_debug_set", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("iqgpu_debug_list", C.c_int, [C.c_char_p, _sz]),
     ("iqgpu_chain_debug_read_scratch", C.c_int, [_vp, _vp]),
     ("iqgpu_get_bytes_per_sample", _sz, [C.c_int]),
     ("iqgpu_convert_block_to_cf32", C.c_int, [_vp, _vp, _sz, C.c_int, C.c_float, C.c_int]),
@@ -174,6 +176,33 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+# The library reads no switch from the environment (ABI v6: iqgpu_debug_set).  The tests, bench.py and the A/B scripts under tools/
+# select kernels with IQGPU_<NAME>=... variables of THEIR OWN process; this mirror forwards them -- explicitly, right before a
+# chain is designed or created -- so that `IQGPU_NO_FAST=1 python bench.py` keeps working while a host that links libiqgpu sees
+# no environment dependence at all.
+DEBUG_NAMES = ("force_generic", "no_fast", "agc_nofuse", "no_raw0", "no_kt", "fft_no_r16", "no_fat", "force_fat", "fat", "mid8",
+               "no_s2", "no_fused_move", "no_p0", "no_casc2", "no_mid_8bit", "no_fuse_filter", "tap_fold", "steal", "steal_min",
+               "steal_rounds", "steal_stride", "steal_lanes", "run_weights", "cus", "fft_log2n", "fft_threads", "casc2_min_run",
+               "sysfs_root")
+
+
+def apply_debug_env():
+    """sets the library's diagnostic switches to what this process's IQGPU_<NAME> variables say (all others cleared)"""
+    lib = load()
+    check(lib.iqgpu_debug_set(None, None))
+    for name in DEBUG_NAMES:
+        v = os.environ.get("IQGPU_" + name.upper())
+        if v:
+            check(lib.iqgpu_debug_set(name.encode(), v.encode()))
+
+
+def debug_switches():
+    """what iqgpu_debug_list reports: {name: value} of the switches that are set"""
+    buf = C.create_string_buffer(4096)
+    check(load().iqgpu_debug_list(buf, len(buf)))
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if kv)
 
 
 def check(rc):

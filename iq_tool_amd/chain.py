@@ -27,6 +27,7 @@ def make_desc(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_r
               filter_impl="auto", fft_size=0, device=0, block_samples=0,
               agc=False, agc_profile="digital", agc_target=0.0, agc_clock="samples", agc_chunk_frames=0):
     lib = _lib.load()
+    _lib.apply_debug_env()          # (the test / bench mirror forwards IQGPU_<NAME> variables to iqgpu_debug_set; the library reads none)
     d = ChainDesc()
     lib.iqgpu_chain_desc_init(C.byref(d))
     d.in_format = _fmt(in_format)
@@ -78,6 +79,7 @@ def bind_thread_to_device(ordinal):
     meant to run before the first GPU call and before pinned buffers are allocated).  Returns (node, pci_bus_id, error): node -1
     when the host does not say or nothing could be bound, error None or the library's message."""
     lib = _lib.load()
+    _lib.apply_debug_env()
     node, bus = C.c_int(-1), C.create_string_buffer(64)
     rc = lib.iqgpu_device_numa_node(int(ordinal), C.byref(node), bus, 64)
     if rc != 0:
@@ -92,6 +94,7 @@ class Chain:
     def __init__(self, desc=None, **kw):
         self._lib = _lib.load()
         self.desc = desc if desc is not None else make_desc(**kw)
+        _lib.apply_debug_env()
         h = C.c_void_p()
         check(self._lib.iqgpu_chain_create(C.byref(self.desc), C.byref(h)))
         self._h = h

@@ -176,6 +176,14 @@ int agc_resolve_pending(iqgpu_chain *c, bool *ran)
     if (c->pend.filter) { e = launch_fftconv(c->pend.fc, c->stream); if (e == hipSuccess) e = launch_agc(c->pend.ga, c->stream); }
     else e = launch_agc_fallback(c, c->pend.fb, c->pend.ga);
     if (e != hipSuccess) { c->poisoned = true; return fail(IQGPU_EHIP, "AGC fallback launch failed: %s", hipGetErrorString(e)); }
+    // The fallback REWRITES the output of the launch it belongs to.  When that launch was a submitted batch whose D2H copy is still
+    // to come (the copy runs on another stream and waits for the batch's "kernels done" event only), the event moves behind the
+    // fallback HERE -- whoever asked for the verdict: the next batch's launch, process_device() or reset() running behind submitted
+    // batches (those two left the old event standing and a later collect() copied bytes the fallback was still writing)
+    if (c->pipe_ready && c->pipe_launched > c->pipe_copied) {
+        const hipError_t er = hipEventRecord(c->pipe[(c->pipe_launched - 1) % iqgpu_chain::kPipeSlots].k_done, c->stream);
+        if (er != hipSuccess) { c->poisoned = true; return fail(IQGPU_EHIP, "hipEventRecord failed: %s", hipGetErrorString(er)); }
+    }
     if (ran) *ran = true;
     return IQGPU_OK;
 }

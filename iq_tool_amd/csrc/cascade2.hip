@@ -110,11 +110,14 @@ bool cascade2_shape(const FrontArgs &a)
     return true;
 }
 
+static int g_casc2_min_run = 0;                       // process-wide diagnostic override, set at iqgpu_chain_create
+void cascade2_set_min_run(int n) { g_casc2_min_run = n; }
+
 // ... and the call: streaming runs of two tiles and more, the tile in front of the first run's warm-up loadable, the slice sized for both layouts
 bool cascade2_applies(const FrontArgs &a)
 {
-    // (IQGPU_CASC2_MIN_RUN: diagnostics -- where the two-tile trips start to pay, tools/gpu/r5_casc2_min.py)
-    static const int min_run = [] { const char *e = getenv("IQGPU_CASC2_MIN_RUN"); const int v = e ? atoi(e) : 0; return v > 0 ? v : kCasc2MinRun; }();
+    // (iqgpu_debug_set("casc2_min_run", n): diagnostics -- where the two-tile trips start to pay, tools/gpu/r5_casc2_min.py)
+    const int min_run = g_casc2_min_run > 0 ? g_casc2_min_run : kCasc2MinRun;
     if (!cascade2_shape(a) || a.w_n_stream <= 0 || a.w_run_q < min_run) return false;
     if ((a.w_edge_ta - a.w_warm_tiles - 1) * (int64_t)kWTile - a.rem0 < 0) return false;
     return a.casc_wave_lds >= cascade2_wave_lds(a.casc_K, a.in_fmt);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -28,6 +29,7 @@ using namespace iqgpu;
 // ---- error reporting (abi.cpp) ----
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 const char *last_error_text();
+std::string debug_value(const char *name);             // abi.cpp: the table iqgpu_debug_set keeps ("" when unset)
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

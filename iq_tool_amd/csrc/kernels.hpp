@@ -226,6 +226,7 @@ int cascade_waves(const FrontArgs &a);    // needs casc_wave_lds
 // pointwise switches, casc_K, m[]); the call (needs the run geometry and casc_wave_lds too); bytes of a wave's slice
 bool cascade2_shape(const FrontArgs &a);
 bool cascade2_applies(const FrontArgs &a);
+void cascade2_set_min_run(int n);                       // diagnostics (iqgpu_debug_set "casc2_min_run"); 0 = the built-in bound
 int cascade2_wave_lds(int K, int in_fmt);
 hipError_t launch_cascade2(const FrontArgs &a, hipStream_t s);
 // one half-band stage (m = 10), no dc blocker: wave-autonomous kernel (front_wave.hip)

@@ -42,10 +42,9 @@ int pipe_advance(iqgpu_chain *c, uint64_t upto)
         int rc = IQGPU_OK;
         if (c->pend.valid && c->pipe_launched > 0) {
             // the batch launched last still owes its AGC verdict: read it before this one is queued behind it.  When the fallback
-            // runs it rewrites that batch's output: its "kernels done" event moves behind the fallback, so that the D2H copy waits
-            bool ran = false;
-            rc = agc_resolve_pending(c, &ran); if (rc) return rc;
-            if (ran) HIP_TRY(hipEventRecord(c->pipe[(c->pipe_launched - 1) % iqgpu_chain::kPipeSlots].k_done, c->stream));
+            // runs it rewrites that batch's output: agc_resolve_pending moves its "kernels done" event behind the fallback, so that
+            // the D2H copy waits
+            rc = agc_resolve_pending(c); if (rc) return rc;
         }
         if (ps.frames_in) {
             HIP_TRY(hipEventSynchronize(ps.in_done));

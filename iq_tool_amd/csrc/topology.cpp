@@ -23,18 +23,18 @@ namespace {
 
 struct GpuNode { int kfd_node; unsigned domain, location; };
 
-// "/sys" -- or the root of a stand-in tree (IQGPU_SYSFS_ROOT: tests/test_host_logic.py builds one to exercise the parsing and the
-// binding on a machine without a GPU)
-const char *sysfs_root()
+// "/sys" -- or the root of a stand-in tree (iqgpu_debug_set("sysfs_root", path): tests/test_host_logic.py builds one to exercise the
+// parsing and the binding on a machine without a GPU)
+std::string sysfs_root()
 {
-    const char *r = getenv("IQGPU_SYSFS_ROOT");
-    return r && r[0] ? r : "/sys";
+    const std::string r = debug_value("sysfs_root");
+    return r.empty() ? std::string("/sys") : r;
 }
 
 bool read_properties(int node, unsigned long long *simd, unsigned long long *loc, unsigned long long *dom)
 {
     char path[512];
-    snprintf(path, sizeof(path), "%s/class/kfd/kfd/topology/nodes/%d/properties", sysfs_root(), node);
+    snprintf(path, sizeof(path), "%s/class/kfd/kfd/topology/nodes/%d/properties", sysfs_root().c_str(), node);
     FILE *f = fopen(path, "r");
     if (!f) return false;
     char key[64]; unsigned long long v;
@@ -73,7 +73,7 @@ int lookup(int ordinal, GpuNode *out)
 {
     std::vector<int> nodes;
     char dir[512];
-    snprintf(dir, sizeof(dir), "%s/class/kfd/kfd/topology/nodes", sysfs_root());
+    snprintf(dir, sizeof(dir), "%s/class/kfd/kfd/topology/nodes", sysfs_root().c_str());
     if (DIR *d = opendir(dir)) {
         while (struct dirent *e = readdir(d)) {
             char *end = nullptr;
@@ -145,7 +145,7 @@ extern "C" int iqgpu_device_numa_node(int ordinal, int *node, char *pci_bus_id, 
     char bdf[32], path[512], line[64];
     bdf_of(g, bdf, sizeof(bdf));
     if (pci_bus_id && cap) snprintf(pci_bus_id, cap, "%s", bdf);
-    snprintf(path, sizeof(path), "%s/bus/pci/devices/%s/numa_node", sysfs_root(), bdf);
+    snprintf(path, sizeof(path), "%s/bus/pci/devices/%s/numa_node", sysfs_root().c_str(), bdf);
     if (!read_line(path, line, sizeof(line))) return fail(IQGPU_ENODEV, "%s not readable", path);
     *node = atoi(line);
     return IQGPU_OK;
@@ -161,7 +161,7 @@ extern "C" int iqgpu_bind_thread_to_device(int ordinal, int *node)
     if (node) *node = nd;
     if (nd < 0) return IQGPU_OK;                          // a single-node host (or a VM that hides the topology): nothing to bind to
     char path[512], line[1024];
-    snprintf(path, sizeof(path), "%s/bus/pci/devices/%s/local_cpulist", sysfs_root(), bdf);
+    snprintf(path, sizeof(path), "%s/bus/pci/devices/%s/local_cpulist", sysfs_root().c_str(), bdf);
     cpu_set_t local, allowed, both;
     if (!read_line(path, line, sizeof(line)) || !parse_cpulist(line, &local)) return fail(IQGPU_ENODEV, "%s not usable", path);
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return fail(IQGPU_EINVAL, "sched_getaffinity failed");

@@ -2138,6 +2138,55 @@ def test_agc_verdict_on_the_host_equals_the_queued_fallback(gpu, monkeypatch, ba
         assert st == st_plain, (name, st, st_plain)
 
 
+def test_process_device_behind_a_submitted_batch_whose_verdict_fails(gpu, monkeypatch):
+    """iqgpu_chain_process_device (and reset) may run behind submitted, uncollected batches; they resolve the
+    deferred AGC verdict of the batch launched last.  When that verdict is "fallback", the fallback rewrites the batch's output on
+    the chain's stream while the batch's D2H copy -- on another stream -- waits for the batch's "kernels done" event only: the event
+    has to move behind the fallback whoever asked for the verdict.  A stream whose envelope rejects batches past the lock, taken
+    alternately through submit() and process_device() with the collect() AFTER the process_device() call: bytes and AGC state equal
+    the unfused path's."""
+    from iq_tool_amd.chain import DeviceBuffer, PinnedBuffer
+    batch = 1 << 18
+    n = int(2.4e6 * 9)
+    raw = _enveloped_stream(n, 47, [(0.0, 0.4), (3.0, 0.64), (3.3, 0.4), (4.0, 0.12)])
+    kw = dict(NRSC5, agc=True)
+
+    ch = gpu.Chain(**kw)
+    cap = ch.max_out_frames(batch) * 4
+    pin_in, pin_out = PinnedBuffer(4 * batch), PinnedBuffer(cap)
+    d_in, d_out = DeviceBuffer(4 * batch), DeviceBuffer(cap)
+    outs = []
+    p = 0
+    while p < n:
+        ka = min(batch, n - p)
+        pin_in.array[:4 * ka] = raw[2 * p:2 * (p + ka)].view(np.uint8)
+        got_a, ticket = ch.submit(pin_in.ptr, ka, pin_out.ptr, cap)
+        p += ka
+        kb = min(batch, n - p)
+        got_b = 0
+        if kb:
+            d_in.upload(raw[2 * p:2 * (p + kb)])
+            got_b = ch.process_device(d_in.ptr, kb, d_out.ptr, d_out.nbytes)      # launches batch A first, reads its verdict
+            p += kb
+        ch.collect(ticket)                                                        # ... and only now is A's D2H copy queued
+        outs.append(pin_out.array[:4 * got_a].view(np.int16).copy())
+        if kb:
+            ch.synchronize()
+            outs.append(d_out.download(4 * got_b, np.int16).copy())
+    mixed = np.concatenate(outs)
+    st_mixed = ch.agc_state()
+
+    monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+    ch = gpu.Chain(**kw)
+    plain = np.concatenate([ch.process(raw[2 * q:2 * min(n, q + batch)]) for q in range(0, n, batch)])
+    st_plain = ch.agc_state()
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE")
+    assert st_plain["locked"] and st_plain["gain"] != 1.0
+    assert mixed.size == plain.size
+    assert np.array_equal(mixed, plain), (int((mixed != plain).sum()), int(np.flatnonzero(mixed != plain)[0]))
+    assert st_mixed == st_plain, (st_mixed, st_plain)
+
+
 @pytest.mark.parametrize("fmt,target_hz", [("cs16", 744187.5), ("cu8", 1488375.0)])
 @pytest.mark.parametrize("case", ["steady", "ratchet_and_creep"])
 def test_agc_fused_in_the_filter_epilogue(gpu, oracle, monkeypatch, fmt, target_hz, case):
