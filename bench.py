@@ -101,6 +101,7 @@ def parse():
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--preset-settle", type=float, default=0.4, help="seconds of untimed steps in front of each leg of secondary.presets")
     ap.add_argument("--only-presets", action="store_true", help="diagnostic: skip the headline legs' extras and run secondary.presets only")
+    ap.add_argument("--presets", default="", help="diagnostic: comma-separated names of the shipped presets to run in secondary.presets (default: all seven)")
     ap.add_argument("--secondary-settle", type=float, default=0.7, help="seconds of untimed steps in front of each secondary leg")
     ap.add_argument("--host-log2-frames", type=int, default=30, help="frames per GPU streamed through pinned host buffers in the host_end_to_end leg")
     ap.add_argument("--host-batch-log2", type=int, default=24, help="frames per submit() in the host_end_to_end leg")
@@ -110,6 +111,11 @@ def parse():
                     help="frames per submit() in the host_end_to_end_stub64 leg: the stub's batch when the reader queue is deep (64 reference chunks)")
     ap.add_argument("--stub-log2-frames", type=int, default=28, help="frames per GPU streamed in the host_end_to_end_stub leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` legs (stub-sized host batches, block_samples = 262144, reference-binary probe)")
+    ap.add_argument("--dry-placement", action="store_true",
+                    help="everything an N-GPU run does EXCEPT GPU work: spawn the N ranks, bind each to the NUMA node of its GPU (sysfs; "
+                         "IQGPU_SYSFS_ROOT names a stand-in tree), rendezvous over gloo, gather and check the devices (N distinct PCI "
+                         "addresses), size the pinned and HBM buffers of every leg, run the barrier + MAX plumbing on an empty step, print "
+                         "ONE JSON line.  For rehearsing the first multi-GPU run on a machine without GPUs")
     a = ap.parse_args()
     a.preset = a.config == "preset"
     a.config = 2 if a.preset else int(a.config)
@@ -440,7 +446,10 @@ def shipped_presets(args, dist, dev, local_rank, world, rank):
     whole step (algorithmic bytes in + out over the device time of all its kernels), which kernels ran and what each took"""
     import torch
     out = {}
+    only = [x for x in args.presets.split(",") if x]
     for name in PRESETS:
+        if only and name not in only:
+            continue
         try:
             c = run_case(args, dist, dev, local_rank, world, rank, 2, False, args.secondary_steps, 2, args.preset_settle, 28, shipped=name)
             out[name] = {"ms_per_step": round(c["dt"] / c["steps"] * 1e3, 4), "frames_per_step": c["frames"],
@@ -607,6 +616,8 @@ def main():
         dist = dist_mod
     if os.environ.get("IQGPU_BENCH_STUB") == "1":
         return stub_main(args, dist, world, rank)     # launcher / reduction plumbing test (tests/test_host_logic.py)
+    if args.dry_placement:
+        return dry_placement(args, dist, world, rank, local_rank, numa)
 
     import iq_tool_amd
     from iq_tool_amd import synth
@@ -759,6 +770,51 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dry_placement(args, dist, world, rank, local_rank, numa):
+    """--dry-placement: the N-rank run up to -- and without -- its first GPU call.  What has run by the time this
+    function is entered is the real thing: fresh child processes, `import torch`, the sysfs walk and the binding of this rank to its
+    GPU's NUMA node, the gloo rendezvous and its first barrier.  Here: every rank reports where it sits and what it WOULD allocate,
+    rank 0 checks that N ranks mean N distinct PCI addresses (from sysfs: there is no runtime to ask) on the right nodes, and one
+    empty timed region exercises barrier + MAX.  No HIP call anywhere (iqgpu_device_count is never asked)."""
+    import iq_tool_amd
+    from iq_tool_amd import chain as chain_mod
+    frames = 1 << args.log2_frames
+    kw = dict(in_format="cs16", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=744187.5, shift_hz=200e3)
+    n_out = chain_mod.design_out_frames(frames, **kw)                     # the create-time design path: host only
+    depth = 8
+    host_batch = 1 << args.host_batch_log2
+    host_cap = chain_mod.design_out_frames(host_batch, **kw) + 64
+    mine = {"rank": rank, "ordinal": local_rank, "host": socket.gethostname(), "pid": os.getpid(),
+            "hbm_bytes": frames * 4 + (n_out + 64) * 4,
+            "pinned_bytes": depth * (host_batch * 4 + host_cap * 4),
+            "cpus": sorted(os.sched_getaffinity(0))}
+    mine.update(numa)
+    devices = [mine]
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+    dt = timed_region(dist, lambda: None, lambda: None, args.steps)
+    problems = []
+    ids = [(d["host"], d["numa_pci_bus_id"]) for d in devices]
+    if any(not d["numa_pci_bus_id"] for d in devices):
+        problems.append("a rank could not find the PCI address of its GPU in sysfs")
+    elif len(set(ids)) != world:
+        problems.append("%d ranks do not sit on %d distinct GPUs" % (world, world))
+    if os.environ.get("IQGPU_BENCH_NO_BIND") != "1":
+        for d in devices:
+            if not d["numa_bound"]:
+                problems.append("rank %d is not bound: %s" % (d["rank"], d.get("numa_note", "no reason given")))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-placement (no GPU work)", "n_gpus": world, "steps": args.steps, "barrier_and_max_s": dt,
+                          "frames_per_step_per_gpu": frames, "out_frames_per_step_per_gpu": n_out, "devices": devices,
+                          "distinct_gpus": len(set(ids)), "ok": not problems, "problems": problems,
+                          "sharding": "independent stream per GPU, no collective (gloo barrier + MAX only)"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if problems:
+        raise SystemExit(4)
 
 
 def stub_main(args, dist, world, rank):

@@ -199,7 +199,12 @@ int    iqgpu_chain_process_device(iqgpu_chain *c, const void *d_raw_in, size_t f
  * The I/Q factors a batch runs with are those in force at its submit().  raw_in / out should be pinned (iqgpu_host_malloc_pinned) --
  * pageable memory works but serialises -- and must stay untouched until the ticket is collected.  Batches are
  * processed in submit order: the stream is continuous across them exactly as across iqgpu_chain_process calls
- * (this is what replaces the reference's chunk hand-off between its three stage threads, src/pipeline.c:436-595). */
+ * (this is what replaces the reference's chunk hand-off between its three stage threads, src/pipeline.c:436-595).
+ * How long submit() may block: normally the ~10 us of queueing.  On a chain with the digital output AGC fused into its last kernel
+ * (agc_enable, profile `digital`, past the lock) the launch of batch N first reads the AGC verdict of batch N-1 from a pinned word,
+ * i.e. it waits until batch N-1's kernels have FINISHED (polled; after 0.25 s it falls back to a stream synchronise): submit() then
+ * blocks for at most one batch's kernel time (0.02 - 1.3 ms at 2^18 - 2^28 frames).  Chains without that AGC never wait for device work
+ * in submit(). */
 int    iqgpu_chain_submit(iqgpu_chain *c, const void *raw_in, size_t frames_in,
                           void *out, size_t out_capacity_bytes, size_t *frames_out, uint64_t *ticket);
 int    iqgpu_chain_collect(iqgpu_chain *c, uint64_t ticket);

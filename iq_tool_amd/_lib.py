@@ -183,8 +183,8 @@ def load():
 # chain is designed or created -- so that `IQGPU_NO_FAST=1 python bench.py` keeps working while a host that links libiqgpu sees
 # no environment dependence at all.
 DEBUG_NAMES = ("force_generic", "no_fast", "agc_nofuse", "no_raw0", "no_kt", "fft_no_r16", "no_fat", "force_fat", "fat", "mid8",
-               "no_s2", "no_fused_move", "no_p0", "no_casc2", "no_mid_8bit", "no_fuse_filter", "tap_fold", "steal", "steal_min",
-               "steal_rounds", "steal_stride", "steal_lanes", "run_weights", "cus", "fft_log2n", "fft_threads", "casc2_min_run",
+               "no_s2", "no_fused_move", "no_p0", "no_casc2", "no_mid_8bit", "fuse_filter", "tap_fold", "steal", "steal_min",
+               "steal_rounds", "steal_stride", "steal_lanes", "run_weights", "cus", "fft_log2n", "fft_threads", "fft_geometry", "casc2_min_run",
                "sysfs_root")
 
 

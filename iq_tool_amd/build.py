@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiqgpu.so")
-SOURCES = ["design.cpp", "abi.cpp", "plan.cpp", "process.cpp", "agc_host.cpp", "pipeline.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "topology.cpp", "kernels.hip", "front_wave.hip", "front_fat.hip", "front_mid.hip", "front_p0.hip", "front_s2.hip", "cascade_wave.hip", "cascade2.hip", "fftconv.hip", "interp.hip", "agc.hip"]
-HEADERS = ["design.hpp", "chain.hpp", "kernels.hpp", "dsp_device.hpp", "wave_common.hpp", "front_tiles.hpp", "cascade_tiles.hpp", "front_fat_common.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
+SOURCES = ["design.cpp", "abi.cpp", "plan.cpp", "process.cpp", "agc_host.cpp", "pipeline.cpp", "iq_optimizer.cpp", "wav_meta.cpp", "topology.cpp", "kernels.hip", "front_wave.hip", "front_fat.hip", "front_mid.hip", "front_p0.hip", "front_s2.hip", "cascade_wave.hip", "cascade2.hip", "fftconv.hip", "p0fft_cu8.hip", "p0fft_cs8.hip", "p0fft_cs16.hip", "interp.hip", "agc.hip"]
+HEADERS = ["design.hpp", "chain.hpp", "kernels.hpp", "dsp_device.hpp", "wave_common.hpp", "front_tiles.hpp", "cascade_tiles.hpp", "front_fat_common.hpp", "front_p0_common.hpp", "fft16.hpp", "p0fft.hpp", os.path.join("..", "..", "include", "iqgpu.h")]
+# headers only some sources include: {header: prefixes of the sources that depend on it} (the rest depend on every header)
+PRIVATE_HEADERS = {"fft16.hpp": ("fftconv.hip", "p0fft_"), "p0fft.hpp": ("p0fft_",)}
 HARNESS_SRC = os.path.join(CSRC, "harness", "iqgpu_run.c")
 HARNESS_BIN = os.path.join(LIBDIR, "iqgpu_run")
 
@@ -49,10 +51,10 @@ def build_lib(force=False, verbose=False, extra_flags=(), out=None):
     # (a stable digest: str hashes are randomised per process, which used to defeat the incremental rebuild and pile up directories)
     objdir = os.path.join(LIBDIR, "obj" + ("" if not extra_flags else "_" + hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:10]))
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     for sname in SOURCES:
         src, obj = os.path.join(CSRC, sname), os.path.join(objdir, sname + ".o")
+        hdrs = [os.path.join(CSRC, h) for h in HEADERS if h not in PRIVATE_HEADERS or sname.startswith(PRIVATE_HEADERS[h])]
         if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc(), *FLAGS, *SOURCE_FLAGS.get(sname, []), *extra_flags, "-c", src, "-o", obj])
 

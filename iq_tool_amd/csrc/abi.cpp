@@ -25,8 +25,8 @@ int fail(int code, const char *fmt, ...)
 // ------------------------------------------------------------------------------------------------
 static const char *const kDebugNames[] = {
     "force_generic", "no_fast", "agc_nofuse", "no_raw0", "no_kt", "fft_no_r16", "no_fat", "force_fat", "fat", "mid8", "no_s2",
-    "no_fused_move", "no_p0", "no_casc2", "no_mid_8bit", "no_fuse_filter", "tap_fold", "steal", "steal_min", "steal_rounds",
-    "steal_stride", "steal_lanes", "run_weights", "cus", "fft_log2n", "fft_threads", "casc2_min_run", "sysfs_root",
+    "no_fused_move", "no_p0", "no_casc2", "no_mid_8bit", "fuse_filter", "tap_fold", "steal", "steal_min", "steal_rounds",
+    "steal_stride", "steal_lanes", "run_weights", "cus", "fft_log2n", "fft_threads", "fft_geometry", "casc2_min_run", "sysfs_root",
 };
 static std::mutex g_dbg_mu;
 static std::map<std::string, std::string> &dbg_table() { static std::map<std::string, std::string> t; return t; }
@@ -181,7 +181,8 @@ int design_chain(iqgpu_chain *c, const iqgpu_chain_desc *d)
                  (on("fft_no_r16") ? kDbgFftNoR16 : 0u) | (on("no_fat") ? kDbgNoFat : 0u) |
                  (on("force_fat") ? kDbgForceFat : 0u) | (on("fat") ? kDbgUseFat : 0u) | (on("mid8") ? kDbgMid8 : 0u) |
                  (on("no_s2") ? kDbgNoS2 : 0u) | (on("no_fused_move") ? kDbgNoFusedMove : 0u) | (on("no_p0") ? kDbgNoP0 : 0u) |
-                 (on("no_casc2") ? kDbgNoCasc2 : 0u) | (on("no_mid_8bit") ? kDbgNoMid8bit : 0u);
+                 (on("no_casc2") ? kDbgNoCasc2 : 0u) | (on("no_mid_8bit") ? kDbgNoMid8bit : 0u) |
+                 (on("fuse_filter") ? kDbgFuseFilter : 0u);
         std::string v;
         if (!(v = debug_value("tap_fold")).empty()) c->tap_fold_env = atoi(v.c_str()) != 0 ? 1 : 0;
         if (!(v = debug_value("steal")).empty()) c->steal = v[0] == '1';
@@ -431,9 +432,30 @@ extern "C" int iqgpu_chain_create(const iqgpu_chain_desc *d, iqgpu_chain **out)
             int lg = (c->dbg & kDbgFftNoR16) ? 8 : 10;
             while ((size_t)(1 << lg) < 4 * (Lt - 1) && (1 << lg) < 4096) ++lg;
             while ((size_t)(1 << lg) < 2 * (Lt - 1)) ++lg;
+            // round 6: a chain WITHOUT a half-band stage whose filter stands behind the resampler CAN run both in one kernel (k_p0fft16,
+            // p0fft.hpp: no cf32 stream in HBM) -- built, byte-equal to the two kernels on the same windows, and slower than they are
+            // (1.43 ms against 1.17 - 1.25 per 2^28 cu8 frames: the polyphase role's registers leave the transforms two waves per SIMD,
+            // profiles/r06_fused_filter.md): opt-in, iqgpu_debug_set("fuse_filter", "1").  That kernel's workgroup carries 35 KB of tap
+            // planes beside its transform buffer, which wants 4096 points (four waves per workgroup, two workgroups per CU) -- the
+            // chain's transform is then that size on either path
+            // (diagnostics: "fft_geometry" = "keep" runs the two kernels at the fused kernel's transform size and on its windows -- win
+            //  stream samples and vout outputs per block -- so that the two paths can be compared byte for byte)
+            c->fft_keep_geometry = debug_value("fft_geometry") == "keep";
+            if (c->decim && c->S == 0 && !c->late && c->fp.post_resample && !(c->dbg & (kDbgFftNoR16 | kDbgNoP0 | kDbgNoFusedMove)) &&
+                ((c->dbg & kDbgFuseFilter) || c->fft_keep_geometry)) {
+                FrontArgs ff{};
+                ff.dbg = c->dbg; ff.S = 0; ff.in_fmt = c->desc.in_format; ff.gain = c->desc.gain;
+                ff.iq_enable = c->desc.iq_correct_enable ? 1 : 0; ff.dc_enable = c->dc ? 1 : 0; ff.nco_mode = c->nco_mode; ff.pnco_mode = 0;
+                ff.step = c->rp.step;
+                const int lgf = lg < 12 ? 12 : lg;
+                if (p0fft_shape(ff, lgf, (int)Lt) && p0fft_geometry(lgf, (int)Lt, &c->fuse_win, &c->fuse_vout)) {
+                    c->fuse_filter = (c->dbg & kDbgFuseFilter) != 0; lg = lgf;
+                }
+            }
             { const std::string e = debug_value("fft_log2n"); if (!e.empty()) { const int v = atoi(e.c_str()); if (v >= 1 && (1 << v) <= kMaxFftN
                 && (size_t)(1 << v) >= 2 * (Lt - 1)) lg = v; } }
             { const std::string e = debug_value("fft_threads"); if (!e.empty()) c->fft_threads = atoi(e.c_str()); }
+            if (c->fuse_win > 0 && !p0fft_geometry(lg, (int)Lt, &c->fuse_win, &c->fuse_vout)) { c->fuse_filter = false; c->fuse_win = c->fuse_vout = 0; }   // (a transform size forced by hand)
             const int N = 1 << lg;
             c->fft_log2n = lg;
             // H = FFT_N(taps) / N and the twiddle table, in double on the host (once per chain)
@@ -515,7 +537,7 @@ extern "C" int iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *i
         fill_info(c, info);
         if (filter_taps_re_im) {
             const size_t n = c->fp.taps.size() < cap_taps ? c->fp.taps.size() : cap_taps;
-            memcpy(filter_taps_re_im, c->fp.taps.data(), n * sizeof(cfloat));
+            if (n) memcpy(filter_taps_re_im, c->fp.taps.data(), n * sizeof(cfloat));     // (a chain without a filter: data() of an empty vector is null, and memcpy's arguments are declared non-null even for 0 bytes -- UBSan, round 6)
         }
         if (hb_taps) {
             size_t o = 0;
@@ -524,7 +546,7 @@ extern "C" int iqgpu_design_probe(const iqgpu_chain_desc *d, iqgpu_chain_info *i
         }
         if (arb_proto && c->resample) {
             const size_t n = c->rp.arb_proto.size() < cap_arb ? c->rp.arb_proto.size() : cap_arb;
-            memcpy(arb_proto, c->rp.arb_proto.data(), n * sizeof(float));
+            if (n) memcpy(arb_proto, c->rp.arb_proto.data(), n * sizeof(float));
         }
     }
     delete c;
@@ -560,7 +582,7 @@ extern "C" int iqgpu_chain_get_filter_taps(const iqgpu_chain *c, float *re_im, s
 {
     if (!c) return fail(IQGPU_EINVAL, "NULL chain");
     const size_t n = c->fp.taps.size();
-    if (re_im) memcpy(re_im, c->fp.taps.data(), (n < cap_taps ? n : cap_taps) * sizeof(cfloat));
+    if (re_im && n && cap_taps) memcpy(re_im, c->fp.taps.data(), (n < cap_taps ? n : cap_taps) * sizeof(cfloat));
     return (int)n;
 }
 // ---- I/Q optimiser hand-off (src/pipeline.c:468-476, src/utility_threads.c:35-47) -------------------------

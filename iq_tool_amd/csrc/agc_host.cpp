@@ -128,6 +128,7 @@ int Call::stage_agc_verify_and_fallback_filter(const FftConvArgs &spec)
     fc.agc_fused = 0; fc.agc_state = nullptr; fc.agc_peak2 = nullptr;
     fc.out_fmt = IQGPU_FMT_CF32; fc.out = c->abuf.p;
     fc.move_dst = nullptr; fc.move_src = nullptr; fc.move_n = 0;
+    fc.feed.write_state = 0;                              // (k_p0fft16: the fused launch has left the next call's state)
     fc.run_if = c->d_agc_flag;
     AgcArgs ga = va;
     ga.peak2_fallback = nullptr; ga.verdict_host = nullptr;

@@ -162,6 +162,9 @@ struct iqgpu_chain {
     // ... and the AGC fused into the user filter's epilogue (k_fftconv16) where a filter stands between the resampler and the AGC:
     // the shipped -usb / -lsb presets
     bool agc_fusable_filter = false;
+    // round 6: resampler -> post-resample overlap-save filter in ONE kernel (k_p0fft16, fftconv.hip): the chain's shape allows it,
+    // with the window geometry it runs (fuse_win stream samples per block, fuse_vout outputs)
+    bool fuse_filter = false; int fuse_win = 0, fuse_vout = 0; bool fft_keep_geometry = false;
     DevBuf ibuf[2]; int icur = 0;  // k_interp input: [ihist history][new samples]
     InterpArgs ia{};              // geometry of the r >= 1 path
     int ihist = 0;
@@ -264,6 +267,7 @@ struct Call {
     bool fat = false;                        // fast_s1 as k_front_fat (front_fat.hip): 8 waves per CU, 1024-frame tiles
     bool mid = false;                        // ... or as k_front_mid (front_mid.hip): 12 waves per CU, 768-frame tiles
     bool p0 = false;                         // fast_s0 as k_front_p0 (front_p0.hip): output-major steps, taps kept in registers
+    bool fusef = false;                      // ... or, with a post-resample filter behind it, resampler AND filter as k_p0fft16 (no front launch at all)
     bool s2 = false;                         // casc with both stages fused into k_front_s2 (front_s2.hip); cplan is then the LAST stage's plan
     int64_t s2_in_tiles = 0;                 //   ... and this the number of 512-frame input tiles of the call
     int wtile, casc_K, rem_k;

@@ -177,7 +177,22 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
     // the time of 16)
     const uint32_t th_lane = a.nco_theta0 + (uint32_t)(4 * lane) * a.nco_dtheta;
     const uint32_t tho_lane = a.nco_theta0 + (uint32_t)(2 * NL * lane - 19) * a.nco_dtheta;
+#ifdef IQGPU_DIAG_NCOHOLD
+    // DIAGNOSTIC build (timing only, wrong bytes): the phasors are looked up for the run's first tile and then HELD -- the most a
+    // scheme that re-reads a lane's phasors only when their table index moves on could save (round 6, profiles/r06_headline.md)
+    bool diag_nco_first = true;
+#endif
     auto nco_lookup = [&](int64_t T) {
+#ifdef IQGPU_DIAG_NCOHOLD
+        if (!diag_nco_first) {
+#pragma unroll
+            for (int c = 0; c < G::NC; ++c) { asm volatile("" : "+v"(cs_n[c][0])); asm volatile("" : "+v"(cs_n[c][1])); }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(cs_o[i]));
+            return;
+        }
+        diag_nco_first = false;
+#endif
         const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(T * G::TILE) * a.nco_dtheta));
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {

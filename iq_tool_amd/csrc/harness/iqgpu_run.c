@@ -29,6 +29,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +51,7 @@ typedef struct {
     long long synthetic_frames;       /* > 0: no input file, reuse one pinned buffer (PCIe-inclusive rate) */
     int have_hash; unsigned long long hash_seed;   /* ... or generate shard s as the counter-hash stream of seed hash_seed + s */
     int no_bind;                      /* --no-numa-bind */
+    int dry;                          /* --dry-placement: plan, bind, size the buffers, report -- no GPU call */
     int quiet;
 } Options;
 
@@ -61,6 +63,7 @@ typedef struct {
     long long frames_out;             /* result */
     long long planned_out;            /* iqgpu_design_out_frames(frames): what out_offset_bytes of the NEXT shard was computed from */
     int device, numa_node;            /* where it ran; -1 = the host does not say / not bound */
+    char bus_id[64]; int cpus_allowed; long long pinned_bytes, hbm_bytes;   /* --dry-placement's report */
     double seconds, stream_seconds;   /* whole shard incl. set-up / copy-process-copy loop only */
     int rc;
     char err[256];
@@ -128,6 +131,24 @@ static void *run_shard(void *arg)
      * touches that GPU.  Best effort: a host that hides its topology leaves the thread where it is (numa_node stays -1) */
     sh->device = d.device_ordinal; sh->numa_node = -1;
     if (!o->no_bind) { int node = -1; if (iqgpu_bind_thread_to_device(d.device_ordinal, &node) == IQGPU_OK) sh->numa_node = node; }
+
+    if (o->dry) {
+        /* --dry-placement: everything the first multi-GPU run does BEFORE its first GPU call -- the device of
+         * this shard, its PCI address and NUMA node from sysfs, the binding, the sizes of the buffers it would pin and allocate --
+         * and nothing after it.  The capacity rule without a handle: src/pipeline.c:246-258 on the designed ratio */
+        int node = -1;
+        sh->bus_id[0] = 0;
+        (void)iqgpu_device_numa_node(d.device_ordinal, &node, sh->bus_id, sizeof(sh->bus_id));
+        if (sh->numa_node < 0 && o->no_bind) sh->numa_node = node;
+        { cpu_set_t m; CPU_ZERO(&m); sh->cpus_allowed = pthread_getaffinity_np(pthread_self(), sizeof(m), &m) == 0 ? CPU_COUNT(&m) : -1; }
+        size_t cap_frames = 0;
+        CK(iqgpu_design_out_frames(&d, o->chunk_frames, &cap_frames));
+        cap_frames += 64;
+        sh->pinned_bytes = (long long)NBUF * (long long)(o->chunk_frames * ibps + cap_frames * obps);
+        sh->hbm_bytes = sh->pinned_bytes;
+        sh->frames_out = sh->planned_out;
+        goto done;
+    }
 
     CK(iqgpu_chain_create(&d, &chain));
     const size_t chunk = o->chunk_frames;
@@ -235,7 +256,8 @@ static void usage(void)
             "          [--iq-factors MAG:PHASE] [--no-resample] [--lowpass HZ] [--highpass HZ] [--pass-range A:B] [--stopband A:B]\n"
             "          [--transition-width HZ] [--attenuation DB] [--filter-taps N] [--filter-type fir|fft] [--filter-fft-size N]\n"
             "          [--chunk-frames N (default 4194304)] [--shards N] [--devices N] [--device D] [--synthetic FRAMES [--synthetic-hash SEED]]\n"
-            "          [--no-numa-bind] [--quiet]\n");
+            "          [--no-numa-bind] [--quiet] [--debug NAME=VALUE (iqgpu_debug_set)]\n"
+            "          [--dry-placement (plan the shards, bind every shard thread, size its buffers, report as JSON: no GPU call)]\n");
 }
 
 int main(int argc, char **argv)
@@ -287,6 +309,14 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--synthetic")) o.synthetic_frames = atoll(NEXT);
         else if (!strcmp(a, "--synthetic-hash")) { o.have_hash = 1; o.hash_seed = strtoull(NEXT, NULL, 0); }
         else if (!strcmp(a, "--no-numa-bind")) o.no_bind = 1;
+        else if (!strcmp(a, "--dry-placement")) o.dry = 1;
+        else if (!strcmp(a, "--debug")) {              /* --debug name=value -> iqgpu_debug_set (the library reads no environment) */
+            char kv[512]; snprintf(kv, sizeof(kv), "%s", NEXT);
+            char *eq = strchr(kv, '=');
+            if (!eq) { fprintf(stderr, "--debug wants name=value\n"); return 2; }
+            *eq = 0;
+            if (iqgpu_debug_set(kv, eq + 1) != IQGPU_OK) { fprintf(stderr, "%s\n", iqgpu_last_error()); return 2; }
+        }
         else if (!strcmp(a, "--quiet")) o.quiet = 1;
         else { usage(); return 2; }
     }
@@ -324,7 +354,7 @@ int main(int argc, char **argv)
         sh[s].planned_out = (long long)nout;
         off += (long long)nout * (long long)obps;
     }
-    if (o.out_path) { int fd = open(o.out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) close(fd); }
+    if (o.out_path && !o.dry) { int fd = open(o.out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) close(fd); }
 
     const double t0 = now_s();
     pthread_t *th = (pthread_t *)calloc((size_t)o.shards, sizeof(pthread_t));
@@ -339,6 +369,20 @@ int main(int argc, char **argv)
         if (sh[s].stream_seconds > stream_s) stream_s = sh[s].stream_seconds;
     }
     const double dt = now_s() - t0;
+    if (o.dry) {
+        /* one JSON line: the placement as planned; `distinct_devices` is what an N-shard job on N GPUs must show */
+        int distinct = 0;
+        for (int s = 0; s < o.shards; s++) { int seen = 0; for (int q = 0; q < s; q++) if (!strcmp(sh[q].bus_id, sh[s].bus_id) && sh[q].device == sh[s].device) seen = 1; if (!seen) distinct++; }
+        printf("{\"dry_placement\": true, \"frames_in\": %lld, \"frames_out\": %lld, \"shards\": %d, \"devices\": %d, \"distinct_devices\": %d, \"per_shard\": [",
+               total_frames, frames_out, o.shards, o.devices, distinct);
+        for (int s = 0; s < o.shards; s++)
+            printf("%s{\"shard\": %d, \"device\": %d, \"pci_bus_id\": \"%s\", \"numa_node\": %d, \"cpus_allowed\": %d, \"first_frame\": %lld, \"frames_in\": %lld, \"planned_out\": %lld, "
+                   "\"out_offset_bytes\": %lld, \"pinned_bytes\": %lld, \"hbm_bytes\": %lld}", s ? ", " : "", s, sh[s].device, sh[s].bus_id, sh[s].numa_node, sh[s].cpus_allowed,
+                   sh[s].first_frame, sh[s].frames, sh[s].planned_out, sh[s].out_offset_bytes, sh[s].pinned_bytes, sh[s].hbm_bytes);
+        printf("]}\n");
+        free(th); free(sh);
+        return rc;
+    }
     if (!o.quiet) {
         printf("{\"frames_in\": %lld, \"frames_out\": %lld, \"shards\": %d, \"devices\": %d, \"seconds\": %.6f, \"msps_end_to_end\": %.3f, \"stream_seconds\": %.6f, \"msps_streaming\": %.3f, "
                "\"h2d_GBs\": %.3f, \"d2h_GBs\": %.3f, \"in_bytes_per_frame\": %zu, \"out_bytes_per_frame\": %zu, \"input\": \"%s\", \"per_shard\": [",

@@ -67,6 +67,8 @@ enum : uint32_t { kDbgNoFast = 1u, kDbgAgcNoFuse = 2u, kDbgNoRaw0 = 4u, kDbgNoKT
                   kDbgNoMid8bit = 8192u,   // IQGPU_NO_MID_8BIT=1: S = 1 chains with 8-bit frames on either side keep k_front_s1 instead of k_front_mid
                   kDbgNoCasc2 = 4096u,     // IQGPU_NO_CASC2=1: raw cu8 cascades keep k_cascade's one tile per trip instead of k_cascade2's two
                   kDbgNoP0 = 2048u,        // IQGPU_NO_P0=1: chains without a half-band stage keep k_front_s1<S0> instead of k_front_p0
+                  kDbgFuseFilter = 16384u, // fuse_filter=1: S = 0 chains with a filter behind the resampler run k_p0fft16 (one kernel, no cf32 stream) instead of
+                                           // k_front_p0 + k_fftconv16 -- opt-in: parity-green and SLOWER than the two kernels (profiles/r06_fused_filter.md)
                   kDbgNoFusedMove = 1024u }; // IQGPU_NO_FUSED_MOVE=1: the filter's history moves by a copy kernel, not inside the filter kernel
 
 struct FrontArgs {
@@ -407,6 +409,24 @@ IQGPU_HD inline int64_t agc_chunk_of_output(const AgcGeom &g, int64_t k)
 constexpr int kMaxFftN = 16384;    // k_fftconv16 transforms in place: N cf32 = 128 KiB (+ pad) of LDS
 constexpr int kMaxFftN4 = 8192;    // the radix-4 ping-pong kernel (only used below N = 1024)
 constexpr int kFftMaxThreads = 1024;
+// k_p0fft16 (round 6): the resampler of a chain WITHOUT a half-band stage computed straight into the filter's overlap-save windows
+// -- a window sample IS a polyphase output -- so that no cf32 stream stands between the two in HBM.  What the window fill needs of
+// the front kernel's arguments (k_front_p0's: front_p0.hip):
+struct P0Feed {
+    const void  *raw;         // frames_in new frames, in_fmt (cu8 / cs8 / cs16); NULL = not fused (k_fftconv16 reads fbuf)
+    const cf2   *hist_in;     // hist_cap processed samples that precede this call
+    cf2         *hist_out;    // the same for the next call (written when write_state)
+    int64_t      frames_in;
+    int32_t      hist_cap, in_fmt;
+    const float *arb_table;   // [256][16]
+    uint32_t     step, tap_fold;
+    uint64_t     phi0;        // phase of output 0 of the call
+    int64_t      n_res;       // resampler outputs of this call: fbuf entry pre + k <-> output k
+    int64_t      pre;         // fbuf entries in front of them: the filter's L - 1 history + the samples still pending (read from fbuf)
+    int64_t      k_a, k_b;    // outputs [k_a, k_b): every one of the 24 frames a lane loads around them lies inside the call's input
+    int32_t      write_state; // 1: the launch also leaves hist_out and the next call's buffer front (move_dst); 0: the AGC fallback
+    int32_t      grid;        // persistent workgroups of the launch (two per CU: what their LDS -- transform buffer + tap planes -- allows)
+};
 struct FftConvArgs {
     uint32_t   dbg;           // kDbg* switches of the chain
     const cf2 *fbuf;          // [ntaps-1 history][pending + new samples]
@@ -435,8 +455,24 @@ struct FftConvArgs {
     unsigned long long *agc_peak2;
     AgcGeom    agc_geom;
     const int32_t *run_if;    // not NULL: the launch does nothing unless *run_if != 0 (the fallback behind a fused launch)
+    // overlap-save geometry other than the default (0 = default: win = N, vout = N - (ntaps - 1)): a block's window holds `win` stream
+    // samples -- the rest of its N points is zero -- and the block emits `vout` <= win - (ntaps - 1) outputs.  k_p0fft16 fills windows
+    // in whole polyphase steps (win a multiple of 320) and moves from block to block by a whole number of steps (vout too), so that a
+    // lane-slot's arm -- and with it the taps it holds -- repeats; k_fftconv16 takes the same two numbers so that the two paths can be
+    // compared byte for byte (radix-16 kernels only)
+    int32_t    win, vout;
+    P0Feed     feed;
 };
 hipError_t launch_fftconv(const FftConvArgs &a, hipStream_t s);
+// the geometry k_p0fft16 runs a filter of ntaps at N = 2^log2n with: false when no whole number of steps fits
+bool p0fft_geometry(int log2n, int ntaps, int *win, int *vout);
+// which chains (the front kernel's shape test on the FRONT arguments -- k_front_p0's, cf32 out -- plus the filter's transform)
+bool p0fft_shape(const FrontArgs &front, int log2n, int ntaps);
+hipError_t launch_p0fft_cu8(const FftConvArgs &a, size_t lds, hipStream_t s);     // p0fft_cu8.hip / _cs8 / _cs16: the instantiations per input format
+hipError_t launch_p0fft_cs8(const FftConvArgs &a, size_t lds, hipStream_t s);
+hipError_t launch_p0fft_cs16(const FftConvArgs &a, size_t lds, hipStream_t s);
+size_t p0fft_tap_lds();                                                               // bytes of the tap planes a workgroup carries (p0fft_cu8.hip)
+constexpr int64_t kP0FftMaxKeep = 1 << 15;     // history + pending samples one workgroup recomputes for the next call: longer -> not fused
 bool fftconv_agc_fusable(int log2n, int ntaps, uint32_t dbg);   // which filters have the epilogue (the radix-16 kernel)
 
 // ---------------------------------------------------------------------------------------------

@@ -190,7 +190,15 @@ void Call::plan_geometry()
                 }
             }
         }
-        // S == 2: both stages in ONE kernel (k_front_s2, front_s2.hip), planned in tiles of the LAST stage -- 512 intermediate samples
+        // ... and with a user filter behind the resampler on the overlap-save path: resampler AND filter in one kernel (k_p0fft16,
+        // fftconv.hip, round 6) -- no front launch, no cf32 stream in HBM.  Long calls only (as k_front_p0); the next call's filter
+        // front (history + pending samples) is recomputed by one workgroup, so it has to be short
+        fusef = false;
+        if (c->fuse_filter && filt && fast_s0 && !casc && p.n_emit > 0 && (int64_t)(L1 + p.fpending_next) <= kP0FftMaxKeep &&
+            ((int64_t)frames_in >= ((int64_t)1 << 22) || (c->dbg & kDbgForceFat))) {
+            fusef = true; p0 = false;
+        }
+                // S == 2: both stages in ONE kernel (k_front_s2, front_s2.hip), planned in tiles of the LAST stage -- 512 intermediate samples
         // = 1024 input frames -- on the intermediate stream's own geometry.  Its streaming waves read the input as whole 16-byte
         // words from the start of a decimation group; calls that do not start on one, or are shorter than the histories they have
         // to leave behind, keep the two kernels (same bytes either way).

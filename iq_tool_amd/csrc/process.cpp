@@ -47,7 +47,8 @@ int Call::stage_dc_carries()
 int Call::prepare_buffers()
 {
     if (filt) {
-        const size_t need = (L1 + (size_t)c->fpending + (size_t)p.n_res + 1) * sizeof(cf2);
+        // (k_p0fft16 computes the resampler's outputs inside the filter kernel: only the buffer front exists)
+        const size_t need = (L1 + (size_t)c->fpending + (fusef ? 0 : (size_t)p.n_res) + 1) * sizeof(cf2);
         int rc = c->fbuf[c->fcur].ensure_keep(need, (L1 + (size_t)c->fpending) * sizeof(cf2), c->stream);
         if (rc) return rc;
         fcur = (cf2 *)c->fbuf[c->fcur].p;
@@ -102,6 +103,11 @@ int Call::prepare_buffers()
 
 int Call::stage_front()
 {
+    if (fusef) {
+        // resampler and filter run as ONE kernel, launched by stage_filter (which also turns the history buffers over)
+        snprintf(c->front_kernel, sizeof(c->front_kernel), "k_p0fft16");
+        return IQGPU_OK;
+    }
     FrontArgs a{};
     a.dbg = c->dbg;
     a.raw = d_raw_in;
@@ -263,6 +269,31 @@ int Call::stage_filter()
         ca.pnco_mode = fa.pnco_mode; ca.pnco_theta0 = fa.pnco_theta0; ca.pnco_dtheta = fa.pnco_dtheta; ca.nco_tab = fa.nco_tab;
         ca.out_fmt = fa.out_fmt; ca.out = fa.out;
         ca.move_dst = fa.move_dst; ca.move_src = fa.move_src; ca.move_n = fa.move_n;
+        if (fusef) {
+            // k_p0fft16: the window fill needs what the front kernel would have been given
+            if (!fused_move) return fail(IQGPU_EINVAL, "internal: the fused filter path needs the history move in the kernel");
+            P0Feed &f = ca.feed;
+            f.raw = d_raw_in; f.hist_in = c->d_hist[c->hist_cur]; f.hist_out = c->d_hist[c->hist_cur ^ 1];
+            f.frames_in = (int64_t)frames_in; f.hist_cap = c->hist_cap; f.in_fmt = c->desc.in_format;
+            f.arb_table = c->d_arb; f.step = c->rp.step; f.tap_fold = 1u; f.phi0 = c->phi;
+            f.n_res = p.n_res; f.pre = (int64_t)(L1 + (size_t)c->fpending);
+            // outputs whose 24-frame window load lies inside this call's input: q_k = (phi0 + k step) >> 24 in [13, frames_in - 11]
+            auto first_k = [&](int64_t pos) {
+                if (pos <= 0) return (int64_t)0;
+                const uint64_t target = (uint64_t)pos << 24;
+                return (int64_t)(target > c->phi ? (target - c->phi + (uint64_t)c->rp.step - 1) / (uint64_t)c->rp.step : 0);
+            };
+            f.k_a = first_k(13); f.k_b = first_k((int64_t)frames_in - 10);
+            if (f.k_b > f.n_res) f.k_b = f.n_res;
+            if (f.k_a > f.k_b) f.k_a = f.k_b;
+            f.write_state = 1;
+            f.grid = c->n_cu * (c->fft_log2n <= 12 ? 2 : 1);
+            ca.win = c->fuse_win; ca.vout = c->fuse_vout;
+        } else if (c->fuse_win > 0) {
+            // the calls of such a chain that stay on the two kernels (short ones) run the fused kernel's windows: the
+            // chain's bytes do not depend on which kernel a call took
+            ca.win = c->fuse_win; ca.vout = c->fuse_vout;
+        }
         if (agc_fused) {       // (past the lock, the filter between the resampler and the AGC: gain and per-chunk peaks in its epilogue)
             ca.agc_fused = 1; ca.agc_state = c->d_agc_state; ca.agc_peak2 = (unsigned long long *)c->agc_peak.p; ca.agc_geom = agc_geom();
             HIP_TRY(clean_agc_peaks());
@@ -279,6 +310,7 @@ int Call::stage_filter()
     }
     c->fcur ^= 1;
     c->fpending = p.fpending_next;
+    if (fusef && c->decim) c->hist_cur ^= 1;               // (what stage_front does behind its launch)
     return IQGPU_OK;
 }
 

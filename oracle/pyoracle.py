@@ -141,6 +141,9 @@ def lib(fast=False):
     name = "liboracle_fast.so" if fast else "liboracle.so"
     if name not in _libs:
         path = os.path.join(HERE, name)
+        # (tools/sanitize_host.py: the same source under ASan + UBSan for the sanitized run of the CPU suite)
+        if not fast and os.environ.get("IQGPU_ORACLE_LIB"):
+            path = os.environ["IQGPU_ORACLE_LIB"]
         if not os.path.exists(path):
             build()
         _libs[name] = _proto(C.CDLL(path))

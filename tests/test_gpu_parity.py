@@ -109,6 +109,30 @@ def test_convert_cf32_to_block_bit_exact(gpu, oracle, fmt):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("fmt", ["cs8", "cu8", "cs16", "cu16", "sc16q11"])
+def test_convert_cf32_to_block_non_finite_input(gpu, oracle, fmt):
+    """the 8- and 16-bit packs clamp with ONE v_med3_f32 (dsp_device.hpp), which equals the reference's compare chain
+    (src/sample_convert.c:213-309) for every finite AND infinite input -- +-Inf saturate to the format's extremes, pinned here against
+    the reference's own code (oracle/_ref through the oracle).  A NaN is UNSPECIFIED on both sides: the reference's float -> integer
+    cast of a NaN is undefined behaviour in C (x86 yields the "integer indefinite"), the GPU's med3 returns one of its bounds; the
+    only contract is that a NaN sample does not disturb its neighbours."""
+    from iq_tool_amd import ops
+    rng = np.random.default_rng(12)
+    n = 4099
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.5)
+    inf = np.float32(np.inf)
+    x[5] = complex(inf, -inf); x[6] = complex(-inf, 0.25); x[4000] = complex(0.125, inf)
+    want = oracle.from_cf32(x, fmt)
+    got = ops.convert_cf32_to_block(x, fmt)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:8]
+    y = x.copy()
+    y[100] = complex(np.nan, 0.5); y[101] = complex(-0.5, np.nan)
+    got_nan = ops.convert_cf32_to_block(y, fmt)
+    keep = np.ones(2 * n, bool); keep[200] = keep[203] = False          # (components 2 * 100 and 2 * 101 + 1)
+    want_nan = oracle.from_cf32(np.nan_to_num(y.view(np.float32), nan=0.0, posinf=np.inf, neginf=-np.inf).view(np.complex64), fmt)
+    assert np.array_equal(got_nan.reshape(-1)[keep], want_nan.reshape(-1)[keep])
+
+
 def test_get_bytes_per_sample(gpu, oracle):
     from iq_tool_amd import ops
     for name, fid in oracle.FMT.items():
@@ -548,6 +572,75 @@ def test_p0_kernel_equals_the_sample_major_kernel(gpu, oracle, monkeypatch, in_f
             assert np.abs(cf(one) - cf(want)).max() <= 2 * TOL
         else:
             int_close(one, want, min_same=0.995)
+
+
+@pytest.mark.parametrize("in_format,out_format,target_hz,extra", [
+    ("cu8", "cu8", 1488375.0, dict(filters=(("passband", 158.5e3, 113e3),))),                       # cu8-nrsc5-usb without its AGC
+    ("cu8", "cu8", 1488375.0, dict(filters=(("passband", -158.5e3, 113e3),), agc=True)),            # cu8-nrsc5-lsb as shipped: AGC in the epilogue
+    ("cs16", "cs16", 2.4e6 / 1.7, dict(filters=(("lowpass", 250e3, 0.0),), filter_taps=401)),       # step class (5, 6), real taps, 400 shared samples per window
+    ("cs8", "cf32", 2.4e6 / 1.376, dict(filters=(("passband", 100e3, 80e3),), shift_hz=-75e3, shift_after_resample=True)),   # (2, 4, 5), post NCO in the epilogue
+    ("cu8", "cs16", 2.4e6 / 1.96, dict(filters=(("lowpass", 200e3, 0.0),), filter_taps=1601)),      # 1600 of every 3840 window samples shared with the block in front
+])
+def test_resampler_and_filter_in_one_kernel_equal_the_two_kernel_path(gpu, oracle, monkeypatch, in_format, out_format, target_hz, extra):
+    """Round 6: chains WITHOUT a half-band stage whose user filter stands behind the resampler -- the shipped
+    cu8-nrsc5-usb / -lsb presets (iq_tool_presets.conf:198-239; placement src/filter.c:53-90; src/post_processor.c:9-36) -- CAN run
+    resampler AND overlap-save filter as ONE kernel, k_p0fft16 (IQGPU_FUSE_FILTER=1: opt-in, it measured slower than the two kernels,
+    profiles/r06_fused_filter.md): a workgroup computes the window of its filter block itself (k_front_p0's output-major steps,
+    straight into the transform's LDS buffer), no cf32 stream in HBM.  Same windows, same slot routines, same transforms and epilogue
+    as the two kernels, so the BYTES must equal theirs (the two kernels with the fused kernel's window geometry kept,
+    IQGPU_FFT_GEOMETRY=keep): whole calls, ragged splits that change path from call to call (calls below 2^22 frames stay on the two
+    kernels), the stream history and the call's end inside a window (the guarded slow path), pending samples of the block
+    quantisation carried between calls, a reset; AGC state too.  Then the oracle."""
+    agc = bool(extra.get("agc"))
+    n = 5_300_003 if not agc else int(2.4e6 * 4.5)
+    raw = synth.raw_stream(n, 2.4e6, 53, in_format)
+    per = raw.size // n
+    kw = dict(in_format=in_format, out_format=out_format, input_rate_hz=2.4e6, target_rate_hz=target_hz, **extra)
+    c16 = 16384
+    splits = [[n]] + ([[c16 * 100, c16 * 60, n - c16 * 160]] if agc else [[4_400_000, 1, 4095, n - 4_404_096], [5_000_001, n - 5_000_001], [300_000, n - 300_000]])
+
+    def run(split):
+        ch = gpu.Chain(**kw)
+        outs, pos, names = [], 0, []
+        for k in split:
+            outs.append(ch.process(raw[per * pos:per * (pos + k)])); pos += k
+            names.append(ch.front_kernel())
+        st = ch.agc_state() if agc else None
+        ch.reset()
+        outs.append(ch.process(raw[:per * 4_250_000]))
+        names.append(ch.front_kernel())
+        return np.concatenate(outs), names, st
+
+    monkeypatch.setenv("IQGPU_FFT_GEOMETRY", "keep")
+    refs = [run(sp) for sp in splits]
+    assert all(nm in ("k_front_p0", "k_front_s1") for r in refs for nm in r[1]), refs[0][1]
+    monkeypatch.delenv("IQGPU_FFT_GEOMETRY")
+    monkeypatch.setenv("IQGPU_FUSE_FILTER", "1")
+    for sp, (ref, _, st_ref) in zip(splits, refs):
+        got, names, st = run(sp)
+        assert "k_p0fft16" in names, names
+        assert got.size == ref.size, (sp, names, got.size, ref.size)
+        assert np.array_equal(got, ref), (sp, names, int((got != ref).sum()), int(np.flatnonzero(got != ref)[0]))
+        assert st == st_ref
+    one = refs[0][0]
+    if not agc:
+        want = run_oracle(oracle, raw, **kw)
+        n_one = want.size
+        if out_format == "cf32":
+            assert np.abs(cf(one[:n_one]) - cf(want)).max() <= 2 * TOL
+        else:
+            int_close(one[:n_one], want, min_same=0.995)
+    # every kernel the fused call launched is the one kernel (+ the AGC's): no front launch at all; and without the switch the chain is
+    # the round-5 chain (two kernels, its own window geometry)
+    ch = gpu.Chain(**kw)
+    ch.set_profiling(True)
+    ch.process(raw)
+    prof = ch.profile()
+    assert ch.front_kernel() == "k_p0fft16" and prof["front"]["launches"] == 0 and prof["filter"]["launches"] >= 1, prof
+    monkeypatch.delenv("IQGPU_FUSE_FILTER")
+    ch = gpu.Chain(**kw)
+    ch.process(raw)
+    assert ch.front_kernel() == "k_front_p0"
 
 
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):

@@ -133,6 +133,24 @@ def check_no_scratch(lines, src, kernel, max_vgpr):
     return errors
 
 
+def check_scratch_at_most(lines, src, kernel, max_vgpr, max_scratch):
+    """every instantiation of `kernel` in `src`: at most max_vgpr registers and max_scratch bytes of scratch"""
+    errors = []
+    text = "\n".join(lines)
+    n = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*%s\S*)\n(.*?)\.end_amdhsa_kernel" % re.escape(kernel), text, re.S):
+        n += 1
+        v = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
+        sc = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+        if sc > max_scratch:
+            errors.append("%s: %s spills %d bytes to scratch (bound %d)" % (src, m.group(1), sc, max_scratch))
+        if v > max_vgpr:
+            errors.append("%s: %s needs %d VGPRs (budget %d)" % (src, m.group(1), v, max_vgpr))
+    if n == 0:
+        errors.append("%s: no instantiation of %s" % (src, kernel))
+    return errors
+
+
 def check_fat_mid(src, kernel, max_vgpr, lines=None):
     """k_front_fat / k_front_mid are plain C++ whose speed hangs on what hipcc makes of it: (5) no scratch (a spill inside the
     tile loop is a memory round trip per tile), (6) the VGPR count that the occupancy they are built for allows (8 waves per CU:
@@ -243,7 +261,7 @@ def check_hot(lines_by_src):
 def main():
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(HERE, "..", "iq_tool_amd", "csrc")
-    names = ["front_wave.hip", "cascade_wave.hip", "front_s2.hip", "front_mid.hip", "front_fat.hip", "front_p0.hip", "cascade2.hip"]
+    names = ["front_wave.hip", "cascade_wave.hip", "front_s2.hip", "front_mid.hip", "front_fat.hip", "front_p0.hip", "cascade2.hip", "p0fft_cu8.hip"]
     with ThreadPoolExecutor(max_workers=min(len(names), max(2, (os.cpu_count() or 4) - 1))) as ex:     # (front_mid.hip alone takes 2 min 40 s)
         isa = dict(zip(names, ex.map(lambda nm: compile_isa(os.path.join(csrc, nm)), names)))
     lines = isa["front_wave.hip"]
@@ -256,6 +274,9 @@ def main():
     errors += check_fat_mid(os.path.join(csrc, "front_fat.hip"), "k_front_fat", 256, isa["front_fat.hip"])
     errors += check_no_scratch(isa["front_p0.hip"], "front_p0.hip", "k_front_p0", 256)
     errors += check_no_scratch(isa["cascade2.hip"], "cascade2.hip", "k_cascade2", 168)
+    # k_p0fft16 (opt-in, round 6): two waves per SIMD; its transforms spill a few dozen registers under that cap (profiles/r06_fused_filter.md)
+    # -- bounded here so that a change of the window fill does not silently double it
+    errors += check_scratch_at_most(isa["p0fft_cu8.hip"], "p0fft_cu8.hip", "k_p0fft16", 256, 256)
     for e in errors:
         print("FAIL", e)
     print("check_isa: %d tap gathers checked: %s" % (n, "ok" if not errors and n > 0 else "FAILED"))
