@@ -643,6 +643,43 @@ def test_resampler_and_filter_in_one_kernel_equal_the_two_kernel_path(gpu, oracl
     assert ch.front_kernel() == "k_front_p0"
 
 
+def test_one_kernel_resampler_filter_on_short_and_ragged_calls(gpu, oracle, monkeypatch):
+    """k_p0fft16 forced onto calls of ANY length (IQGPU_FORCE_FAT lifts the 2^22-frame rule): calls of 1, 2, 13, 14 frames (no output,
+    fewer frames than the polyphase window, than the stream history), calls whose every window entry takes the guarded per-output
+    path, calls that end inside a filter block, pending samples of the block quantisation carried across them, a reset -- against the
+    two kernels on the same window geometry: the same bytes, the same counts per call."""
+    n = 700_001
+    kw = dict(in_format="cu8", out_format="cs16", input_rate_hz=2.4e6, target_rate_hz=1488375.0, filters=(("passband", 158.5e3, 113e3),))
+    raw = synth.raw_stream(n, 2.4e6, 57, "cu8")
+    split = [1, 2, 13, 14, 100, 4095, 65536, 1, 300_000, 17, n - 369_779]
+    assert sum(split) == n
+
+    def run():
+        ch = gpu.Chain(**kw)
+        outs, pos, names = [], 0, []
+        for k in split:
+            o = ch.process(raw[2 * pos:2 * (pos + k)]); pos += k
+            outs.append(o); names.append(ch.front_kernel())
+        ch.reset()
+        outs.append(ch.process(raw[:2 * 123_457])); names.append(ch.front_kernel())
+        return outs, names
+
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")
+    monkeypatch.setenv("IQGPU_FFT_GEOMETRY", "keep")
+    ref, ref_names = run()
+    assert "k_p0fft16" not in ref_names
+    monkeypatch.delenv("IQGPU_FFT_GEOMETRY")
+    monkeypatch.setenv("IQGPU_FUSE_FILTER", "1")
+    got, names = run()
+    assert names.count("k_p0fft16") >= 4, names                      # (calls that emit nothing stay on the two kernels)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.size == b.size, (i, names[i], a.size, b.size)
+        assert np.array_equal(a, b), (i, names[i], int((a != b).sum()), int(np.flatnonzero(a != b)[0]))
+    want = run_oracle(oracle, raw, **kw)
+    one = np.concatenate(got[:-1])
+    int_close(one, want[:one.size], min_same=0.995)
+
+
 def test_cascade_chain_post_shift_and_integer_output(gpu, oracle):
     n = 1 << 20
     raw = synth.raw_stream(n, 61.44e6, 42, "cu8")
