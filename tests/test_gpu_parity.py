@@ -2372,6 +2372,58 @@ def test_agc_fused_in_the_filter_epilogue(gpu, oracle, monkeypatch, fmt, target_
         int_close(fused, want, min_same=0.99)
 
 
+@pytest.mark.parametrize("case", ["steady", "ratchet_and_creep"])
+def test_agc_in_the_epilogue_of_the_one_kernel_resampler_filter(gpu, monkeypatch, case):
+    """k_p0fft16 (IQGPU_FUSE_FILTER=1; IQGPU_FORCE_FAT lifts the call-length rule) with the digital AGC in its epilogue, on the
+    cu8-nrsc5-usb preset's chain and a stream whose envelope makes verdicts fail past the lock: the rejected call is redone by the SAME
+    kernel with cf32 output (no second write of the next call's state) and the unfused AGC kernels -- deferred to the host's verdict
+    on process() / submit / collect, queued behind the launch on process_device.  Bytes and AGC state equal the two kernels' with the
+    unfused AGC on the same window geometry."""
+    n = int(2.4e6 * 8)
+    env = [(0.0, 0.5)] if case == "steady" else [(0.0, 0.4), (3.0, 0.66), (3.3, 0.4), (4.2, 0.1)]
+    raw = ((_enveloped_stream(n, 48, env).astype(np.int32) >> 8) + 128).astype(np.uint8)
+    kw = dict(in_format="cu8", out_format="cu8", input_rate_hz=2.4e6, target_rate_hz=1488375.0, agc=True, filters=(("passband", 158.5e3, 113e3),))
+    batch = 40 * 16384
+    per = 2 * batch
+
+    def chunks():
+        return [raw[p:p + per] for p in range(0, raw.size, per)]
+
+    def run_sync():
+        ch = gpu.Chain(**kw)
+        outs, names = [], set()
+        for x in chunks():
+            outs.append(ch.process(x)); names.add(ch.front_kernel())
+        return np.concatenate(outs), ch.agc_state(), names
+
+    monkeypatch.setenv("IQGPU_FORCE_FAT", "1")
+    monkeypatch.setenv("IQGPU_FFT_GEOMETRY", "keep")
+    monkeypatch.setenv("IQGPU_AGC_NOFUSE", "1")
+    plain, st_plain, names = run_sync()
+    assert st_plain["locked"] and "k_p0fft16" not in names
+    monkeypatch.delenv("IQGPU_AGC_NOFUSE")
+    monkeypatch.delenv("IQGPU_FFT_GEOMETRY")
+    monkeypatch.setenv("IQGPU_FUSE_FILTER", "1")
+    fused, st_fused, names = run_sync()
+    assert "k_p0fft16" in names, names
+    assert fused.size == plain.size
+    assert np.array_equal(fused, plain), (int((fused != plain).sum()), int(np.flatnonzero(fused != plain)[0]))
+    assert st_fused == st_plain
+    ch = gpu.Chain(**kw)
+    piped = ch.process_pipelined(raw, batch)
+    assert ch.front_kernel() == "k_p0fft16" and np.array_equal(piped, plain) and ch.agc_state() == st_plain
+    from iq_tool_amd.chain import DeviceBuffer
+    ch = gpu.Chain(**kw)
+    d_in, d_out = DeviceBuffer(per), DeviceBuffer(ch.out_bytes * ch.max_out_frames(batch))
+    outs = []
+    for x in chunks():
+        d_in.upload(x)
+        got = ch.process_device(d_in.ptr, x.size // 2, d_out.ptr, d_out.nbytes)
+        ch.synchronize()
+        outs.append(d_out.download(ch.out_bytes * got, plain.dtype).copy())
+    assert np.array_equal(np.concatenate(outs), plain) and ch.agc_state() == st_plain
+
+
 def test_agc_fused_through_submit_collect_and_reset(gpu, monkeypatch):
     n = int(2.4e6 * 4)
     raw = _enveloped_stream(n, 46, [(0.0, 0.5)])
