@@ -334,9 +334,29 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
             // the lane's NS - 1 or NS outputs are consecutive: 8-byte aligned cf32, NS - 1 of them always
             typedef float f32x2 __attribute__((ext_vector_type(2), aligned(8)));
             char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 8;
+            if constexpr (NS == 4) {
+                // Round 6: two whole 16-byte pieces per lane instead of three 8-byte ones and a masked fourth.  A lane whose fourth slot
+                // holds no output stores its UPPER NEIGHBOUR's first output there (two wave_shl:1 DPP moves): the very sample the
+                // neighbour writes to the very same address in the very same instruction, so every lane but the wave's last can always
+                // store 32 bytes and the tile leaves as one hole-free range in two instructions.  Same-box A/B, four rounds of 60 steps
+                // on the cs16-fm-nrsc5-usb preset: 0.4116 -> 0.3945 ms (-4.2 %), bytes unchanged.  (The cs16 form of the same idea is
+                // byte-identical too and gains nothing -- profiles/r06_headline.md (c) -- and is not in the shipped kernel.)
+                typedef float f32x4 __attribute__((ext_vector_type(4), aligned(8)));
+                const bool has_last = Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24);
+                const float ux = dpp_f<0x130, 0xf, false>(0.0f, y[0].x), uy = dpp_f<0x130, 0xf, false>(0.0f, y[0].y);      // wave_shl:1
+                const v2f tail = has_last ? y[NS - 1] : v2f{ux, uy};
+                if (lane < 63 || has_last) {
+                    *(f32x4 *)ob = f32x4{y[0].x, y[0].y, y[1].x, y[1].y};
+                    *(f32x4 *)(ob + 16) = f32x4{y[2].x, y[2].y, tail.x, tail.y};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NS - 1; ++j) *(f32x2 *)(ob + 8 * j) = f32x2{y[j].x, y[j].y};
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < NS - 1; ++j) *(f32x2 *)(ob + 8 * j) = f32x2{y[j].x, y[j].y};
             if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(f32x2 *)(ob + 8 * (NS - 1)) = f32x2{y[NS - 1].x, y[NS - 1].y};
+            }
         } else if constexpr (OUT8 != 0) {
             // 2-byte frames at a 2-byte-aligned address: the lane's NS - 1 or NS outputs as dwords and a short
             static_assert(NS == 4, "8-bit output: six outputs per lane only");
@@ -356,9 +376,19 @@ __device__ __forceinline__ void run_mid(const FrontArgs &a, const MidLds &w, con
         typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
         char *ob = (char *)a.out + ((int64_t)k_tile0 + n0) * 4;
+#ifdef IQGPU_DIAG_NOSTORE
+        // DIAGNOSTIC build (timing only, no output): what do the cs16 stores -- a 12-byte piece per lane and a masked dword in the holes,
+        // i.e. short segments per wave-instruction -- cost this kernel?  8.7 % (0.337 against 0.369 ms); and the SHAPE is not what costs:
+        // one whole 16-byte piece per lane (a lane without a fourth output repeating its upper neighbour's first code, by a DPP move) was
+        // built, byte-identical, and timed the same (tools/gpu/r6_store_shape.patch; round 6, profiles/r06_headline.md)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) asm volatile("" :: "v"(pk[j]));
+        keep(ob);
+#else
         if constexpr (NS == 4) *(u32x3 *)ob = u32x3{pk[0], pk[1], pk[2]};
         else *(u32x4 *)ob = u32x4{pk[0], pk[1], pk[2], pk[3]};
         if (Pl + (uint32_t)(NS - 1) * step < ((uint32_t)NL << 24)) *(uint32_t *)(ob + 4 * (NS - 1)) = pk[NS - 1];
+#endif
         }
         // (all in 32 bits: delta0 + n_est step < SPAN <=> delta0 < span_rem, and nt step - SPAN is step - span_rem or -span_rem)
         const bool more = delta0 < span_rem;

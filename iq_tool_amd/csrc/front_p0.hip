@@ -48,18 +48,19 @@ constexpr int kP0EdgeMax = 6;                               // edge waves of a l
 constexpr int kP0EdgeTpw = 4;                               // 256-frame tiles per edge run
 constexpr int kP0ArbLds = 256 * 14 * 4;                     // the edge waves' table (layout of k_front_s1)
 
-static_assert(kP0ArbLds + kFTapLds + kP0EdgeMax * kWaveLds <= 160 * 1024, "LDS");
+constexpr int kP0StripB = kP0Step * 8;                      // cf32 output: a step's 320 outputs pass through a strip of the wave's own (coalesced stores)
+static_assert(kP0ArbLds + kFTapLds + kP0EdgeMax * kWaveLds + kP0Waves * kP0StripB <= 160 * 1024, "LDS");
 
 int front_p0_waves() { return kP0Waves; }
 int front_p0_max_edge_waves() { return kP0EdgeMax; }
 int front_p0_edge_tpw() { return kP0EdgeTpw; }
-static size_t p0_lds_bytes() { return (size_t)kP0ArbLds + kFTapLds + (size_t)kP0EdgeMax * kWaveLds; }
+static size_t p0_lds_bytes() { return (size_t)kP0ArbLds + kFTapLds + (size_t)kP0EdgeMax * kWaveLds + (size_t)kP0Waves * kP0StripB; }
 
 // Steps [s_begin, s_end) of the launch's streaming outputs [k_a, k_b) (call-relative output indices).
 // FMT: cu8 / cs8 (2 bytes per frame) or cs16; OUTF: the output format (cu8 / cs8: 2 bytes per frame, cs16: 4, cf32: 8)
 // L2, L3, L4 = floor(2 s), floor(3 s), floor(4 s) of the step class (s = step / 2^24; floor(s) = 1)
 template <int FMT, int L3, int L4, int OUTF, bool AGC, int L2 = 3>
-__device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_lds, const int lane, const int64_t s_begin, const int64_t s_end)
+__device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_lds, const unsigned strip_lds, const int lane, const int64_t s_begin, const int64_t s_end)
 {
     constexpr int BPS = (FMT == IQGPU_FMT_CS16) ? 4 : 2;
     constexpr int OUTB = OUTF == IQGPU_FMT_CF32 ? 8 : OUTF == IQGPU_FMT_CS16 ? 4 : 2;
@@ -197,13 +198,28 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
         char *ob = (char *)a.out + k0 * OUTB;
         const bool whole = !PARTIAL;
         if (OUTB == 8) {
-            typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
             typedef float f2v __attribute__((ext_vector_type(2), aligned(8)));
             if (whole) {
-                // (non-temporal stores: measured, no change -- 0.59 .. 0.65 ms either way for the 1.33 GB of a 2^28-frame cu8 call)
-                *(f4v *)ob = f4v{y[0].x, y[0].y, y[1].x, y[1].y};
-                *(f4v *)(ob + 16) = f4v{y[2].x, y[2].y, y[3].x, y[3].y};
-                *(f2v *)(ob + 32) = f2v{y[4].x, y[4].y};
+                // Round 6: a lane's five outputs are 40 contiguous bytes, so the three stores above each touched 64 pieces 40 bytes
+                // apart -- twenty-odd cache lines per instruction, every line of the step written by three instructions -- and the
+                // kernel with cf32 output ran 0.59 - 0.65 ms for work its instruction and LDS counters price at 0.21 (profiles/
+                // r06_fused_pmc.txt).  The step's 320 outputs pass through a 2560-byte strip of the wave's own in LDS and leave as five
+                // stores of 64 consecutive outputs each: 512 contiguous bytes per instruction, every cache line written once.
+                // (non-temporal stores on the old pattern: measured in round 5, no change.  The same strip for the 2- and 4-byte outputs:
+                //  measured, +2.5 % -- 0.4235 against 0.4132 ms for the cu8-nrsc5 preset: those forms are bound by their instructions, not their stores)
+                typedef __attribute__((address_space(3))) v2f lds_wv2f;
+                const unsigned wa = strip_lds + 40u * (unsigned)lane;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) *(lds_wv2f *)(size_t)(wa + 8u * j) = y[j];
+                __builtin_amdgcn_wave_barrier();
+                const unsigned ra = strip_lds + 8u * (unsigned)lane;
+                char *ow = (char *)a.out + (a.p0_k_a + s * kP0Step) * OUTB + 8 * lane;       // (the step's first output: wave-uniform base)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const v2f v = *(lds_v2f *)(size_t)(ra + 512u * j);
+                    *(f2v *)(ow + 512 * j) = f2v{v.x, v.y};
+                }
+                __builtin_amdgcn_wave_barrier();             // (the strip is the next step's too)
             } else {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) if (k0 + j < a.p0_k_b) *(f2v *)(ob + 8 * j) = f2v{y[j].x, y[j].y};
@@ -303,7 +319,8 @@ __global__ __launch_bounds__(kP0Threads) void k_front_p0(const FrontArgs a)
         if (r >= a.w_n_stream) return;
         const int64_t s0 = r * a.w_run_q + (r < a.w_run_r ? r : a.w_run_r), s1 = s0 + a.w_run_q + (r < a.w_run_r ? 1 : 0);
         const unsigned tap_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)s_tap;
-        run_p0<FMT, L3, L4, OUTF, AGC, L2>(a, tap_lds, lane, s0, s1);
+        const unsigned strip_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)(arena + kP0EdgeMax * kWaveLds + wave * kP0StripB);
+        run_p0<FMT, L3, L4, OUTF, AGC, L2>(a, tap_lds, strip_lds, lane, s0, s1);
     }
 }
 
