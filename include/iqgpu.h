@@ -293,7 +293,8 @@ int    iqgpu_chain_get_profile(iqgpu_chain *c, iqgpu_profile *p);  /* synchronis
 /* name of the front kernel the LAST process call launched: "k_front_mid<6,nco>", "k_front_mid<6,nonco>", "k_front_mid<8,nco>" (the
  * outputs per lane of the instantiation and whether it mixes; ",cf32" = cf32 out to a filter, ",8bit" = 8-bit frames in or out,
  * ",gain" = 16-bit frames with a gain or of the sc16q11 scale), "k_front_s1", "k_front_fat", "k_front_s2", "k_cascade+k_front_s1",
- * "k_cascade2+k_front_s1", "k_front_p0", "k_front", "k_front+k_interp"; "" before the first call.  Diagnostics, bench.py's
+ * "k_cascade2+k_front_s1", "k_front_p0", "k_p0fft16" (round 6, opt-in by iqgpu_debug_set("fuse_filter", "1"): resampler and post-resample
+ * filter in one kernel, no front launch), "k_front", "k_front+k_interp"; "" before the first call.  Diagnostics, bench.py's
  * roofline.kernel */
 const char *iqgpu_chain_front_kernel(const iqgpu_chain *c);
 
