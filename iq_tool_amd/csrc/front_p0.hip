@@ -21,7 +21,7 @@
 //     lanes costs about a cycle of the LDS pipe, tools/lds_mask_bench.hip, against 5.8 for the full gather).  For a step without
 //     such a period every slot reloads every time: the full gather, and still no sample traffic in LDS.
 //
-// Measured (round 5, profiles/r05_presets.md): cu8-nrsc5 front end 0.561 -> 0.441 ms per 2^28 cu8 frames, 0.66 -> 0.61 ms with cf32
+// Measured (round 5, profiles/r05_presets.md; round 6: 0.34 ms and 0.40 ms): cu8-nrsc5 front end 0.561 -> 0.441 ms per 2^28 cu8 frames, 0.66 -> 0.61 ms with cf32
 // output in front of the -usb / -lsb filter (where the 1.3 GB of cf32 it writes set the pace).  What it took beyond the design:
 // the tap re-reads of step s + 1 are issued at the END of step s (their LDS round trip runs beside the stores and the next unpack:
 // 0.585 -> 0.465 ms); the frames of step s + 2 are fetched BEHIND the stores of step s (vmcnt counts in order, and hipcc waits
@@ -30,7 +30,7 @@
 // one step in thirty that holds a boundary.  Bound today by VALU + LDS added up (two waves per SIMD hardly overlap them): 368
 // VALU instructions and 179 LDS cycles per step.  IQGPU_NO_P0=1 keeps k_front_s1<S0>.
 //
-// Two waves per SIMD (80 VGPRs of taps + 44 of window + the frames of the step after next in flight).  Edge tiles -- the stream
+// Three waves per SIMD since round 6 (80 VGPRs of taps + 44 of window + ONE step of frames in flight; two waves with two steps until then).  Edge tiles -- the stream
 // history in front of the call, the tail that becomes the next call's history -- are run by the scalar-load instantiation of
 // run_tiles (front_tiles.hpp, 256-frame tiles) on a few extra waves, as in the other wave-autonomous kernels; the streaming part is
 // the outputs whose position lies in tiles [w_edge_ta, w_edge_tb).  Fused digital AGC as in k_front_mid (float peaks per chunk).
@@ -42,7 +42,14 @@
 
 namespace iqgpu {
 
-constexpr int kP0Waves = 8;
+// Round 6: TWELVE waves per CU (three per SIMD; 8 until then) with ONE frame buffer (two until then): every instantiation fits 156
+// VGPRs without scratch, and the third wave per SIMD is worth more than the second step of frames in flight -- cu8-nrsc5 front end
+// 0.4087 -> 0.3444 ms (-15.7 %), with cf32 output 0.477 -> 0.401; twelve waves with two buffers 0.363 / 0.407 (same box, three
+// rounds of 40 steps, tools/gpu/r6_p0_waves.sh).  Bytes unchanged.
+#ifndef IQGPU_P0_WAVES
+#define IQGPU_P0_WAVES 12
+#endif
+constexpr int kP0Waves = IQGPU_P0_WAVES;
 constexpr int kP0Threads = kP0Waves * 64;
 constexpr int kP0EdgeMax = 6;                               // edge waves of a launch (k_front_s1's slice layout, an arena of their own)
 constexpr int kP0EdgeTpw = 4;                               // 256-frame tiles per edge run
@@ -78,9 +85,9 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
     // little latency by themselves; and vmcnt counts in order: a wait for a store -- hipcc places one wherever a register that a
     // store reads is written again -- must not stand behind younger loads, or every step waits for the frames it has just asked for)
 #ifndef IQGPU_P0_NB
-#define IQGPU_P0_NB 2
+#define IQGPU_P0_NB 1
 #endif
-    constexpr int NB = IQGPU_P0_NB;                          // (three buffers left the instantiations with the fused AGC short of registers)
+    constexpr int NB = IQGPU_P0_NB;                          // (round 6: ONE buffer and a third wave per SIMD instead of two and two)
     uint32_t rb[NB][NW];
     auto fetch = [&](uint64_t Pq, uint32_t (&r)[NW]) {
         int64_t f0 = (int64_t)(Pq >> 24) - 13;
