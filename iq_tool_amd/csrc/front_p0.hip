@@ -27,8 +27,8 @@
 // 0.585 -> 0.465 ms); the frames of step s + 2 are fetched BEHIND the stores of step s (vmcnt counts in order, and hipcc waits
 // for a store wherever its registers are written again); the folded arm placement (consecutive lanes are 16 arms apart for
 // this step: linear planes put a slot's re-reading lanes into two bank pairs); the chunk sorting of the fused AGC only in the
-// one step in thirty that holds a boundary.  Bound today by VALU + LDS added up (two waves per SIMD hardly overlap them): 368
-// VALU instructions and 179 LDS cycles per step.  IQGPU_NO_P0=1 keeps k_front_s1<S0>.
+// one step in thirty that holds a boundary.  368 VALU instructions and 179 LDS cycles per step: at two waves per SIMD (round 5) the
+// kernel took their sum, at three (round 6) it overlaps them.  IQGPU_NO_P0=1 keeps k_front_s1<S0>.
 //
 // Three waves per SIMD since round 6 (80 VGPRs of taps + 44 of window + ONE step of frames in flight; two waves with two steps until then).  Edge tiles -- the stream
 // history in front of the call, the tail that becomes the next call's history -- are run by the scalar-load instantiation of
@@ -81,8 +81,8 @@ __device__ __forceinline__ void run_p0(const FrontArgs &a, const unsigned tap_ld
 
     // phase of the lane's first output of step s_begin: phi + k step, in samples << 24 from the call's first frame
     uint64_t P = a.phi0 + (uint64_t)(a.p0_k_a + s_begin * kP0Step + 5 * lane) * (uint64_t)step;
-    // the frames of a step are fetched NB steps ahead, behind the stores of the step that frees their buffer (two waves per SIMD cover
-    // little latency by themselves; and vmcnt counts in order: a wait for a store -- hipcc places one wherever a register that a
+    // the frames of a step are fetched NB steps ahead, behind the stores of the step that frees their buffer (round 5: NB = 2, two
+    // waves per SIMD cover little latency by themselves; round 6: NB = 1 and three waves; and vmcnt counts in order: a wait for a store -- hipcc places one wherever a register that a
     // store reads is written again -- must not stand behind younger loads, or every step waits for the frames it has just asked for)
 #ifndef IQGPU_P0_NB
 #define IQGPU_P0_NB 1
