@@ -49,6 +49,19 @@ __device__ __forceinline__ cf2 interp_branch(const cf2 *p, const float *taps, in
     return cf2{ar, ai};
 }
 
+// one frame of a 4-byte / 2-byte output format as the word pack_store would write (dsp_device.hpp: the same expressions, case by case)
+__device__ __forceinline__ uint32_t interp_word32(int fmt, cf2 v)
+{
+    if (fmt == IQGPU_FMT_CU16) return pk_unsigned(v.x, 32767.0f, 32767.5f, 65535.0f) | (pk_unsigned(v.y, 32767.0f, 32767.5f, 65535.0f) << 16);
+    const float s = (fmt == IQGPU_FMT_CS16) ? 32767.0f : 2048.0f;
+    return ((unsigned)pk_signed(v.x, s, -32768.0f, 32767.0f) & 0xffffu) | (((unsigned)pk_signed(v.y, s, -32768.0f, 32767.0f) & 0xffffu) << 16);
+}
+__device__ __forceinline__ uint32_t interp_word16(int fmt, cf2 v)
+{
+    if (fmt == IQGPU_FMT_CU8) return pk_unsigned(v.x, 127.0f, 127.5f, 255.0f) | (pk_unsigned(v.y, 127.0f, 127.5f, 255.0f) << 8);
+    return ((unsigned)pk_signed(v.x, 127.0f, -128.0f, 127.0f) & 0xffu) | (((unsigned)pk_signed(v.y, 127.0f, -128.0f, 127.0f) & 0xffu) << 8);
+}
+
 __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -92,33 +105,70 @@ __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
         }
         __syncthreads();
         // ---- level 0: arbitrary resampler ----
-        for (int i = tid; i < n_k; i += kThreads) {
-            const int64_t k = k_lo + i;
-            const int64_t P = phi + k * step;
-            const int64_t q = P >> 24;
-            cf2 y{0.0f, 0.0f};
-            if (q <= q_top) {                                // later inputs have not arrived yet
-                const int arm = (int)((P >> 16) & 255);
-                const cf2 *w = s_in + (int)(q - q_base);
-                const float2 *tp2 = (const float2 *)(s_arb + arm * kArbWin);                     // 56-byte rows: 8-byte reads
+        // Round 6: a thread takes the PAIR of outputs (2 idx, 2 idx + 1).  Their windows are the same 14 samples or one sample apart
+        // (the stage's step is at most one sample: rate_arb >= 1), so 15 window reads serve both where 28 did -- the kernel is bound
+        // by its LDS reads (14 window + 7 tap reads per output until now) -- and the second output picks its samples out of the
+        // shared registers by the one-bit distance d.  Same products in the same order (tap 0 first, started from zero).
+        for (int idx = tid; 2 * idx < n_k; idx += kThreads) {
+            const int i0 = 2 * idx;
+            const bool has1 = i0 + 1 < n_k;
+            const int64_t k0 = k_lo + i0;
+            const int64_t P0 = phi + k0 * step, P1 = P0 + step;
+            const int64_t q0 = P0 >> 24, q1 = P1 >> 24;
+            cf2 y0{0.0f, 0.0f}, y1{0.0f, 0.0f};
+            if (q0 <= q_top) {                               // later inputs have not arrived yet
+                const cf2 *w = s_in + (int)(q0 - q_base) - (kArbWin - 1);          // w[j] = x[q0 - 13 + j], j = 0 .. 14
+                cf2 sr[kArbWin + 1];
+#pragma unroll
+                for (int j = 0; j <= kArbWin; ++j) sr[j] = w[j];
+                const float2 *ta = (const float2 *)(s_arb + (int)((P0 >> 16) & 255) * kArbWin);     // 56-byte rows: 8-byte reads
                 float ar = 0.0f, ai = 0.0f;
 #pragma unroll
                 for (int n2 = 0; n2 < kArbWin / 2; ++n2) {
-                    const float2 t2 = tp2[n2];
-                    const cf2 s0 = w[-2 * n2], s1 = w[-2 * n2 - 1];
+                    const float2 t2 = ta[n2];
+                    const cf2 s0 = sr[kArbWin - 1 - 2 * n2], s1 = sr[kArbWin - 2 - 2 * n2];
                     ar = fmaf(t2.x, s0.x, ar); ai = fmaf(t2.x, s0.y, ai);
                     ar = fmaf(t2.y, s1.x, ar); ai = fmaf(t2.y, s1.y, ai);
                 }
-                y = cf2{ar, ai};
+                y0 = cf2{ar, ai};
+                if (has1 && q1 <= q_top) {
+                    const bool d = q1 != q0;                 // the second output's newest sample: x[q0 + 1] or x[q0]
+                    const float2 *tb = (const float2 *)(s_arb + (int)((P1 >> 16) & 255) * kArbWin);
+                    float br = 0.0f, bi = 0.0f;
+#pragma unroll
+                    for (int n2 = 0; n2 < kArbWin / 2; ++n2) {
+                        const float2 t2 = tb[n2];
+                        const cf2 s0 = d ? sr[kArbWin - 2 * n2] : sr[kArbWin - 1 - 2 * n2];
+                        const cf2 s1 = d ? sr[kArbWin - 1 - 2 * n2] : sr[kArbWin - 2 - 2 * n2];
+                        br = fmaf(t2.x, s0.x, br); bi = fmaf(t2.x, s0.y, bi);
+                        br = fmaf(t2.y, s1.x, br); bi = fmaf(t2.y, s1.y, bi);
+                    }
+                    y1 = cf2{br, bi};
+                }
             }
             if (S == 0) {
-                if (k < a.n_arb) {                           // ext[0] = 0: k >= 0
-                    if (a.pnco_mode != 0)
-                        y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k * a.pnco_dtheta), a.pnco_mode);
-                    pack_store(a.out, k, a.out_fmt, y);
+                const bool st0 = k0 < a.n_arb, st1 = has1 && k0 + 1 < a.n_arb;      // ext[0] = 0: k0 >= 0
+                if (a.pnco_mode != 0) {
+                    y0 = nco_mix(y0, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)k0 * a.pnco_dtheta), a.pnco_mode);
+                    y1 = nco_mix(y1, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)(k0 + 1) * a.pnco_dtheta), a.pnco_mode);
+                }
+                const int of = a.out_fmt;
+                if (st0 && st1 && of == IQGPU_FMT_CF32) {
+                    typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+                    *(f4a8 *)((char *)a.out + 8 * k0) = f4a8{y0.x, y0.y, y1.x, y1.y};
+                } else if (st0 && st1 && (of == IQGPU_FMT_CS16 || of == IQGPU_FMT_SC16Q11 || of == IQGPU_FMT_CU16)) {
+                    typedef uint32_t u2a4 __attribute__((ext_vector_type(2), aligned(4)));
+                    *(u2a4 *)((char *)a.out + 4 * k0) = u2a4{interp_word32(of, y0), interp_word32(of, y1)};
+                } else if (st0 && st1 && (of == IQGPU_FMT_CS8 || of == IQGPU_FMT_CU8)) {
+                    typedef uint32_t u1a2 __attribute__((aligned(2)));
+                    *(u1a2 *)((char *)a.out + 2 * k0) = interp_word16(of, y0) | (interp_word16(of, y1) << 16);
+                } else {
+                    if (st0) pack_store(a.out, k0, of, y0);
+                    if (st1) pack_store(a.out, k0 + 1, of, y1);
                 }
             } else {
-                s_lvl[a.lvl_off[0] + i] = y;
+                s_lvl[a.lvl_off[0] + i0] = y0;
+                if (has1) s_lvl[a.lvl_off[0] + i0 + 1] = y1;
             }
         }
         // ---- half-band interpolators ----
@@ -154,17 +204,27 @@ __global__ __launch_bounds__(kThreads) void k_interp(const InterpArgs a)
                     }
                 }
                 if (last) {
-                    if (has_e && u < a.n_emit) {
-                        cf2 y = ye;
-                        if (a.pnco_mode != 0)
-                            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)u * a.pnco_dtheta), a.pnco_mode);
-                        pack_store(a.out, u, a.out_fmt, y);
+                    const bool st_e = has_e && u < a.n_emit, st_o = has_o && u + 1 < a.n_emit;
+                    cf2 y0 = ye, y1 = yo;
+                    if (a.pnco_mode != 0) {
+                        y0 = nco_mix(y0, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)u * a.pnco_dtheta), a.pnco_mode);
+                        y1 = nco_mix(y1, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)(u + 1) * a.pnco_dtheta), a.pnco_mode);
                     }
-                    if (has_o && u + 1 < a.n_emit) {
-                        cf2 y = yo;
-                        if (a.pnco_mode != 0)
-                            y = nco_mix(y, nco_phasor(s_nco, a.pnco_theta0 + (uint32_t)(u + 1) * a.pnco_dtheta), a.pnco_mode);
-                        pack_store(a.out, u + 1, a.out_fmt, y);
+                    // Round 6: the pair leaves as ONE piece where the format allows it (two stores of one frame each had every cache line
+                    // written twice: the store shape of DESIGN 3.3); the same expressions as pack_store
+                    const int of = a.out_fmt;
+                    if (st_e && st_o && of == IQGPU_FMT_CF32) {
+                        typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+                        *(f4a8 *)((char *)a.out + 8 * u) = f4a8{y0.x, y0.y, y1.x, y1.y};
+                    } else if (st_e && st_o && (of == IQGPU_FMT_CS16 || of == IQGPU_FMT_SC16Q11 || of == IQGPU_FMT_CU16)) {
+                        typedef uint32_t u2a4 __attribute__((ext_vector_type(2), aligned(4)));
+                        *(u2a4 *)((char *)a.out + 4 * u) = u2a4{interp_word32(of, y0), interp_word32(of, y1)};
+                    } else if (st_e && st_o && (of == IQGPU_FMT_CS8 || of == IQGPU_FMT_CU8)) {
+                        typedef uint32_t u1a2 __attribute__((aligned(2)));
+                        *(u1a2 *)((char *)a.out + 2 * u) = interp_word16(of, y0) | (interp_word16(of, y1) << 16);
+                    } else {
+                        if (st_e) pack_store(a.out, u, of, y0);
+                        if (st_o) pack_store(a.out, u + 1, of, y1);
                     }
                 } else {
                     if (has_e) dst[u - u_lo] = ye;
